@@ -1,0 +1,36 @@
+// kernels.h -- internal launch interfaces between the C ABI (hip_api.hip) and
+// the gfx950 kernels.  Not installed; the public surface is include/*.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace crp {
+
+struct SpmmArgs
+{
+    int nrow;
+    int n;
+    const int    *rowptr;
+    const int    *colidx;
+    const double *val;
+    const double *B0;
+    int64_t       ldB0;
+    const double *B1;
+    int64_t       ldB1;
+    double       *C;
+    int64_t       ldC;
+};
+
+// spmm_kernels.hip
+hipError_t spmm_rm_f64_rowgroup(const SpmmArgs &a, hipStream_t s);
+hipError_t spmm_cm_f64(const SpmmArgs &a, hipStream_t s);
+
+// row_kernels.hip
+hipError_t gather_rows_f64(int layout, int nidx, int n, const int *ridx, const double *src, int64_t lds,
+                           double *dst, int64_t ldd, hipStream_t s);
+hipError_t scatter_rows_f64(int layout, int nidx, int n, const int *ridx, const double *src, int64_t lds,
+                            double *dst, int64_t ldd, hipStream_t s);
+hipError_t transpose_f64(int nrow, int ncol, const double *src, int64_t lds, double *dst, int64_t ldd,
+                         hipStream_t s);
+
+}  // namespace crp

@@ -1,0 +1,318 @@
+// mpi_facade.cpp -- lib/libcrpspmm.so: the reference's MPI-typed API
+// (include/rowpara_spmm.h, include/para2d_spmm.h) on top of the communicator-
+// agnostic engines (include/crp_engine.h).
+//
+// crp_comm_t over MPI: the control-plane members call the same MPI routines the
+// reference calls (src/rowpara_spmm.c:154-162,439-442; src/para2d_spmm.c:41-83).
+// The per-multiply B exchange moves DEVICE buffers; with a plain (not GPU-aware)
+// MPI it is staged through pinned host buffers the way the reference's
+// mat_redist stages CUDA memory (src/mat_redist.c:362-378), honouring RP_SPMM_P2P
+// (ring-ordered Isend/Irecv, src/rowpara_spmm.c:275-303) or MPI_Alltoallv (:305-308).
+#include <limits.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include <mpi.h>
+#include "crp_engine.h"
+#include "crpspmm_hip.h"
+#include "para2d_spmm.h"
+#include "rowpara_spmm.h"
+#include "utils.h"
+
+namespace {
+
+struct MpiCtx
+{
+    MPI_Comm comm;
+    bool     owned;
+    int      p2p;
+    std::vector<double> hsend, hrecv;   // host staging of the device exchange
+};
+
+void m_alltoall(void *c, const int *s, int *r, int count)
+{
+    MPI_Alltoall(s, count, MPI_INT, r, count, MPI_INT, ((MpiCtx *) c)->comm);
+}
+void m_alltoallv(void *c, const int *s, const int *sc, const int *sd, int *r, const int *rc, const int *rd)
+{
+    MPI_Alltoallv(s, sc, sd, MPI_INT, r, rc, rd, MPI_INT, ((MpiCtx *) c)->comm);
+}
+void m_allgatherv(void *c, const void *s, size_t sb, void *r, const size_t *rb, const size_t *rd)
+{
+    MpiCtx *x = (MpiCtx *) c;
+    int P;
+    MPI_Comm_size(x->comm, &P);
+    std::vector<int> cnt(P), dsp(P);
+    for (int i = 0; i < P; i++)
+    {
+        ASSERT_PRINTF(rb[i] <= INT_MAX && rd[i] <= INT_MAX, "allgatherv piece exceeds 2 GiB\n");
+        cnt[i] = (int) rb[i];
+        dsp[i] = (int) rd[i];
+    }
+    MPI_Allgatherv(s, (int) sb, MPI_BYTE, r, cnt.data(), dsp.data(), MPI_BYTE, x->comm);
+}
+void m_barrier(void *c) { MPI_Barrier(((MpiCtx *) c)->comm); }
+void m_red_f64(void *c, const double *in, double *out, int n, int op)
+{
+    MPI_Reduce(in, out, n, MPI_DOUBLE, op == CRP_OP_MAX ? MPI_MAX : MPI_SUM, 0, ((MpiCtx *) c)->comm);
+}
+void m_red_u64(void *c, const uint64_t *in, uint64_t *out, int n, int op)
+{
+    MPI_Reduce(in, out, n, MPI_UINT64_T, op == CRP_OP_MAX ? MPI_MAX : MPI_SUM, 0, ((MpiCtx *) c)->comm);
+}
+
+void m_alltoallv_dev(void *c, const double *send_dev, const long long *sc, const long long *sd, double *recv_dev,
+                     const long long *rc, const long long *rd, void *stream)
+{
+    MpiCtx *x = (MpiCtx *) c;
+    int P, me;
+    MPI_Comm_size(x->comm, &P);
+    MPI_Comm_rank(x->comm, &me);
+    const long long ns = sd[P], nr = rd[P];
+    if ((long long) x->hsend.size() < ns) x->hsend.resize((size_t) ns);
+    if ((long long) x->hrecv.size() < nr) x->hrecv.resize((size_t) nr);
+    if (ns > 0)
+    {
+        int rc_ = crp_dev_memcpy(x->hsend.data(), send_dev, sizeof(double) * (size_t) ns, 1, stream);
+        ASSERT_PRINTF(rc_ == 0, "device -> host staging failed (%d)\n", rc_);
+    }
+    crp_stream_sync(stream);
+    std::vector<MPI_Request> reqs;
+    reqs.reserve(2 * (size_t) P);
+    const long long chunk = INT_MAX / 2;   // counts are int in MPI: split large messages
+    for (int i = 1; i < P; i++)
+    {
+        const int src = (me + i) % P;
+        for (long long off = 0; off < rc[src]; off += chunk)
+        {
+            const int cnt = (int) ((rc[src] - off < chunk) ? rc[src] - off : chunk);
+            reqs.emplace_back();
+            MPI_Irecv(x->hrecv.data() + rd[src] + off, cnt, MPI_DOUBLE, src, src, x->comm, &reqs.back());
+        }
+    }
+    for (int i = 1; i < P; i++)
+    {
+        const int dst = (me - i + P) % P;
+        for (long long off = 0; off < sc[dst]; off += chunk)
+        {
+            const int cnt = (int) ((sc[dst] - off < chunk) ? sc[dst] - off : chunk);
+            reqs.emplace_back();
+            MPI_Isend(x->hsend.data() + sd[dst] + off, cnt, MPI_DOUBLE, dst, me, x->comm, &reqs.back());
+        }
+    }
+    MPI_Waitall((int) reqs.size(), reqs.data(), MPI_STATUSES_IGNORE);
+    if (nr > 0)
+    {
+        int rc_ = crp_dev_memcpy(recv_dev, x->hrecv.data(), sizeof(double) * (size_t) nr, 0, stream);
+        ASSERT_PRINTF(rc_ == 0, "host -> device staging failed (%d)\n", rc_);
+    }
+}
+
+crp_comm_t *wrap(MPI_Comm comm, bool owned);
+
+crp_comm_t *m_split(void *c, int color, int key)
+{
+    MPI_Comm sub;
+    MPI_Comm_split(((MpiCtx *) c)->comm, color, key, &sub);
+    return wrap(sub, true);
+}
+
+void m_free(crp_comm_t *self)
+{
+    MpiCtx *x = (MpiCtx *) self->ctx;
+    if (x->owned) MPI_Comm_free(&x->comm);
+    delete x;
+    free(self);
+}
+
+crp_comm_t *wrap(MPI_Comm comm, bool owned)
+{
+    crp_comm_t *c = (crp_comm_t *) calloc(1, sizeof(crp_comm_t));
+    MpiCtx *x = new MpiCtx;
+    x->comm = comm;
+    x->owned = owned;
+    GET_ENV_INT_VAR(x->p2p, "RP_SPMM_P2P", "rB_p2p", 1, 0, 1, 0);
+    c->ctx = x;
+    MPI_Comm_size(comm, &c->nproc);
+    MPI_Comm_rank(comm, &c->rank);
+    c->alltoall_i32 = m_alltoall;
+    c->alltoallv_i32 = m_alltoallv;
+    c->allgatherv_bytes = m_allgatherv;
+    c->barrier = m_barrier;
+    c->reduce_f64 = m_red_f64;
+    c->reduce_u64 = m_red_u64;
+    c->alltoallv_dev_f64 = m_alltoallv_dev;
+    c->split = m_split;
+    c->free = m_free;
+    return c;
+}
+
+// one GPU per rank, chosen from the launcher's local-rank variable
+// (same variables as /root/reference/deprecated/src/cuda_proxy.cu:11-46)
+void select_device_once()
+{
+    static bool done = false;
+    if (done) return;
+    done = true;
+    const char *names[] = {"MPI_LOCALRANKID", "MV2_COMM_WORLD_LOCAL_RANK", "OMPI_COMM_WORLD_NODE_RANK",
+                           "OMPI_COMM_WORLD_LOCAL_RANK", "SLURM_LOCALID", "PBS_O_VNODENUM", "PMI_RANK", "LOCAL_RANK"};
+    int local = 0, ndev = 0;
+    for (const char *nm : names)
+    {
+        const char *v = getenv(nm);
+        if (v != NULL) { local = atoi(v); break; }
+    }
+    if (crp_hip_device_count(&ndev) == 0 && ndev > 0) crp_hip_set_device(local % ndev);
+}
+
+struct RpGlue
+{
+    crp_rp_spmm_p eng = nullptr;
+    crp_comm_t   *comm = nullptr;   // wrapper we own (not the MPI_Comm itself)
+    bool          own_eng = true;
+    std::vector<int> scnts, sdispls, rcnts, rdispls;
+};
+
+int sat(long long v) { return v > INT_MAX ? INT_MAX : (int) v; }
+
+void sync_public(rp_spmm_p s)
+{
+    RpGlue *g = (RpGlue *) s->impl;
+    crp_rp_plan_view_t v;
+    crp_rp_spmm_get_plan(g->eng, &v);
+    s->nproc = v.nproc; s->my_rank = v.my_rank; s->glb_n = v.glb_n; s->A_nrow = v.A_nrow; s->rB_nrow = v.rB_nrow;
+    s->rB_self_src_offset = v.rB_self_src_offset; s->rB_self_dst_offset = v.rB_self_dst_offset;
+    s->rB_self_nrow = v.rB_self_nrow; s->rB_p2p = v.rB_p2p; s->rB_reidx = v.rB_reidx;
+    s->A_rowptr = (int *) v.A_rowptr; s->A_colidx = (int *) v.A_colidx; s->A_val = (double *) v.A_val;
+    s->rB_self_src_ridxs = (int *) v.rB_self_src_ridxs;
+    s->rB_sridxs = (int *) v.rB_sridxs; s->rB_rridxs = (int *) v.rB_rridxs;
+    const int P = v.nproc;
+    g->scnts.resize(P); g->rcnts.resize(P); g->sdispls.resize(P + 1); g->rdispls.resize(P + 1);
+    for (int q = 0; q < P; q++) { g->scnts[q] = sat(v.rB_scnts[q]); g->rcnts[q] = sat(v.rB_rcnts[q]); }
+    for (int q = 0; q <= P; q++) { g->sdispls[q] = sat(v.rB_sdispls[q]); g->rdispls[q] = sat(v.rB_rdispls[q]); }
+    s->rB_scnts = g->scnts.data(); s->rB_sdispls = g->sdispls.data();
+    s->rB_rcnts = g->rcnts.data(); s->rB_rdispls = g->rdispls.data();
+    s->rB_recv_size = v.rB_recv_size; s->n_exec = v.n_exec;
+    s->t_init = v.t_init; s->t_pack = v.t_pack; s->t_a2a = v.t_a2a; s->t_unpack = v.t_unpack;
+    s->t_spmm = v.t_spmm; s->t_exec = v.t_exec;
+}
+
+struct P2dGlue
+{
+    crp_para2d_spmm_p eng = nullptr;
+    crp_comm_t       *comm = nullptr;
+};
+
+}  // namespace
+
+extern "C" {
+
+void rp_spmm_init(const int A_srow, const int A_nrow, const int *A_rowptr, const int *A_colidx, const double *A_val,
+                  const int *B_row_displs, const int glb_n, MPI_Comm comm, rp_spmm_p *rp_spmm)
+{
+    select_device_once();
+    rp_spmm_p s = (rp_spmm_p) calloc(1, sizeof(rp_spmm_s));
+    RpGlue *g = new RpGlue;
+    g->comm = wrap(comm, false);
+    crp_rp_spmm_init(A_srow, A_nrow, A_rowptr, A_colidx, A_val, B_row_displs, glb_n, g->comm, &g->eng);
+    s->impl = g;
+    s->comm = comm;
+    sync_public(s);
+    *rp_spmm = s;
+}
+
+void rp_spmm_free(rp_spmm_p *rp_spmm)
+{
+    if (rp_spmm == NULL || *rp_spmm == NULL) return;
+    rp_spmm_p s = *rp_spmm;
+    RpGlue *g = (RpGlue *) s->impl;
+    if (g->own_eng) crp_rp_spmm_free(&g->eng);
+    if (g->comm) g->comm->free(g->comm);
+    delete g;
+    free(s);
+    *rp_spmm = NULL;
+}
+
+void rp_spmm_exec(rp_spmm_p s, const int BC_layout, const double *B, const int ldB, double *C, const int ldC)
+{
+    if (s == NULL) return;
+    RpGlue *g = (RpGlue *) s->impl;
+    crp_rp_spmm_exec(g->eng, BC_layout, B, ldB, C, ldC);
+    sync_public(s);
+}
+
+void rp_spmm_print_stat(rp_spmm_p s)
+{
+    if (s == NULL) return;
+    crp_rp_spmm_print_stat(((RpGlue *) s->impl)->eng);
+}
+
+void rp_spmm_clear_stat(rp_spmm_p s)
+{
+    if (s == NULL) return;
+    crp_rp_spmm_clear_stat(((RpGlue *) s->impl)->eng);
+    sync_public(s);
+}
+
+void para2d_spmm_init(MPI_Comm comm, const int pm, const int pn, const int *A0_rowptr, const int *B_rowptr,
+                      const int *AC_rowptr, const int *BC_colptr, const int *A_rowptr, const int *A_colidx,
+                      const double *A_val, para2d_spmm_p *para2d_spmm)
+{
+    select_device_once();
+    para2d_spmm_p s = (para2d_spmm_p) calloc(1, sizeof(para2d_spmm_s));
+    P2dGlue *g = new P2dGlue;
+    g->comm = wrap(comm, false);
+    crp_para2d_spmm_init(g->comm, pm, pn, A0_rowptr, B_rowptr, AC_rowptr, BC_colptr, A_rowptr, A_colidx, A_val,
+                         &g->eng);
+    s->impl = g;
+    s->comm_glb = comm;
+    s->comm_col = MPI_COMM_NULL;   // owned by the engine's communicator wrapper
+    s->rA_cost = crp_para2d_spmm_rA_cost(g->eng);
+    s->t_ag_A = crp_para2d_spmm_t_ag_A(g->eng);
+    // public 1D view over the engine's inner rp engine (not owned by the view)
+    rp_spmm_p v = (rp_spmm_p) calloc(1, sizeof(rp_spmm_s));
+    RpGlue *rg = new RpGlue;
+    rg->eng = crp_para2d_spmm_rp(g->eng);
+    rg->own_eng = false;
+    v->impl = rg;
+    v->comm = MPI_COMM_NULL;
+    sync_public(v);
+    s->rp_spmm = v;
+    *para2d_spmm = s;
+}
+
+void para2d_spmm_free(para2d_spmm_p *para2d_spmm)
+{
+    if (para2d_spmm == NULL || *para2d_spmm == NULL) return;
+    para2d_spmm_p s = *para2d_spmm;
+    P2dGlue *g = (P2dGlue *) s->impl;
+    rp_spmm_free(&s->rp_spmm);
+    crp_para2d_spmm_free(&g->eng);
+    if (g->comm) g->comm->free(g->comm);
+    delete g;
+    free(s);
+    *para2d_spmm = NULL;
+}
+
+void para2d_spmm_exec(para2d_spmm_p s, const int BC_layout, const double *B, const int ldB, double *C, const int ldC)
+{
+    if (s == NULL) return;
+    crp_para2d_spmm_exec(((P2dGlue *) s->impl)->eng, BC_layout, B, ldB, C, ldC);
+    sync_public(s->rp_spmm);
+}
+
+void para2d_spmm_print_stat(para2d_spmm_p s)
+{
+    if (s == NULL) return;
+    crp_para2d_spmm_print_stat(((P2dGlue *) s->impl)->eng);
+}
+
+void para2d_spmm_clear_stat(para2d_spmm_p s)
+{
+    if (s == NULL) return;
+    crp_para2d_spmm_clear_stat(((P2dGlue *) s->impl)->eng);
+    sync_public(s->rp_spmm);
+}
+
+}  // extern "C"

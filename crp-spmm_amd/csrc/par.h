@@ -1,0 +1,53 @@
+// par.h -- minimal host parallel-for on std::thread (the library deliberately
+// does not link an OpenMP runtime: it is loaded into processes, e.g. Python
+// with torch, that already carry one).
+#pragma once
+#include <algorithm>
+#include <atomic>
+#include <cstdlib>
+#include <thread>
+#include <vector>
+
+namespace crp {
+
+inline int host_threads()
+{
+    const char *e = getenv("CRPSPMM_NUM_THREADS");
+    if (e == nullptr) e = getenv("OMP_NUM_THREADS");
+    int n = e ? atoi(e) : 0;
+    if (n <= 0) n = (int) std::thread::hardware_concurrency();
+    if (n <= 0) n = 1;
+    return std::min(n, 64);
+}
+
+// fn(begin, end, thread_id) over [0, n) in dynamically claimed chunks.
+template <typename F>
+void parallel_chunks(long long n, long long chunk, F fn)
+{
+    if (n <= 0) return;
+    if (chunk < 1) chunk = 1;
+    const long long nchunks = (n + chunk - 1) / chunk;
+    const int nthr = (int) std::min<long long>(host_threads(), nchunks);
+    if (nthr <= 1)
+    {
+        fn(0LL, n, 0);
+        return;
+    }
+    std::atomic<long long> next(0);
+    auto worker = [&](int tid) {
+        for (;;)
+        {
+            const long long c = next.fetch_add(1);
+            if (c >= nchunks) break;
+            const long long b = c * chunk;
+            fn(b, std::min(n, b + chunk), tid);
+        }
+    };
+    std::vector<std::thread> pool;
+    pool.reserve((size_t) nthr - 1);
+    for (int t = 1; t < nthr; t++) pool.emplace_back(worker, t);
+    worker(0);
+    for (auto &th : pool) th.join();
+}
+
+}  // namespace crp

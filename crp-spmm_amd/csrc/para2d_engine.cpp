@@ -1,0 +1,205 @@
+// para2d_engine.cpp -- the 2D (pm x pn) engine (include/crp_engine.h).
+//
+// Follows /root/reference/src/para2d_spmm.c:20-205: rank r sits at
+// (pi, pj) = (r / pn, r % pn); the pn ranks of a grid row pool their A0 slices
+// into the row panel AC_rowptr[pi] .. AC_rowptr[pi+1] (one-time replication,
+// reference :56-98), then a 1D row-parallel engine runs inside each grid
+// column on the BC_colptr[pj] .. BC_colptr[pj+1] columns of B and C.
+// The panel is assembled on the host through the communicator's allgatherv
+// and uploaded once by the 1D engine; the replication-cost statistic is
+// computed without the reference's rank (P-1) -> rank 0 message, which
+// deadlocks at one rank (reference :102-109).
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "crp_engine.h"
+#include "utils.h"
+
+struct crp_para2d_spmm
+{
+    crp_rp_spmm_p rp = nullptr;
+    crp_comm_t   *comm_glb = nullptr;   // not owned
+    crp_comm_t   *comm_col = nullptr;   // owned
+    size_t rA_cost = 0;
+    double t_init = 0.0, t_ag_A = 0.0;
+};
+
+extern "C" {
+
+static void para2d_init_common(crp_comm_t *comm, int pm, int pn, const int *A0_rowptr, const int *B_rowptr,
+                               const int *AC_rowptr, const int *BC_colptr, const int *A_rowptr, const int *A_colidx,
+                               const double *A_val, crp_para2d_spmm_p *out, bool plan_only)
+{
+    ASSERT_PRINTF(out != NULL && comm != NULL && pm > 0 && pn > 0 && comm->nproc == pm * pn,
+                  "para2d_spmm_init: grid %d x %d does not match %d ranks\n", pm, pn, comm ? comm->nproc : -1);
+    (void) AC_rowptr;   // implied by A0_rowptr, exactly as in the reference (:49-52)
+    crp_para2d_spmm *e = new crp_para2d_spmm;
+    e->comm_glb = comm;
+    double t0 = get_wtime_sec();
+    const int r = comm->rank, pi = r / pn, pj = r % pn;
+    crp_comm_t *comm_row = comm->split(comm->ctx, pi, pj);
+    e->comm_col = comm->split(comm->ctx, pj, pi);
+    e->t_init += get_wtime_sec() - t0;
+
+    // ---- replicate the row panel inside the grid row (reference :49-99)
+    t0 = get_wtime_sec();
+    const int my_nrow = A0_rowptr[r + 1] - A0_rowptr[r];
+    const int my_nnz  = A_rowptr[my_nrow] - A_rowptr[0];
+    const int p_srow  = A0_rowptr[pi * pn];
+    const int p_nrow  = A0_rowptr[(pi + 1) * pn] - p_srow;
+    std::vector<int>    p_rowptr((size_t) p_nrow + 1, 0), p_colidx;
+    std::vector<double> p_val;
+    if (pn > 1)
+    {
+        std::vector<size_t> cnt(pn), dsp(pn);
+        std::vector<int> nnzs(pn);
+        for (int j = 0; j < pn; j++) { cnt[j] = sizeof(int); dsp[j] = sizeof(int) * (size_t) j; }
+        comm_row->allgatherv_bytes(comm_row->ctx, &my_nnz, sizeof(int), nnzs.data(), cnt.data(), dsp.data());
+        // row pointers carry global nnz offsets, so the slices concatenate into one monotone array
+        size_t off = 0;
+        for (int j = 0; j < pn; j++)
+        {
+            const int rk = pi * pn + j;
+            cnt[j] = sizeof(int) * (size_t) (A0_rowptr[rk + 1] - A0_rowptr[rk]);
+            dsp[j] = off;
+            off += cnt[j];
+        }
+        comm_row->allgatherv_bytes(comm_row->ctx, A_rowptr, cnt[pj], p_rowptr.data(), cnt.data(), dsp.data());
+        long long p_nnz = 0;
+        for (int j = 0; j < pn; j++) p_nnz += nnzs[j];
+        // the gathered entries are the first row pointer of every row; an empty leading slice
+        // starts where the next one does, so entry 0 is already the panel's first offset
+        if (p_nrow == 0) p_rowptr[0] = 0;
+        p_rowptr[p_nrow] = p_rowptr[0] + (int) p_nnz;
+        p_colidx.resize((size_t) (p_nnz > 0 ? p_nnz : 1));
+        p_val.resize((size_t) (p_nnz > 0 ? p_nnz : 1));
+        off = 0;
+        for (int j = 0; j < pn; j++) { cnt[j] = sizeof(int) * (size_t) nnzs[j]; dsp[j] = off; off += cnt[j]; }
+        comm_row->allgatherv_bytes(comm_row->ctx, A_colidx, cnt[pj], p_colidx.data(), cnt.data(), dsp.data());
+        off = 0;
+        for (int j = 0; j < pn; j++) { cnt[j] = sizeof(double) * (size_t) nnzs[j]; dsp[j] = off; off += cnt[j]; }
+        comm_row->allgatherv_bytes(comm_row->ctx, A_val, cnt[pj], p_val.data(), cnt.data(), dsp.data());
+    }
+    else
+    {
+        memcpy(p_rowptr.data(), A_rowptr, sizeof(int) * ((size_t) p_nrow + 1));
+        p_colidx.assign(A_colidx, A_colidx + my_nnz);
+        p_val.assign(A_val, A_val + my_nnz);
+        if (my_nnz == 0) { p_colidx.resize(1); p_val.resize(1); }
+    }
+    e->t_ag_A += get_wtime_sec() - t0;
+
+    // ---- replication cost statistic: floor(1.5 * nnz(A) * (pn - 1)), nnz(A) = end of the last
+    //      rank's global row pointer (reference :100-106), shared without a point-to-point message
+    {
+        const int P = comm->nproc;
+        std::vector<int> ends(P);
+        std::vector<size_t> cnt(P, sizeof(int)), dsp(P);
+        for (int q = 0; q < P; q++) dsp[q] = sizeof(int) * (size_t) q;
+        const int my_end = A_rowptr[my_nrow];
+        comm->allgatherv_bytes(comm->ctx, &my_end, sizeof(int), ends.data(), cnt.data(), dsp.data());
+        e->rA_cost = (size_t) ((double) ends[P - 1] * (double) (pn - 1) * 1.5);
+    }
+
+    // ---- 1D engine on the grid column (reference :111-118)
+    t0 = get_wtime_sec();
+    const int n_loc = BC_colptr[pj + 1] - BC_colptr[pj];
+    if (plan_only)
+        crp_rp_spmm_init_plan_only(p_srow, p_nrow, p_rowptr.data(), p_colidx.data(), p_val.data(), B_rowptr, n_loc,
+                                   e->comm_col, &e->rp);
+    else
+        crp_rp_spmm_init(p_srow, p_nrow, p_rowptr.data(), p_colidx.data(), p_val.data(), B_rowptr, n_loc,
+                         e->comm_col, &e->rp);
+    e->t_init += get_wtime_sec() - t0;
+    comm_row->free(comm_row);
+    *out = e;
+}
+
+void crp_para2d_spmm_init(crp_comm_t *comm, int pm, int pn, const int *A0_rowptr, const int *B_rowptr,
+                          const int *AC_rowptr, const int *BC_colptr, const int *A_rowptr, const int *A_colidx,
+                          const double *A_val, crp_para2d_spmm_p *out)
+{
+    para2d_init_common(comm, pm, pn, A0_rowptr, B_rowptr, AC_rowptr, BC_colptr, A_rowptr, A_colidx, A_val, out, false);
+}
+
+void crp_para2d_spmm_init_plan_only(crp_comm_t *comm, int pm, int pn, const int *A0_rowptr, const int *B_rowptr,
+                                    const int *AC_rowptr, const int *BC_colptr, const int *A_rowptr,
+                                    const int *A_colidx, const double *A_val, crp_para2d_spmm_p *out)
+{
+    para2d_init_common(comm, pm, pn, A0_rowptr, B_rowptr, AC_rowptr, BC_colptr, A_rowptr, A_colidx, A_val, out, true);
+}
+
+void crp_para2d_spmm_free(crp_para2d_spmm_p *p)
+{
+    if (p == NULL || *p == NULL) return;
+    crp_para2d_spmm *e = *p;
+    crp_rp_spmm_free(&e->rp);
+    if (e->comm_col) e->comm_col->free(e->comm_col);
+    delete e;
+    *p = NULL;
+}
+
+void crp_para2d_spmm_exec(crp_para2d_spmm_p e, int BC_layout, const double *B, int ldB, double *C, int ldC)
+{
+    if (e == NULL) return;
+    crp_rp_spmm_exec(e->rp, BC_layout, B, ldB, C, ldC);
+}
+
+void crp_para2d_spmm_exec_ex(crp_para2d_spmm_p e, int BC_layout, const double *B, long long ldB, double *C,
+                             long long ldC, void *stream)
+{
+    if (e == NULL) return;
+    crp_rp_spmm_exec_ex(e->rp, BC_layout, B, ldB, C, ldC, stream);
+}
+
+void crp_para2d_spmm_print_stat(crp_para2d_spmm_p e)
+{
+    if (e == NULL) return;
+    crp_rp_plan_view_t v;
+    crp_rp_spmm_get_plan(e->rp, &v);
+    if (v.n_exec == 0) return;
+    crp_comm_t *c = e->comm_glb;
+    const int P = c->nproc;
+    uint64_t recv = (uint64_t) v.rB_recv_size * (uint64_t) v.glb_n, recv_max = 0, recv_sum = 0;
+    double raw[7] = {e->t_init, e->t_ag_A, v.t_pack, v.t_a2a, v.t_unpack, v.t_spmm, v.t_exec}, tmax[7], tavg[7];
+    c->reduce_u64(c->ctx, &recv, &recv_max, 1, CRP_OP_MAX);
+    c->reduce_u64(c->ctx, &recv, &recv_sum, 1, CRP_OP_SUM);
+    c->reduce_f64(c->ctx, raw, tmax, 7, CRP_OP_MAX);
+    c->reduce_f64(c->ctx, raw, tavg, 7, CRP_OP_SUM);
+    if (c->rank != 0) return;
+    for (int i = 2; i <= 6; i++)
+    {
+        tmax[i] /= v.n_exec;
+        tavg[i] /= ((double) v.n_exec * P);
+    }
+    tavg[1] /= P;
+    // same lines as src/para2d_spmm.c:183-196
+    printf("para2d_spmm_init() time = %.2f s\n", tmax[0]);
+    printf("Total comm size for replicating A = %zu\n", e->rA_cost);
+    printf("Total comm size for replicating B = %zu\n", (size_t) recv_sum);
+    printf("Total comm size for SpMM          = %zu\n", e->rA_cost + (size_t) recv_sum);
+    printf("-------------------- Runtime (s) --------------------\n");
+    printf("                                     avg         max\n");
+    printf("Replicate A matrix (once)         %6.3f      %6.3f\n", tavg[1], tmax[1]);
+    printf("Pack B matrix for redistribution  %6.3f      %6.3f\n", tavg[2], tmax[2]);
+    printf("Redistribute B matrix             %6.3f      %6.3f\n", tavg[3], tmax[3]);
+    printf("Unpack received B matrix data     %6.3f      %6.3f\n", tavg[4], tmax[4]);
+    printf("Local SpMM                        %6.3f      %6.3f\n", tavg[5], tmax[5]);
+    printf("Total para2d_spmm_exec()          %6.3f      %6.3f\n", tavg[6], tmax[6]);
+    printf("Replicate A + para2d_spmm_exec()  %6.3f      %6.3f\n", tavg[1] + tavg[6], tmax[1] + tmax[6]);
+    printf("\n");
+    fflush(stdout);
+}
+
+void crp_para2d_spmm_clear_stat(crp_para2d_spmm_p e)
+{
+    if (e == NULL) return;
+    crp_rp_spmm_clear_stat(e->rp);
+}
+
+crp_rp_spmm_p crp_para2d_spmm_rp(crp_para2d_spmm_p e) { return e ? e->rp : NULL; }
+size_t crp_para2d_spmm_rA_cost(crp_para2d_spmm_p e) { return e ? e->rA_cost : 0; }
+double crp_para2d_spmm_t_ag_A(crp_para2d_spmm_p e) { return e ? e->t_ag_A : 0.0; }
+
+}  // extern "C"

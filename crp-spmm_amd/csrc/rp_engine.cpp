@@ -1,0 +1,506 @@
+// rp_engine.cpp -- the 1D row-parallel SpMM engine (include/crp_engine.h).
+//
+// Host side of /root/reference/src/rowpara_spmm.c re-thought for a device-
+// resident data path:
+//   init  (reference :20-190): one pass builds the needed-row flags, a prefix
+//         rank array gives the compact ids, the needs are exchanged through the
+//         communicator's alltoall(v); A is uploaded once with a two-source column
+//         index (local B row | row of the receive buffer), so exec never copies
+//         locally owned B rows and never unpacks.
+//   exec  (reference :212-422): gather kernel -> device all-to-all -> SpMM kernel
+//         on one stream; no allocation, no sparse-handle creation.
+// Public plan fields keep the reference's meaning (crp_rp_plan_view_t).
+#include <limits.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "crp_engine.h"
+#include "crpspmm_hip.h"
+#include "utils.h"
+
+struct crp_rp_spmm
+{
+    // ---- plan, reference field names (src/rowpara_spmm.h:8-40)
+    int nproc = 1, my_rank = 0, glb_n = 0, A_nrow = 0, rB_nrow = 0;
+    int rB_self_src_offset = 0, rB_self_dst_offset = 0, rB_self_nrow = 0;
+    int rB_p2p = 1, rB_reidx = 1;
+    std::vector<int>       A_rowptr, A_colidx;
+    std::vector<double>    A_val;
+    std::vector<int>       rB_self_src_ridxs, rB_sridxs, rB_rridxs;
+    std::vector<long long> rB_scnts, rB_sdispls, rB_rcnts, rB_rdispls;
+    size_t rB_recv_size = 0;
+    int    n_exec = 0;
+    double t_init = 0, t_pack = 0, t_a2a = 0, t_unpack = 0, t_spmm = 0, t_exec = 0;
+    crp_comm_t *comm = nullptr;
+
+    // ---- device side
+    bool plan_only = false;
+    int  timing = 1, variant = 0;
+    int  loc_B_nrow = 0;
+    long long n_send_rows = 0, n_recv_rows = 0, n_needed_rows = 0;
+    std::vector<int> dev_colidx_host;
+    crp_csr_dev_p A_dev = nullptr;
+    int    *sridxs_dev = nullptr;
+    double *sendbuf_dev = nullptr, *recvbuf_dev = nullptr;
+    void   *stream = nullptr;
+    // staging (host-pointer API) and column-major temporaries, grown on demand
+    double *B_stage = nullptr, *C_stage = nullptr, *B_rm = nullptr, *C_rm = nullptr;
+    size_t  B_stage_sz = 0, C_stage_sz = 0, B_rm_sz = 0, C_rm_sz = 0;
+};
+
+#define HIP_OK(call)                                                              \
+    do {                                                                          \
+        int rc__ = (call);                                                        \
+        ASSERT_PRINTF(rc__ == 0, "%s failed with code %d\n", #call, rc__);        \
+    } while (0)
+
+static void grow(double **buf, size_t *cur, size_t need_elems)
+{
+    if (need_elems <= *cur) return;
+    if (*buf) HIP_OK(crp_dev_free(*buf));
+    void *p = NULL;
+    HIP_OK(crp_dev_malloc(&p, need_elems * sizeof(double)));
+    *buf = (double *) p;
+    *cur = need_elems;
+}
+
+// ---------------------------------------------------------------------------
+static void build_plan(crp_rp_spmm *e, int A_nrow, const int *A_rowptr, const int *A_colidx,
+                       const double *A_val, const int *B_row_displs, int glb_n, crp_comm_t *comm)
+{
+    const int P = comm->nproc, me = comm->rank;
+    e->nproc = P;
+    e->my_rank = me;
+    e->glb_n = glb_n;
+    e->A_nrow = A_nrow;
+    e->comm = comm;
+    GET_ENV_INT_VAR(e->rB_p2p, "RP_SPMM_P2P", "rB_p2p", 1, 0, 1, me == 0);
+    GET_ENV_INT_VAR(e->rB_reidx, "RP_SPMM_REIDX", "rB_reidx", 1, 0, 1, me == 0);
+
+    const int    base = A_rowptr[0];
+    const size_t nnz  = (size_t) ((long long) A_rowptr[A_nrow] - (long long) base);
+    const int    glb_k = B_row_displs[P];
+    const int    lo = B_row_displs[me], hi = B_row_displs[me + 1];
+    e->loc_B_nrow = hi - lo;
+
+    // needed-row flags and the span of touched columns
+    std::vector<unsigned char> flag((size_t) glb_k + 1, 0);
+    int cmin = INT_MAX, cmax = -1;
+    for (size_t p = 0; p < nnz; p++)
+    {
+        const int c = A_colidx[p];
+        ASSERT_PRINTF(c >= 0 && c < glb_k, "column index %d outside B (%d rows)\n", c, glb_k);
+        flag[c] = 1;
+        if (c < cmin) cmin = c;
+        if (c > cmax) cmax = c;
+    }
+    if (nnz == 0) { cmin = 0; cmax = -1; }
+
+    // rank_[g] = number of needed rows with global index < g
+    std::vector<int> rank_((size_t) glb_k + 1);
+    int run = 0;
+    for (int g = 0; g < glb_k; g++)
+    {
+        rank_[g] = run;
+        run += flag[g];
+    }
+    rank_[glb_k] = run;
+    const int n_needed = run;
+    e->n_needed_rows = n_needed;
+    e->rB_nrow = e->rB_reidx ? n_needed : (cmax - cmin + 1);
+
+    // rebased / re-indexed copy of A (public plan fields)
+    e->A_rowptr.resize((size_t) A_nrow + 1);
+    for (int i = 0; i <= A_nrow; i++) e->A_rowptr[i] = A_rowptr[i] - base;
+    e->A_colidx.resize(nnz);
+    e->A_val.assign(A_val, A_val + nnz);
+    for (size_t p = 0; p < nnz; p++)
+        e->A_colidx[p] = e->rB_reidx ? rank_[A_colidx[p]] : (A_colidx[p] - cmin);
+
+    // rows served from this rank's own block of B
+    const int self_n = rank_[hi] - rank_[lo];
+    e->rB_self_nrow = self_n;
+    e->rB_self_src_ridxs.clear();
+    e->rB_self_src_ridxs.reserve((size_t) self_n);
+    for (int g = lo; g < hi; g++)
+        if (flag[g]) e->rB_self_src_ridxs.push_back(g);
+    if (self_n > 0)
+    {
+        const int first = e->rB_self_src_ridxs[0];
+        e->rB_self_src_offset = first - lo;
+        e->rB_self_dst_offset = e->rB_reidx ? rank_[first] : (first - cmin);
+    }
+
+    // rows to fetch, grouped by owner (owners hold ascending contiguous ranges,
+    // so ascending global order is already owner order)
+    std::vector<int> rcnt(P, 0), rdsp(P + 1, 0), need_glb;
+    need_glb.reserve((size_t) (n_needed - self_n));
+    for (int q = 0; q < P; q++)
+    {
+        if (q != me)
+            for (int g = B_row_displs[q]; g < B_row_displs[q + 1]; g++)
+                if (flag[g]) need_glb.push_back(g);
+        rdsp[q + 1] = (int) need_glb.size();
+        rcnt[q] = rdsp[q + 1] - rdsp[q];
+    }
+    e->n_recv_rows = rdsp[P];
+    e->rB_recv_size = (size_t) rdsp[P];
+
+    // tell every owner which of its rows are wanted (reference :152-165)
+    std::vector<int> scnt(P, 0), sdsp(P + 1, 0);
+    comm->alltoall_i32(comm->ctx, rcnt.data(), scnt.data(), 1);
+    for (int q = 0; q < P; q++) sdsp[q + 1] = sdsp[q] + scnt[q];
+    e->n_send_rows = sdsp[P];
+    e->rB_sridxs.assign((size_t) sdsp[P] + 1, 0);
+    if (need_glb.empty()) need_glb.push_back(0);   // keep .data() valid for empty lists
+    comm->alltoallv_i32(comm->ctx, need_glb.data(), rcnt.data(), rdsp.data(), e->rB_sridxs.data(), scnt.data(),
+                        sdsp.data());
+    e->rB_sridxs.resize((size_t) sdsp[P]);
+    for (auto &r : e->rB_sridxs)
+    {
+        ASSERT_PRINTF(r >= lo && r < hi, "peer requested row %d outside my block [%d, %d)\n", r, lo, hi);
+        r -= lo;
+    }
+
+    e->rB_rridxs.resize((size_t) rdsp[P]);
+    for (int i = 0; i < rdsp[P]; i++)
+        e->rB_rridxs[i] = e->rB_reidx ? rank_[need_glb[i]] : (need_glb[i] - cmin);
+
+    e->rB_rcnts.resize(P);
+    e->rB_rdispls.resize((size_t) P + 1);
+    e->rB_scnts.resize(P);
+    e->rB_sdispls.resize((size_t) P + 1);
+    for (int q = 0; q < P; q++)
+    {
+        e->rB_rcnts[q] = (long long) rcnt[q] * glb_n;
+        e->rB_scnts[q] = (long long) scnt[q] * glb_n;
+    }
+    for (int q = 0; q <= P; q++)
+    {
+        e->rB_rdispls[q] = (long long) rdsp[q] * glb_n;
+        e->rB_sdispls[q] = (long long) sdsp[q] * glb_n;
+    }
+
+    // device column index: local B row, or ~(position in the receive buffer).
+    // Position = rank among needed rows minus the self rows that precede it.
+    e->dev_colidx_host.resize(nnz);
+    for (size_t p = 0; p < nnz; p++)
+    {
+        const int g = A_colidx[p];
+        if (g >= lo && g < hi) e->dev_colidx_host[p] = g - lo;
+        else e->dev_colidx_host[p] = ~(rank_[g] - (g >= hi ? self_n : 0));
+    }
+}
+
+static void rp_init_common(int A_nrow, const int *A_rowptr, const int *A_colidx, const double *A_val,
+                           const int *B_row_displs, int glb_n, crp_comm_t *comm, crp_rp_spmm_p *out,
+                           bool plan_only)
+{
+    ASSERT_PRINTF(out != NULL && comm != NULL && A_rowptr != NULL && B_row_displs != NULL && A_nrow >= 0 && glb_n >= 0,
+                  "invalid arguments to rp_spmm_init\n");
+    const double t0 = get_wtime_sec();
+    crp_rp_spmm *e = new crp_rp_spmm;
+    e->plan_only = plan_only;
+    build_plan(e, A_nrow, A_rowptr, A_colidx, A_val, B_row_displs, glb_n, comm);
+    if (!plan_only)
+    {
+        HIP_OK(crp_csr_dev_create(A_nrow, e->loc_B_nrow, e->A_rowptr.data(), e->dev_colidx_host.data(),
+                                  e->A_val.data(), &e->A_dev));
+        HIP_OK(crp_stream_create(&e->stream));
+        void *p = NULL;
+        if (e->n_send_rows > 0)
+        {
+            HIP_OK(crp_dev_malloc(&p, sizeof(int) * (size_t) e->n_send_rows));
+            e->sridxs_dev = (int *) p;
+            HIP_OK(crp_dev_memcpy(e->sridxs_dev, e->rB_sridxs.data(), sizeof(int) * (size_t) e->n_send_rows, 0, NULL));
+            HIP_OK(crp_dev_malloc(&p, sizeof(double) * (size_t) e->n_send_rows * (size_t) glb_n));
+            e->sendbuf_dev = (double *) p;
+        }
+        if (e->n_recv_rows > 0)
+        {
+            HIP_OK(crp_dev_malloc(&p, sizeof(double) * (size_t) e->n_recv_rows * (size_t) glb_n));
+            e->recvbuf_dev = (double *) p;
+        }
+        HIP_OK(crp_stream_sync(NULL));
+    }
+    e->t_init = get_wtime_sec() - t0;
+    *out = e;
+}
+
+extern "C" {
+
+void crp_rp_spmm_init(int A_srow, int A_nrow, const int *A_rowptr, const int *A_colidx, const double *A_val,
+                      const int *B_row_displs, int glb_n, crp_comm_t *comm, crp_rp_spmm_p *rp_spmm)
+{
+    (void) A_srow;   // never read by the reference either (src/rowpara_spmm.c:20-24)
+    rp_init_common(A_nrow, A_rowptr, A_colidx, A_val, B_row_displs, glb_n, comm, rp_spmm, false);
+}
+
+void crp_rp_spmm_init_plan_only(int A_srow, int A_nrow, const int *A_rowptr, const int *A_colidx,
+                                const double *A_val, const int *B_row_displs, int glb_n, crp_comm_t *comm,
+                                crp_rp_spmm_p *rp_spmm)
+{
+    (void) A_srow;
+    rp_init_common(A_nrow, A_rowptr, A_colidx, A_val, B_row_displs, glb_n, comm, rp_spmm, true);
+}
+
+void crp_rp_spmm_free(crp_rp_spmm_p *rp_spmm)
+{
+    if (rp_spmm == NULL || *rp_spmm == NULL) return;
+    crp_rp_spmm *e = *rp_spmm;
+    if (!e->plan_only)
+    {
+        crp_csr_dev_destroy(&e->A_dev);
+        crp_dev_free(e->sridxs_dev);
+        crp_dev_free(e->sendbuf_dev);
+        crp_dev_free(e->recvbuf_dev);
+        crp_dev_free(e->B_stage);
+        crp_dev_free(e->C_stage);
+        crp_dev_free(e->B_rm);
+        crp_dev_free(e->C_rm);
+        crp_stream_destroy(e->stream);
+    }
+    delete e;
+    *rp_spmm = NULL;
+}
+
+void crp_rp_spmm_exec_ex(crp_rp_spmm_p e, int BC_layout, const double *B, long long ldB, double *C,
+                         long long ldC, void *stream_)
+{
+    if (e == NULL) return;
+    ASSERT_PRINTF(!e->plan_only, "rp_spmm_exec on a plan-only engine (no device state)\n");
+    ASSERT_PRINTF(BC_layout == 0 || BC_layout == 1, "BC_layout must be 0 or 1\n");
+    const double t_begin = get_wtime_sec();
+    void *s = stream_ ? stream_ : e->stream;
+    const int n = e->glb_n, kb = e->loc_B_nrow, m = e->A_nrow;
+    const bool timing = e->timing != 0;
+    double t0, t1;
+
+    int B_on_dev = 0, C_on_dev = 0;
+    HIP_OK(crp_dev_ptr_is_device(B, &B_on_dev));
+    HIP_OK(crp_dev_ptr_is_device(C, &C_on_dev));
+
+    // ---- bring B to a device-resident row-major view (Bd, ldBd)
+    const double *Bd = B;
+    long long ldBd = ldB;
+    if (!B_on_dev && kb > 0 && n > 0)
+    {
+        // host operand: stage the whole local block (ld preserved)
+        const size_t elems = (BC_layout == 0) ? (size_t) kb * (size_t) ldB : (size_t) n * (size_t) ldB;
+        grow(&e->B_stage, &e->B_stage_sz, elems);
+        const size_t used = (BC_layout == 0) ? ((size_t) (kb - 1) * (size_t) ldB + (size_t) n)
+                                             : ((size_t) (n - 1) * (size_t) ldB + (size_t) kb);
+        HIP_OK(crp_dev_memcpy(e->B_stage, B, used * sizeof(double), 0, s));
+        Bd = e->B_stage;
+    }
+    if (BC_layout == 1 && kb > 0 && n > 0)
+    {
+        grow(&e->B_rm, &e->B_rm_sz, (size_t) kb * (size_t) n);
+        // column-major kb x n (ld ldB) == row-major n x kb; transpose to row-major kb x n
+        HIP_OK(crp_transpose_f64(n, kb, Bd, ldB, e->B_rm, n, s));
+        Bd = e->B_rm;
+        ldBd = n;
+    }
+    double *Cd = C;
+    long long ldCd = ldC;
+    if (BC_layout == 1)
+    {
+        grow(&e->C_rm, &e->C_rm_sz, (size_t) m * (size_t) n);
+        Cd = e->C_rm;
+        ldCd = n;
+    }
+    else if (!C_on_dev && m > 0 && n > 0)
+    {
+        grow(&e->C_stage, &e->C_stage_sz, (size_t) m * (size_t) ldC);
+        Cd = e->C_stage;
+    }
+
+    // ---- 1. pack the rows other ranks asked for (reference :232-262)
+    if (timing) { HIP_OK(crp_stream_sync(s)); }
+    t0 = get_wtime_sec();
+    if (e->n_send_rows > 0 && n > 0)
+        HIP_OK(crp_gather_rows_f64(0, (int) e->n_send_rows, n, e->sridxs_dev, Bd, ldBd, e->sendbuf_dev, n, s));
+    if (timing)
+    {
+        HIP_OK(crp_stream_sync(s));
+        t1 = get_wtime_sec();
+        e->t_pack += t1 - t0;
+        t0 = t1;
+    }
+
+    // ---- 2. exchange (reference :275-309); received rows land in final order
+    if (e->nproc > 1)
+        e->comm->alltoallv_dev_f64(e->comm->ctx, e->sendbuf_dev, e->rB_scnts.data(), e->rB_sdispls.data(),
+                                   e->recvbuf_dev, e->rB_rcnts.data(), e->rB_rdispls.data(), s);
+    if (timing)
+    {
+        HIP_OK(crp_stream_sync(s));
+        t1 = get_wtime_sec();
+        e->t_a2a += t1 - t0;
+        t0 = t1;
+    }
+
+    // ---- 3. local SpMM (reference :388-408)
+    HIP_OK(crp_spmm_csr_f64(e->A_dev, 0, n, Bd, ldBd, e->recvbuf_dev, n, Cd, ldCd, e->variant, s));
+    if (BC_layout == 1 && m > 0 && n > 0)
+    {
+        double *Ccm = C;
+        if (!C_on_dev)
+        {
+            grow(&e->C_stage, &e->C_stage_sz, (size_t) n * (size_t) ldC);
+            Ccm = e->C_stage;
+        }
+        HIP_OK(crp_transpose_f64(m, n, Cd, n, Ccm, ldC, s));   // row-major n x m (ld ldC) == column-major m x n
+        Cd = Ccm;
+    }
+    if (timing)
+    {
+        HIP_OK(crp_stream_sync(s));
+        t1 = get_wtime_sec();
+        e->t_spmm += t1 - t0;
+    }
+
+    if (!C_on_dev && m > 0 && n > 0)
+    {
+        const size_t used = (BC_layout == 0) ? ((size_t) (m - 1) * (size_t) ldC + (size_t) n)
+                                             : ((size_t) (n - 1) * (size_t) ldC + (size_t) m);
+        if (BC_layout == 0 && ldC != n)
+        {
+            // do not clobber the caller's padding between rows: copy row by row
+            for (int i = 0; i < m; i++)
+                HIP_OK(crp_dev_memcpy(C + (size_t) i * ldC, Cd + (size_t) i * ldC, sizeof(double) * (size_t) n, 1, s));
+        }
+        else if (BC_layout == 1 && ldC != m)
+        {
+            for (int j = 0; j < n; j++)
+                HIP_OK(crp_dev_memcpy(C + (size_t) j * ldC, Cd + (size_t) j * ldC, sizeof(double) * (size_t) m, 1, s));
+        }
+        else HIP_OK(crp_dev_memcpy(C, Cd, used * sizeof(double), 1, s));
+        HIP_OK(crp_stream_sync(s));
+    }
+    else if (!B_on_dev || timing)
+    {
+        HIP_OK(crp_stream_sync(s));
+    }
+    e->t_exec += get_wtime_sec() - t_begin;
+    e->n_exec++;
+}
+
+void crp_rp_spmm_exec(crp_rp_spmm_p e, int BC_layout, const double *B, int ldB, double *C, int ldC)
+{
+    crp_rp_spmm_exec_ex(e, BC_layout, B, (long long) ldB, C, (long long) ldC, NULL);
+}
+
+void crp_rp_spmm_print_stat(crp_rp_spmm_p e)
+{
+    if (e == NULL) return;
+    const int n_exec = e->n_exec;
+    if (n_exec == 0) return;
+    uint64_t recv = (uint64_t) e->rB_recv_size, recv_max = 0, recv_sum = 0;
+    double raw[6] = {e->t_init, e->t_pack, e->t_a2a, e->t_unpack, e->t_spmm, e->t_exec}, tmax[6], tavg[6];
+    crp_comm_t *c = e->comm;
+    c->reduce_u64(c->ctx, &recv, &recv_max, 1, CRP_OP_MAX);
+    c->reduce_u64(c->ctx, &recv, &recv_sum, 1, CRP_OP_SUM);
+    c->reduce_f64(c->ctx, raw, tmax, 6, CRP_OP_MAX);
+    c->reduce_f64(c->ctx, raw, tavg, 6, CRP_OP_SUM);
+    if (e->my_rank != 0) return;
+    for (int i = 1; i <= 5; i++)
+    {
+        tmax[i] /= n_exec;
+        tavg[i] /= ((double) n_exec * e->nproc);
+    }
+    recv_sum *= (uint64_t) e->glb_n;
+    recv_max *= (uint64_t) e->glb_n;
+    // same lines as src/rowpara_spmm.c:450-461 (harness scripts grep them)
+    printf("rp_spmm_init() time = %.2f s\n", tmax[0]);
+    printf("Total / rank-max SpMM comm size = %zu, %zu\n", (size_t) recv_sum, (size_t) recv_max);
+    printf("-------------------- Runtime (s) --------------------\n");
+    printf("                                     avg         max\n");
+    printf("Pack B matrix for redistribution  %6.3f      %6.3f\n", tavg[1], tmax[1]);
+    printf("Redistribute B matrix             %6.3f      %6.3f\n", tavg[2], tmax[2]);
+    printf("Unpack received B matrix data     %6.3f      %6.3f\n", tavg[3], tmax[3]);
+    printf("Local SpMM                        %6.3f      %6.3f\n", tavg[4], tmax[4]);
+    printf("Total rp_spmm_exec()              %6.3f      %6.3f\n", tavg[5], tmax[5]);
+    printf("\n");
+    fflush(stdout);
+}
+
+void crp_rp_spmm_clear_stat(crp_rp_spmm_p e)
+{
+    if (e == NULL) return;
+    e->n_exec = 0;
+    e->t_pack = e->t_a2a = e->t_unpack = e->t_spmm = e->t_exec = 0.0;
+}
+
+void crp_rp_spmm_get_plan(crp_rp_spmm_p e, crp_rp_plan_view_t *v)
+{
+    if (e == NULL || v == NULL) return;
+    v->nproc = e->nproc; v->my_rank = e->my_rank; v->glb_n = e->glb_n; v->A_nrow = e->A_nrow;
+    v->rB_nrow = e->rB_nrow;
+    v->rB_self_src_offset = e->rB_self_src_offset;
+    v->rB_self_dst_offset = e->rB_self_dst_offset;
+    v->rB_self_nrow = e->rB_self_nrow;
+    v->rB_p2p = e->rB_p2p; v->rB_reidx = e->rB_reidx;
+    v->A_rowptr = e->A_rowptr.data(); v->A_colidx = e->A_colidx.data(); v->A_val = e->A_val.data();
+    v->rB_self_src_ridxs = e->rB_self_src_ridxs.data();
+    v->rB_scnts = e->rB_scnts.data(); v->rB_sdispls = e->rB_sdispls.data(); v->rB_sridxs = e->rB_sridxs.data();
+    v->rB_rcnts = e->rB_rcnts.data(); v->rB_rdispls = e->rB_rdispls.data(); v->rB_rridxs = e->rB_rridxs.data();
+    v->rB_recv_size = e->rB_recv_size;
+    v->n_exec = e->n_exec;
+    v->t_init = e->t_init; v->t_pack = e->t_pack; v->t_a2a = e->t_a2a; v->t_unpack = e->t_unpack;
+    v->t_spmm = e->t_spmm; v->t_exec = e->t_exec;
+}
+
+void crp_rp_spmm_set_timing(crp_rp_spmm_p e, int timing) { if (e) e->timing = timing ? 1 : 0; }
+void crp_rp_spmm_set_variant(crp_rp_spmm_p e, int variant) { if (e) e->variant = variant; }
+
+long long crp_rp_spmm_nnz(crp_rp_spmm_p e) { return e ? (long long) e->A_val.size() : -1; }
+
+long long crp_rp_spmm_alg_bytes(crp_rp_spmm_p e)
+{
+    if (e == NULL) return -1;
+    const long long nnz = (long long) e->A_val.size();
+    return 12LL * nnz + 4LL * ((long long) e->A_nrow + 1) + 8LL * e->glb_n * e->n_needed_rows +
+           8LL * e->glb_n * (long long) e->A_nrow;
+}
+
+const int *crp_rp_spmm_dev_colidx_host(crp_rp_spmm_p e) { return e ? e->dev_colidx_host.data() : NULL; }
+
+// ---------------------------------------------------------------------------
+// single-rank communicator
+static void self_a2a(void *, const int *s, int *r, int count) { memcpy(r, s, sizeof(int) * (size_t) count); }
+static void self_a2av(void *, const int *s, const int *sc, const int *sd, int *r, const int *, const int *rd)
+{
+    memcpy(r + rd[0], s + sd[0], sizeof(int) * (size_t) sc[0]);
+}
+static void self_agv(void *, const void *s, size_t sb, void *r, const size_t *, const size_t *rd)
+{
+    memcpy((char *) r + rd[0], s, sb);
+}
+static void self_barrier(void *) {}
+static void self_red_f64(void *, const double *in, double *out, int n, int) { memcpy(out, in, sizeof(double) * (size_t) n); }
+static void self_red_u64(void *, const uint64_t *in, uint64_t *out, int n, int) { memcpy(out, in, sizeof(uint64_t) * (size_t) n); }
+static void self_a2av_dev(void *, const double *, const long long *, const long long *, double *, const long long *,
+                          const long long *, void *) {}
+static void self_free(crp_comm_t *c) { free(c); }
+static crp_comm_t *self_split(void *, int, int) { return crp_comm_self(); }
+
+crp_comm_t *crp_comm_self(void)
+{
+    crp_comm_t *c = (crp_comm_t *) calloc(1, sizeof(crp_comm_t));
+    c->nproc = 1;
+    c->rank = 0;
+    c->alltoall_i32 = self_a2a;
+    c->alltoallv_i32 = self_a2av;
+    c->allgatherv_bytes = self_agv;
+    c->barrier = self_barrier;
+    c->reduce_f64 = self_red_f64;
+    c->reduce_u64 = self_red_u64;
+    c->alltoallv_dev_f64 = self_a2av_dev;
+    c->split = self_split;
+    c->free = self_free;
+    return c;
+}
+
+}  // extern "C"

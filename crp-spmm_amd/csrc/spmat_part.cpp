@@ -1,0 +1,182 @@
+// spmat_part.cpp -- host partition planner behind include/spmat_part.h.
+// Integer outputs are bit-exact with /root/reference/src/spmat_part.c:12-210;
+// the distinct-column counting uses a stamp array instead of the reference's
+// per-thread byte flags (one pass over the nonzeros, no memset per block).
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "spmat_part.h"
+#include "utils.h"
+#include "par.h"
+
+// Row index the reference's bisection reaches for `target` (src/spmat_part.c:22-32):
+// a lower bound on row_ptr over [0, nrow) that stops early on an exact hit, so
+// with runs of empty rows the answer is the hit the bisection meets first.
+static int bisect_row_ptr(const int *row_ptr, int nrow, int target)
+{
+    int lo = 0, hi = nrow;
+    while (lo < hi)
+    {
+        const int mid = (lo + hi) / 2;
+        const int v = row_ptr[mid];
+        if (v == target) return mid;
+        if (v < target) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+
+extern "C" {
+
+void csr_mat_row_partition(const int nrow, const int *row_ptr, const int nblk, int *rblk_ptr)
+{
+    const int nnz = row_ptr[nrow];
+    const int share = nnz / nblk;
+    rblk_ptr[0] = 0;
+    for (int b = 0; b < nblk; b++)
+    {
+        const int target = (b == nblk - 1) ? nnz : share * (b + 1);
+        rblk_ptr[b + 1] = bisect_row_ptr(row_ptr, nrow, target);
+    }
+}
+
+int prime_factorization(int n, int **factors)
+{
+    // at most log2(n) factors
+    int cap = 2;
+    for (int t = n; t > 1; t >>= 1) cap++;
+    int *fac = (int *) malloc(sizeof(int) * cap);
+    int nfac = 0;
+    for (int c = 2; n > 1;)
+    {
+        if (n % c == 0)
+        {
+            fac[nfac++] = c;
+            n /= c;
+        }
+        else c++;
+    }
+    *factors = fac;
+    return nfac;
+}
+
+void csr_mat_row_part_comm_size(const int nrow, const int ncol, const int *row_ptr, const int *col_idx,
+                                const int nblk, const int *rblk_ptr, const int *x_displs,
+                                int *comm_sizes, int *total_size)
+{
+    (void) nrow;
+    // one stamp array per worker thread: stamp[c] == b + 1  <=>  column c already seen in block b
+    std::vector<std::vector<int>> stamps((size_t) crp::host_threads());
+    crp::parallel_chunks(nblk, 1, [&](long long b0, long long b1, int tid) {
+        std::vector<int> &stamp = stamps[(size_t) tid];
+        if (stamp.empty()) stamp.assign((size_t) (ncol > 0 ? ncol : 1), 0);
+        for (int b = (int) b0; b < (int) b1; b++)
+        {
+            const int xlo = x_displs[b], xhi = x_displs[b + 1], tag = b + 1;
+            int cnt = 0;
+            for (int p = row_ptr[rblk_ptr[b]]; p < row_ptr[rblk_ptr[b + 1]]; p++)
+            {
+                const int c = col_idx[p];
+                if (stamp[c] != tag)
+                {
+                    stamp[c] = tag;
+                    if (c < xlo || c >= xhi) cnt++;
+                }
+            }
+            comm_sizes[b] = cnt;
+        }
+    });
+    int tot = 0;
+    for (int b = 0; b < nblk; b++) tot += comm_sizes[b];
+    *total_size = tot;
+}
+
+void calc_spmm_part2d_from_1d(const int nproc, const int m, const int n, const int k, const int *rb_displs0,
+                              const int *rowptr, const int *colidx, const int rA, int *pm, int *pn,
+                              size_t *comm_cost, int **A0_rowptr, int **B_rowptr, int **AC_rowptr,
+                              int **BC_colptr, int dbg_print)
+{
+    const double nnz_cf = 1.5;   // cost of one replicated nonzero in fp64 elements (int32 + fp64)
+    std::vector<int> best_rows(rb_displs0, rb_displs0 + nproc + 1), cand_rows(nproc + 1), xd(nproc + 1),
+        sizes(nproc);
+    int tmp;
+
+    // B's rows follow A's row blocks when A is square, else an even split
+    auto b_rows_for = [&](const int *rows, int nblk, int *out) {
+        if (m == k) memcpy(out, rows, sizeof(int) * (nblk + 1));
+        else for (int i = 0; i <= nblk; i++) calc_block_spos_size(k, nblk, i, out + i, &tmp);
+    };
+
+    // pure 1D start point: nproc x 1
+    b_rows_for(rb_displs0, nproc, xd.data());
+    int vol = 0;
+    csr_mat_row_part_comm_size(m, k, rowptr, colidx, nproc, rb_displs0, xd.data(), sizes.data(), &vol);
+    size_t best = (size_t) vol * (size_t) n;
+    if (dbg_print) printf("Basic 1D row partitioning comm cost: %zu\n", best);
+
+    int gm = nproc, gn = 1, rejected = -1;
+    const int nnz = rowptr[m];
+    int *fac = NULL;
+    const int nfac = prime_factorization(nproc, &fac);
+    for (int step = 0; step < nfac; step++)
+    {
+        const int p = fac[nfac - 1 - step];   // largest factor first
+        if (p == rejected) continue;
+        const int tn = gn * p, tm = nproc / tn;
+        for (int i = 0; i <= tm; i++) cand_rows[i] = rb_displs0[i * tn];
+        b_rows_for(cand_rows.data(), tm, xd.data());
+        const double t0 = get_wtime_sec();
+        csr_mat_row_part_comm_size(m, k, rowptr, colidx, tm, cand_rows.data(), xd.data(), sizes.data(), &vol);
+        const double t1 = get_wtime_sec();
+        const size_t costA = (size_t) ((double) nnz * (double) (tn - 1) * nnz_cf);
+        const size_t costB = (size_t) rA * (size_t) vol * (size_t) n;
+        const size_t cost = costA + costB;
+        if (dbg_print)
+        {
+            printf("Step %d, factor %d, time = %.2f\n", step, p, t1 - t0);
+            printf("Evaluated: pm = %d, pn = %d, cost = %zu\n", tm, tn, cost);
+            if (cost < best) printf("Found better partitioning\n");
+        }
+        if (cost < best)
+        {
+            best = cost;
+            gm = tm;
+            gn = tn;
+            memcpy(best_rows.data(), cand_rows.data(), sizeof(int) * (tm + 1));
+            rejected = -1;
+        }
+        else rejected = p;
+    }
+    free(fac);
+    *comm_cost = best;
+    *pm = gm;
+    *pn = gn;
+    if (dbg_print) printf("Final 2D partitioning: pm = %d, pn = %d, cost = %zu\n", gm, gn, best);
+
+    int *ac = (int *) malloc(sizeof(int) * (gm + 1));
+    int *br = (int *) malloc(sizeof(int) * (gm + 1));
+    int *bc = (int *) malloc(sizeof(int) * (gn + 1));
+    int *a0 = (int *) malloc(sizeof(int) * (nproc + 1));
+    memcpy(ac, best_rows.data(), sizeof(int) * (gm + 1));
+    b_rows_for(ac, gm, br);
+    for (int j = 0; j <= gn; j++) calc_block_spos_size(n, gn, j, bc + j, &tmp);
+
+    // nnz-balanced re-split of every replicated panel into gn source slices
+    std::vector<int> local_ptr((size_t) m + 1);
+    for (int i = 0; i < gm; i++)
+    {
+        const int r0 = ac[i], r1 = ac[i + 1];
+        for (int r = r0; r <= r1; r++) local_ptr[r - r0] = rowptr[r] - rowptr[r0];
+        int *slice = a0 + i * gn;
+        csr_mat_row_partition(r1 - r0, local_ptr.data(), gn, slice);
+        for (int j = 0; j <= gn; j++) slice[j] += r0;
+    }
+    *A0_rowptr = a0;
+    *B_rowptr  = br;
+    *AC_rowptr = ac;
+    *BC_colptr = bc;
+}
+
+}  // extern "C"

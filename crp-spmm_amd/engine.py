@@ -1,0 +1,209 @@
+"""Host-side mirror of the reference's engine API over the C ABI.
+
+``RpSpmm`` ~ rp_spmm_*  (/root/reference/src/rowpara_spmm.h:60-87)
+``Para2dSpmm`` ~ para2d_spmm_* (/root/reference/src/para2d_spmm.h:42-75)
+
+Same argument names, meaning and call protocol (init -> exec ... -> print_stat
+-> free) as the reference; B and C are torch tensors (device-resident: the
+zero-copy path) or numpy arrays (host pointers, staged like the reference API).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _ip(a):
+    return a.ctypes.data_as(L.c_int_p)
+
+
+def _dp(a):
+    return a.ctypes.data_as(L.c_dbl_p)
+
+
+def _ptr_ld(x, layout):
+    """(address, leading dimension, keepalive) of a 2-D operand."""
+    try:
+        import torch
+        if isinstance(x, torch.Tensor):
+            if x.dtype != torch.float64 or x.dim() != 2:
+                raise TypeError("B and C must be 2-D float64")
+            if x.stride(1) != 1:
+                raise ValueError("operand must be contiguous along its fast dimension")
+            return x.data_ptr(), x.stride(0), x
+    except ImportError:
+        pass
+    if not isinstance(x, np.ndarray) or x.dtype != np.float64 or x.ndim != 2 or x.strides[1] != 8:
+        raise TypeError("B and C must be 2-D float64 torch tensors or numpy arrays, contiguous along the fast dimension")
+    return x.ctypes.data, x.strides[0] // 8, x
+
+
+def _current_stream(x):
+    try:
+        import torch
+        if isinstance(x, torch.Tensor) and x.is_cuda:
+            return torch.cuda.current_stream(x.device).cuda_stream
+    except ImportError:
+        pass
+    return None
+
+
+class RpSpmm:
+    """1D row-parallel SpMM engine: C := A * B with A's row block on this rank.
+
+    Arguments as rp_spmm_init (src/rowpara_spmm.h:49-64): ``A_rowptr`` is this
+    rank's slice of the GLOBAL row pointer (global nnz offsets), ``B_row_displs``
+    has nproc + 1 entries, ``comm`` is a TorchComm / SelfComm and must outlive
+    the engine."""
+
+    def __init__(self, A_srow, A_nrow, A_rowptr, A_colidx, A_val, B_row_displs, glb_n, comm, plan_only=False):
+        lib = L.load()
+        self._lib = lib
+        self.comm = comm
+        rp, ci, va, bd = _i32(A_rowptr), _i32(A_colidx), _f64(A_val), _i32(B_row_displs)
+        if ci.size == 0:
+            ci, va = np.zeros(1, np.int32), np.zeros(1, np.float64)
+        self.handle = C.c_void_p()
+        fn = lib.crp_rp_spmm_init_plan_only if plan_only else lib.crp_rp_spmm_init
+        fn(A_srow, A_nrow, _ip(rp), _ip(ci), _dp(va), _ip(bd), glb_n, comm.ptr, C.byref(self.handle))
+        self.glb_n = glb_n
+        self.A_nrow = A_nrow
+        self.loc_B_nrow = int(bd[comm.rank + 1] - bd[comm.rank])
+        self._owned = True
+
+    @classmethod
+    def _wrap(cls, handle, comm, lib):
+        self = cls.__new__(cls)
+        self._lib, self.comm, self.handle, self._owned = lib, comm, C.c_void_p(handle), False
+        v = self.plan_view()
+        self.glb_n, self.A_nrow = v.glb_n, v.A_nrow
+        return self
+
+    def exec(self, BC_layout, B, C_out, stream=None):
+        """rp_spmm_exec (src/rowpara_spmm.h:69-81); ldB / ldC come from the strides.
+        For layout 1 pass the operands as (n, ld) arrays holding the column-major data."""
+        bp, ldb, _kb = _ptr_ld(B, BC_layout)
+        cp, ldc, _kc = _ptr_ld(C_out, BC_layout)
+        if stream is None:
+            stream = _current_stream(C_out)
+        self._lib.crp_rp_spmm_exec_ex(self.handle, BC_layout, bp, ldb, cp, ldc, stream)
+
+    def print_stat(self):
+        self._lib.crp_rp_spmm_print_stat(self.handle)
+
+    def clear_stat(self):
+        self._lib.crp_rp_spmm_clear_stat(self.handle)
+
+    def set_timing(self, on):
+        self._lib.crp_rp_spmm_set_timing(self.handle, int(bool(on)))
+
+    def set_variant(self, variant):
+        self._lib.crp_rp_spmm_set_variant(self.handle, int(variant))
+
+    def alg_bytes(self):
+        return int(self._lib.crp_rp_spmm_alg_bytes(self.handle))
+
+    def nnz(self):
+        return int(self._lib.crp_rp_spmm_nnz(self.handle))
+
+    def plan_view(self):
+        v = L.RpPlanView()
+        self._lib.crp_rp_spmm_get_plan(self.handle, C.byref(v))
+        return v
+
+    def plan(self):
+        """The struct's plan fields (src/rowpara_spmm.h:8-40) as numpy copies."""
+        v = self.plan_view()
+        P, nnz = v.nproc, self.nnz()
+
+        def arr(p, n, dt):
+            return np.ctypeslib.as_array(p, (n,)).astype(dt).copy() if n > 0 else np.zeros(0, dt)
+        d = {k: getattr(v, k) for k in ("nproc", "my_rank", "glb_n", "A_nrow", "rB_nrow", "rB_self_src_offset",
+                                        "rB_self_dst_offset", "rB_self_nrow", "rB_p2p", "rB_reidx", "rB_recv_size",
+                                        "n_exec", "t_init", "t_pack", "t_a2a", "t_unpack", "t_spmm", "t_exec")}
+        d["A_rowptr"] = arr(v.A_rowptr, v.A_nrow + 1, np.int32)
+        d["A_colidx"] = arr(v.A_colidx, nnz, np.int32)
+        d["A_val"] = arr(v.A_val, nnz, np.float64)
+        d["rB_self_src_ridxs"] = arr(v.rB_self_src_ridxs, v.rB_self_nrow, np.int32)
+        d["rB_scnts"] = arr(v.rB_scnts, P, np.int64)
+        d["rB_sdispls"] = arr(v.rB_sdispls, P + 1, np.int64)
+        d["rB_rcnts"] = arr(v.rB_rcnts, P, np.int64)
+        d["rB_rdispls"] = arr(v.rB_rdispls, P + 1, np.int64)
+        n = max(v.glb_n, 1)
+        d["rB_sridxs"] = arr(v.rB_sridxs, int(d["rB_sdispls"][P]) // n if v.glb_n else 0, np.int32)
+        d["rB_rridxs"] = arr(v.rB_rridxs, int(d["rB_rdispls"][P]) // n if v.glb_n else 0, np.int32)
+        p = self._lib.crp_rp_spmm_dev_colidx_host(self.handle)
+        d["dev_colidx"] = arr(p, nnz, np.int32)
+        return d
+
+    def free(self):
+        if getattr(self, "handle", None) is not None and self.handle and self._owned:
+            self._lib.crp_rp_spmm_free(C.byref(self.handle))
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Para2dSpmm:
+    """2D (pm x pn) engine, arguments as para2d_spmm_init (src/para2d_spmm.h:22-47)."""
+
+    def __init__(self, comm, pm, pn, A0_rowptr, B_rowptr, AC_rowptr, BC_colptr, A_rowptr, A_colidx, A_val,
+                 plan_only=False):
+        lib = L.load()
+        self._lib, self.comm = lib, comm
+        a0, br, ac, bc = _i32(A0_rowptr), _i32(B_rowptr), _i32(AC_rowptr), _i32(BC_colptr)
+        rp, ci, va = _i32(A_rowptr), _i32(A_colidx), _f64(A_val)
+        if ci.size == 0:
+            ci, va = np.zeros(1, np.int32), np.zeros(1, np.float64)
+        self.handle = C.c_void_p()
+        fn = lib.crp_para2d_spmm_init_plan_only if plan_only else lib.crp_para2d_spmm_init
+        fn(comm.ptr, pm, pn, _ip(a0), _ip(br), _ip(ac), _ip(bc), _ip(rp), _ip(ci), _dp(va),
+                                 C.byref(self.handle))
+        self.pm, self.pn = pm, pn
+        self.pi, self.pj = comm.rank // pn, comm.rank % pn
+        self.rp = RpSpmm._wrap(lib.crp_para2d_spmm_rp(self.handle), comm, lib)
+
+    def exec(self, BC_layout, B, C_out, stream=None):
+        bp, ldb, _kb = _ptr_ld(B, BC_layout)
+        cp, ldc, _kc = _ptr_ld(C_out, BC_layout)
+        if stream is None:
+            stream = _current_stream(C_out)
+        self._lib.crp_para2d_spmm_exec_ex(self.handle, BC_layout, bp, ldb, cp, ldc, stream)
+
+    def print_stat(self):
+        self._lib.crp_para2d_spmm_print_stat(self.handle)
+
+    def clear_stat(self):
+        self._lib.crp_para2d_spmm_clear_stat(self.handle)
+
+    @property
+    def rA_cost(self):
+        return int(self._lib.crp_para2d_spmm_rA_cost(self.handle))
+
+    @property
+    def t_ag_A(self):
+        return float(self._lib.crp_para2d_spmm_t_ag_A(self.handle))
+
+    def free(self):
+        if getattr(self, "handle", None) is not None and self.handle:
+            self._lib.crp_para2d_spmm_free(C.byref(self.handle))
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

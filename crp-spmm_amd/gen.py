@@ -1,0 +1,83 @@
+"""Seeded synthetic matrices standing in for the SuiteSparse inputs of
+BASELINE.json (no .mtx files and no network in the build or GPU containers;
+SURVEY.md section 8d).  Everything is a pure function of its arguments: values
+come from a counter-based hash (splitmix64), not from RNG state."""
+import numpy as np
+
+_M = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _mix(x):
+    """splitmix64 finaliser on a uint64 array."""
+    with np.errstate(over="ignore"):
+        z = (x + np.uint64(0x9E3779B97F4A7C15))
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def _u01(key, seed):
+    h = _mix(key.astype(np.uint64) ^ _mix(np.uint64(seed) + np.zeros(1, dtype=np.uint64)))
+    return (h >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+PWTK_OFFSETS = tuple(range(1, 15)) + tuple(range(1200, 1206)) + tuple(range(36000, 36006))
+
+
+def banded_fem(m, offsets=PWTK_OFFSETS, seed=20261004):
+    """Symmetric banded FEM-like matrix: entries at |i - j| in `offsets` plus the
+    diagonal; off-diagonal values U(-1, 1) (symmetric), diagonal 30 + U(0, 1).
+    banded_fem(217918) is the pwtk stand-in: 217,918 rows, 11,102,984 nnz (~51/row).
+    -> (rowptr int32, colidx int32, val float64), columns ascending per row."""
+    offs = np.array(sorted([-d for d in offsets] + [0] + list(offsets)), dtype=np.int64)
+    rows = np.arange(m, dtype=np.int64)
+    rowptr = np.zeros(m + 1, dtype=np.int64)
+    cols_parts, vals_parts = [], []
+    chunk = 1 << 16
+    for r0 in range(0, m, chunk):
+        r = rows[r0:r0 + chunk]
+        cc = r[:, None] + offs[None, :]
+        ok = (cc >= 0) & (cc < m)
+        rowptr[r0 + 1:r0 + 1 + r.size] = ok.sum(axis=1)
+        ri = np.broadcast_to(r[:, None], cc.shape)[ok]
+        ci = cc[ok]
+        lo, d = np.minimum(ri, ci), np.abs(ri - ci)
+        u = _u01(lo * np.int64(65536 * 4) + d, seed)
+        v = np.where(d == 0, 30.0 + u, 2.0 * u - 1.0)
+        cols_parts.append(ci.astype(np.int32))
+        vals_parts.append(v)
+    rowptr = np.cumsum(rowptr).astype(np.int32)
+    return rowptr, np.concatenate(cols_parts), np.concatenate(vals_parts)
+
+
+def erdos_renyi(m, k, deg, seed=1):
+    """deg nonzeros per row, columns i.i.d. uniform (duplicates kept), ascending per row."""
+    idx = np.arange(m * deg, dtype=np.uint64)
+    cols = (_mix(idx ^ _mix(np.uint64(seed) + np.zeros(1, dtype=np.uint64))) % np.uint64(k)).astype(np.int32)
+    cols = np.sort(cols.reshape(m, deg), axis=1).reshape(-1)
+    vals = 2.0 * _u01(idx + np.uint64(1 << 40), seed) - 1.0
+    rowptr = (np.arange(m + 1, dtype=np.int64) * deg).astype(np.int32)
+    return rowptr, cols, vals
+
+
+def random_csr(m, k, max_deg, seed=7, empty_every=0):
+    """General test matrix: row i has (hash % (max_deg + 1)) distinct sorted columns;
+    every `empty_every`-th row is empty."""
+    rng = np.random.default_rng(seed)
+    deg = rng.integers(0, max_deg + 1, size=m)
+    if empty_every:
+        deg[::empty_every] = 0
+    deg = np.minimum(deg, k)
+    rowptr = np.zeros(m + 1, dtype=np.int32)
+    rowptr[1:] = np.cumsum(deg)
+    cols = np.empty(int(rowptr[-1]), dtype=np.int32)
+    for i in range(m):
+        if deg[i]:
+            cols[rowptr[i]:rowptr[i + 1]] = np.sort(rng.choice(k, size=deg[i], replace=False))
+    vals = rng.uniform(-1.0, 1.0, size=cols.size)
+    return rowptr, cols, vals
+
+
+def alg_bytes(m, k, n, nnz, vb=8):
+    """compulsory HBM bytes of one SpMM: A once, B once, C written once."""
+    return (vb + 4) * nnz + 4 * (m + 1) + vb * k * n + vb * m * n

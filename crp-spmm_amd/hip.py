@@ -1,0 +1,84 @@
+"""Device-level wrappers over include/crpspmm_hip.h for torch tensors
+(data_ptr plumbing only; all arithmetic happens in the HIP kernels)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+class CsrDev:
+    """Device-resident CSR (crp_csr_dev_create)."""
+
+    def __init__(self, nrow, ncol, rowptr, colidx, val):
+        lib = L.load()
+        self._lib = lib
+        rp = np.ascontiguousarray(rowptr, dtype=np.int32)
+        ci = np.ascontiguousarray(colidx, dtype=np.int32)
+        va = np.ascontiguousarray(val, dtype=np.float64)
+        if ci.size == 0:
+            ci, va = np.zeros(1, np.int32), np.zeros(1, np.float64)
+        self.handle = C.c_void_p()
+        L.check(lib.crp_csr_dev_create(nrow, ncol, rp.ctypes.data_as(L.c_int_p), ci.ctypes.data_as(L.c_int_p),
+                                       va.ctypes.data_as(L.c_dbl_p), C.byref(self.handle)), "crp_csr_dev_create")
+        self.nrow, self.ncol = nrow, ncol
+
+    @property
+    def nnz(self):
+        return int(self._lib.crp_csr_dev_nnz(self.handle))
+
+    def free(self):
+        if self.handle:
+            self._lib.crp_csr_dev_destroy(C.byref(self.handle))
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _stream(t):
+    import torch
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def spmm_csr(A, B0, C_out, n=None, layout=0, B1=None, variant=0, stream=None):
+    """C_out := A * B (crp_spmm_csr_f64). B0 / B1 / C_out are 2-D float64 cuda tensors;
+    layout 1 operands are passed as (n, ld) tensors holding the column-major data."""
+    lib = L.load()
+    if layout == 0:
+        n = C_out.shape[1] if n is None else n
+    else:
+        n = C_out.shape[0] if n is None else n
+    b1p, ld1 = (B1.data_ptr(), B1.stride(0)) if B1 is not None else (None, 0)
+    L.check(lib.crp_spmm_csr_f64(A.handle, layout, n, B0.data_ptr() if B0 is not None else None,
+                                 B0.stride(0) if B0 is not None else 0, b1p, ld1, C_out.data_ptr(),
+                                 C_out.stride(0), variant, _stream(C_out) if stream is None else stream),
+            "crp_spmm_csr_f64")
+
+
+def gather_rows(ridx, src, dst, layout=0, scatter=False, stream=None):
+    lib = L.load()
+    fn = lib.crp_scatter_rows_f64 if scatter else lib.crp_gather_rows_f64
+    if layout == 0:
+        n = (src if scatter else dst).shape[1]
+    else:
+        n = (src if scatter else dst).shape[0]
+    L.check(fn(layout, ridx.numel(), n, ridx.data_ptr(), src.data_ptr(), src.stride(0), dst.data_ptr(),
+               dst.stride(0), _stream(dst) if stream is None else stream), "crp_gather/scatter_rows_f64")
+
+
+def transpose(src, dst, stream=None):
+    lib = L.load()
+    L.check(lib.crp_transpose_f64(src.shape[0], src.shape[1], src.data_ptr(), src.stride(0), dst.data_ptr(),
+                                  dst.stride(0), _stream(dst) if stream is None else stream), "crp_transpose_f64")
+
+
+def device_info(dev=0):
+    lib = L.load()
+    name = C.create_string_buffer(256)
+    cu, mem = C.c_int(), C.c_size_t()
+    L.check(lib.crp_hip_device_info(dev, name, C.byref(cu), C.byref(mem)), "crp_hip_device_info")
+    return name.value.decode(), cu.value, mem.value

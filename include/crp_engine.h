@@ -1,0 +1,132 @@
+/*
+ * crp_engine.h -- communicator-agnostic C ABI of the two CRP-SpMM engines.
+ *
+ * Same operations, argument meaning and error behaviour as the reference's
+ * public API, with the MPI_Comm replaced by a crp_comm_t* (crp_comm.h):
+ *
+ *   reference (/root/reference)                         this header
+ *   --------------------------------------------------  -----------------------
+ *   rp_spmm_init        src/rowpara_spmm.h:60-64         crp_rp_spmm_init
+ *   rp_spmm_exec        src/rowpara_spmm.h:78-81         crp_rp_spmm_exec
+ *   rp_spmm_free        src/rowpara_spmm.h:67            crp_rp_spmm_free
+ *   rp_spmm_print_stat  src/rowpara_spmm.h:84            crp_rp_spmm_print_stat
+ *   rp_spmm_clear_stat  src/rowpara_spmm.h:87            crp_rp_spmm_clear_stat
+ *   para2d_spmm_*       src/para2d_spmm.h:42-75          crp_para2d_spmm_*
+ *
+ * include/rowpara_spmm.h and include/para2d_spmm.h are the MPI-typed facade
+ * (exact reference signatures) over these functions.
+ *
+ * Differences that are deliberate ("reference defects"):
+ *   - A is uploaded once at init and stays device-resident; exec does no
+ *     malloc/free and creates no sparse handle (defect 6);
+ *   - locally owned B rows are read in place: there is no self-to-self copy
+ *     (defect 7), received rows land contiguously so there is no unpack pass;
+ *   - all offsets are 64-bit internally (defect 3);
+ *   - para2d at one rank does not self-send (defect 1).
+ * B and C may be host pointers (staged through device buffers, as the
+ * reference API implies) or device pointers (detected automatically; the
+ * zero-copy path the benchmark uses).
+ */
+#ifndef CRP_ENGINE_H
+#define CRP_ENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "crp_comm.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct crp_rp_spmm     *crp_rp_spmm_p;
+typedef struct crp_para2d_spmm *crp_para2d_spmm_p;
+
+/* Host-side view of the exchange plan: the fields of struct rowpara_spmm
+ * (src/rowpara_spmm.h:8-40), same names and meaning (counts / displs are in
+ * ELEMENTS = rows * glb_n, as the reference stores them, but 64-bit). */
+typedef struct crp_rp_plan_view
+{
+    int nproc, my_rank, glb_n, A_nrow, rB_nrow;
+    int rB_self_src_offset, rB_self_dst_offset, rB_self_nrow;
+    int rB_p2p, rB_reidx;
+    const int       *A_rowptr;           /* A_nrow + 1, rebased to 0          */
+    const int       *A_colidx;           /* compact (re-indexed) column ids   */
+    const double    *A_val;
+    const int       *rB_self_src_ridxs;  /* rB_self_nrow global row ids       */
+    const long long *rB_scnts, *rB_sdispls;   /* nproc, nproc + 1             */
+    const int       *rB_sridxs;          /* local B row ids to send           */
+    const long long *rB_rcnts, *rB_rdispls;
+    const int       *rB_rridxs;          /* compact rB row ids of received rows */
+    size_t rB_recv_size;                 /* rows received from other ranks    */
+    int    n_exec;
+    double t_init, t_pack, t_a2a, t_unpack, t_spmm, t_exec;
+} crp_rp_plan_view_t;
+
+/* See rp_spmm_init (src/rowpara_spmm.h:49-64).  A_rowptr is a slice of the
+ * global row pointer (global nnz offsets; rebased internally), A_srow is
+ * accepted and ignored exactly like the reference.  comm is not duplicated
+ * and must outlive the engine.  Honours RP_SPMM_P2P / RP_SPMM_REIDX
+ * (src/rowpara_spmm.c:42-43).  On failure prints "[FATAL] ..." and aborts,
+ * like ASSERT_PRINTF (src/utils.h:58-68). */
+void crp_rp_spmm_init(int A_srow, int A_nrow, const int *A_rowptr, const int *A_colidx,
+                      const double *A_val, const int *B_row_displs, int glb_n,
+                      crp_comm_t *comm, crp_rp_spmm_p *rp_spmm);
+void crp_rp_spmm_free(crp_rp_spmm_p *rp_spmm);
+/* C := A * B.  BC_layout 0 row-major / 1 column-major; NULL engine is a no-op
+ * (src/rowpara_spmm.c:217). */
+void crp_rp_spmm_exec(crp_rp_spmm_p rp_spmm, int BC_layout, const double *B, int ldB,
+                      double *C, int ldC);
+/* Same, 64-bit leading dimensions and an explicit stream (NULL = the engine's
+ * own stream).  With device pointers and timing off nothing synchronises. */
+void crp_rp_spmm_exec_ex(crp_rp_spmm_p rp_spmm, int BC_layout, const double *B, long long ldB,
+                         double *C, long long ldC, void *stream);
+void crp_rp_spmm_print_stat(crp_rp_spmm_p rp_spmm);
+void crp_rp_spmm_clear_stat(crp_rp_spmm_p rp_spmm);
+void crp_rp_spmm_get_plan(crp_rp_spmm_p rp_spmm, crp_rp_plan_view_t *view);
+/* timing = 1 (default): every phase is bracketed by stream synchronisation and
+ * billed to t_pack / t_a2a / t_unpack / t_spmm like the reference; 0: fully
+ * asynchronous exec, only t_exec (host enqueue time) is accumulated. */
+void crp_rp_spmm_set_timing(crp_rp_spmm_p rp_spmm, int timing);
+/* kernel variant for the local SpMM (crpspmm_hip.h: crp_spmm_variant_name). */
+void crp_rp_spmm_set_variant(crp_rp_spmm_p rp_spmm, int variant);
+/* bytes of HBM the local kernel must touch per exec (SURVEY 8d bytes_alg for
+ * this rank): 12*nnz + 4*(A_nrow+1) + 8*n*(distinct B rows) + 8*n*A_nrow. */
+long long crp_rp_spmm_alg_bytes(crp_rp_spmm_p rp_spmm);
+long long crp_rp_spmm_nnz(crp_rp_spmm_p rp_spmm);
+
+/* See para2d_spmm_init (src/para2d_spmm.h:22-47). Rank r sits at grid position
+ * (r / pn, r % pn); A_rowptr/A_colidx/A_val is the rank's A0 slice. */
+void crp_para2d_spmm_init(crp_comm_t *comm, int pm, int pn, const int *A0_rowptr,
+                          const int *B_rowptr, const int *AC_rowptr, const int *BC_colptr,
+                          const int *A_rowptr, const int *A_colidx, const double *A_val,
+                          crp_para2d_spmm_p *para2d_spmm);
+void crp_para2d_spmm_free(crp_para2d_spmm_p *para2d_spmm);
+void crp_para2d_spmm_exec(crp_para2d_spmm_p para2d_spmm, int BC_layout, const double *B, int ldB,
+                          double *C, int ldC);
+void crp_para2d_spmm_exec_ex(crp_para2d_spmm_p para2d_spmm, int BC_layout, const double *B,
+                             long long ldB, double *C, long long ldC, void *stream);
+void crp_para2d_spmm_print_stat(crp_para2d_spmm_p para2d_spmm);
+void crp_para2d_spmm_clear_stat(crp_para2d_spmm_p para2d_spmm);
+crp_rp_spmm_p crp_para2d_spmm_rp(crp_para2d_spmm_p para2d_spmm);
+size_t crp_para2d_spmm_rA_cost(crp_para2d_spmm_p para2d_spmm);
+double crp_para2d_spmm_t_ag_A(crp_para2d_spmm_p para2d_spmm);
+
+/* ---- host-only pieces exposed for tests (no GPU needed) -------------------
+ * Build only the exchange plan (everything rp_spmm_init computes on the host,
+ * including the alltoall of needed row ids) without touching the device.
+ * Release with crp_rp_spmm_free. exec on such an engine aborts. */
+void crp_rp_spmm_init_plan_only(int A_srow, int A_nrow, const int *A_rowptr, const int *A_colidx,
+                                const double *A_val, const int *B_row_displs, int glb_n,
+                                crp_comm_t *comm, crp_rp_spmm_p *rp_spmm);
+void crp_para2d_spmm_init_plan_only(crp_comm_t *comm, int pm, int pn, const int *A0_rowptr,
+                                    const int *B_rowptr, const int *AC_rowptr, const int *BC_colptr,
+                                    const int *A_rowptr, const int *A_colidx, const double *A_val,
+                                    crp_para2d_spmm_p *para2d_spmm);
+/* The device-side (two-source) column index the kernel consumes, host copy:
+ * c >= 0 local B row, c < 0 -> ~c = row of the receive buffer. */
+const int *crp_rp_spmm_dev_colidx_host(crp_rp_spmm_p rp_spmm);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,120 @@
+/*
+ * crpspmm_hip.h -- device-level C ABI of the MI355X (gfx950) CRP-SpMM hot path.
+ *
+ * These are the entry points a host binding (cgo / JNI / ctypes / the MPI
+ * facade in rowpara_spmm.h) calls for the work the reference does inside
+ * rp_spmm_exec():
+ *
+ *   reference call site (under /root/reference)        replaced by
+ *   -------------------------------------------------  -------------------------
+ *   src/rowpara_spmm.c:388-408  mkl_sparse_d_create_csr
+ *        + mkl_sparse_d_mm + mkl_sparse_destroy         crp_csr_dev_create (once)
+ *                                                       + crp_spmm_csr_f64
+ *   src/rowpara_spmm.c:232-262  pack B rows (OpenMP)    crp_gather_rows_f64
+ *   src/rowpara_spmm.c:313-344  unpack B rows           crp_scatter_rows_f64
+ *   src/rowpara_spmm.c:348-384  self-to-self copy       eliminated (two-source
+ *                                                       column index, see below)
+ *   deprecated/src/cuda_proxy.cu:53-118 mem/copy shims  crp_dev_* helpers
+ *
+ * Plain pointers and sizes only; no torch / MPI types.  Every function
+ * returns 0 on success or a hipError_t value (> 0) / negative argument
+ * error; nothing here falls back to the CPU.
+ *
+ * Two-source column index: a column index c >= 0 addresses row c of the
+ * caller's local B block (B0, leading dimension ldB0); c < 0 addresses row
+ * (~c) of the compact buffer of rows received from peers (B1, ldB1).  With
+ * one rank every index is >= 0 and B1 may be NULL.
+ */
+#ifndef CRPSPMM_HIP_H
+#define CRPSPMM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CRP_LAYOUT_ROW_MAJOR 0
+#define CRP_LAYOUT_COL_MAJOR 1
+
+/* Opaque device-resident sparse matrix (CSR arrays + launch schedule). */
+typedef struct crp_csr_dev *crp_csr_dev_p;
+
+/* ---- device management --------------------------------------------------- */
+int crp_hip_device_count(int *count);
+int crp_hip_set_device(int dev);
+int crp_hip_get_device(int *dev);
+/* name must hold >= 256 bytes; cu_count / hbm_bytes may be NULL. */
+int crp_hip_device_info(int dev, char *name, int *cu_count, size_t *hbm_bytes);
+
+int crp_dev_malloc(void **ptr, size_t bytes);
+int crp_dev_free(void *ptr);
+int crp_dev_memset(void *ptr, int value, size_t bytes, void *stream);
+/* kind: 0 host->device, 1 device->host, 2 device->device.  Asynchronous on
+ * `stream` when the host side is pinned; crp_stream_sync() to wait. */
+int crp_dev_memcpy(void *dst, const void *src, size_t bytes, int kind, void *stream);
+/* returns 1 in *is_dev when ptr is device memory, 0 for host memory. */
+int crp_dev_ptr_is_device(const void *ptr, int *is_dev);
+
+int crp_stream_create(void **stream);
+int crp_stream_destroy(void *stream);
+int crp_stream_sync(void *stream);
+int crp_event_create(void **event);
+int crp_event_destroy(void *event);
+int crp_event_record(void *event, void *stream);
+int crp_event_sync(void *event);
+int crp_stream_wait_event(void *stream, void *event);
+int crp_event_elapsed_ms(void *start, void *stop, float *ms);
+
+/* ---- device-resident CSR -------------------------------------------------- */
+/* Upload a host CSR (0-based rowptr[0] == 0, int32 indices, fp64 values).
+ * colidx may carry the two-source encoding described above; ncol is the row
+ * count of B0 (used for argument checking only).  Blocking. */
+int crp_csr_dev_create(int nrow, int ncol, const int *rowptr, const int *colidx,
+                       const double *val, crp_csr_dev_p *out);
+int crp_csr_dev_destroy(crp_csr_dev_p *A);
+int crp_csr_dev_nrow(crp_csr_dev_p A);
+long long crp_csr_dev_nnz(crp_csr_dev_p A);
+/* bytes of HBM the kernel must touch for A itself: 12*nnz + 4*(nrow+1). */
+long long crp_csr_dev_bytes(crp_csr_dev_p A);
+
+/* ---- the hot kernel --------------------------------------------------------
+ * C[nrow x n] := A * B (alpha = 1, beta = 0; C is overwritten, never read),
+ * the arithmetic of mkl_sparse_d_mm as called at src/rowpara_spmm.c:403-406:
+ * C[i][j] = sum_p val[p] * B[col[p]][j], p ascending within the row.
+ * layout 0: B0/B1/C row-major (ld >= n); layout 1: column-major
+ * (ldB0 >= rows of B0, ldB1 >= rows of B1, ldC >= nrow).  All pointers are
+ * device pointers; the launch is asynchronous on `stream`.  `variant` picks a
+ * kernel (0 = automatic); see crp_spmm_variant_name(). */
+int crp_spmm_csr_f64(crp_csr_dev_p A, int layout, int n,
+                     const double *B0, long long ldB0,
+                     const double *B1, long long ldB1,
+                     double *C, long long ldC, int variant, void *stream);
+const char *crp_spmm_variant_name(int variant);
+int crp_spmm_variant_count(void);
+
+/* ---- row gather / scatter (pack / unpack of the B exchange) ----------------
+ * gather : dst[i][0:n] = src[ridx[i]][0:n]   (i < nidx)
+ * scatter: dst[ridx[i]][0:n] = src[i][0:n]
+ * layout 0: rows are contiguous (row-major, leading dimensions in elements);
+ * layout 1: column-major operands (element (r, j) at r + j*ld).  ridx is a
+ * device array of int32. */
+int crp_gather_rows_f64(int layout, int nidx, int n, const int *ridx,
+                        const double *src, long long lds,
+                        double *dst, long long ldd, void *stream);
+int crp_scatter_rows_f64(int layout, int nidx, int n, const int *ridx,
+                         const double *src, long long lds,
+                         double *dst, long long ldd, void *stream);
+/* out-of-place transpose: dst[c][r] = src[r][c] for an nrow x ncol row-major
+ * src (equivalently col-major <-> row-major conversion). */
+int crp_transpose_f64(int nrow, int ncol, const double *src, long long lds,
+                      double *dst, long long ldd, void *stream);
+
+/* Library identification: "crpspmm-hip <version> gfx950". */
+const char *crp_hip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

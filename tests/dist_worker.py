@@ -1,0 +1,110 @@
+"""Worker for tests/test_dist_cpu.py: one process per rank, gloo backend, CPU only.
+Exercises the N > 1 host path of the engines end to end: exchange plan through the
+communicator callbacks, para2d replication of A, and the B exchange (on host
+buffers) -- everything except the HIP kernels, whose role is played by the oracle."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def slices(rp, ci, va, displs, r):
+    s, e = displs[r], displs[r + 1]
+    return rp[s:e + 1], ci[rp[s]:rp[e]], va[rp[s]:rp[e]]
+
+
+def emulate_exec(plan, comm, B_loc, n, orc):
+    """pack -> comm.alltoallv_dev_f64 (host buffers) -> two-source SpMM by the oracle."""
+    P = plan["nproc"]
+    send = np.ascontiguousarray(B_loc[plan["rB_sridxs"], :n]).reshape(-1)
+    if send.size == 0:
+        send = np.zeros(1)
+    nrecv = int(plan["rB_rdispls"][P])
+    recv = np.full(max(nrecv, 1), np.nan)
+    ll = lambda a: np.ascontiguousarray(a, dtype=np.int64).ctypes.data_as(C.POINTER(C.c_longlong))
+    sc, sd, rc, rd = (np.ascontiguousarray(plan[k], dtype=np.int64) for k in ("rB_scnts", "rB_sdispls", "rB_rcnts", "rB_rdispls"))
+    comm.struct.alltoallv_dev_f64(None, send.ctypes.data, ll(sc), ll(sd), recv.ctypes.data, ll(rc), ll(rd), None)
+    B1 = recv[:nrecv].reshape(-1, n) if nrecv else np.zeros((0, n))
+    # two-source column index -> one stacked operand [B_loc ; B1]
+    c = plan["dev_colidx"].astype(np.int64)
+    stacked = np.vstack([B_loc[:, :n], B1])
+    cc = np.where(c >= 0, c, B_loc.shape[0] + (~c))
+    return orc.spmm_csr(plan["A_rowptr"], cc.astype(np.int32), plan["A_val"], stacked, n=n)
+
+
+def main():
+    import torch.distributed as dist
+    import oracle as orc
+    from crp_spmm_amd import comm as crp_comm, engine, gen, planner
+
+    crp_comm.init_process_group()
+    world = crp_comm.TorchComm()
+    P, me = world.nproc, world.rank
+    m, k, n = 1500, 1500, 12
+    rp, ci, va = gen.banded_fem(m, offsets=(1, 2, 3, 40, 41, 400), seed=9)
+    B = orc.fill_B(0, k, 0, n)
+    C_ref = orc.spmm_csr(rp, ci, va, B)
+
+    # ---- 1D engine (test_rp_spmm protocol, examples/test_rp_spmm.c:55-124)
+    rb = planner.csr_mat_row_partition(rp, P)
+    parts = [slices(rp, ci, va, rb, r) for r in range(P)]
+    for reidx in ("1", "0"):
+        os.environ["RP_SPMM_REIDX"] = reidx
+        e = engine.RpSpmm(int(rb[me]), int(rb[me + 1] - rb[me]), *parts[me], rb, n, world, plan_only=True)
+        p = e.plan()
+        o = orc.rp_plan_all(parts, rb, n, reidx=int(reidx))[me]
+        for key in ("A_rowptr", "A_colidx", "rB_nrow", "rB_self_nrow", "rB_self_src_offset", "rB_self_dst_offset",
+                    "rB_self_src_ridxs", "rB_sridxs", "rB_rridxs", "rB_rcnts", "rB_scnts", "rB_rdispls",
+                    "rB_sdispls", "rB_recv_size"):
+            assert np.array_equal(np.asarray(p[key]), np.asarray(o[key])), (me, reidx, key)
+        C_loc = emulate_exec(p, world, B[rb[me]:rb[me + 1]], n, orc)
+        assert orc.rel_fro_err(C_ref[rb[me]:rb[me + 1]], C_loc) <= 1e-13, (me, "1D")
+        e.free()
+    os.environ.pop("RP_SPMM_REIDX")
+
+    # ---- 2D engine (test_para2d_spmm protocol, examples/test_para2d_spmm.c:46-149); force every grid
+    for pn in [d for d in range(1, P + 1) if P % d == 0]:
+        pm = P // pn
+        plan2d = planner.calc_spmm_part2d_from_1d(P, m, n, k, rb, rp, ci)
+        # derive arrays for the forced grid the way the planner does (src/spmat_part.c:169-202)
+        ac = np.array([rb[i * pn] for i in range(pm + 1)], dtype=np.int32)
+        a0 = np.zeros(P + 1, dtype=np.int32)
+        for i in range(pm):
+            loc = rp[ac[i]:ac[i + 1] + 1] - rp[ac[i]]
+            a0[i * pn:(i + 1) * pn + 1] = planner.csr_mat_row_partition(loc, pn) + ac[i]
+        bc = planner.even_displs(n, pn)
+        if (pm, pn) == (plan2d["pm"], plan2d["pn"]):
+            assert np.array_equal(a0, plan2d["A0_rowptr"]) and np.array_equal(ac, plan2d["AC_rowptr"])
+        pi, pj = me // pn, me % pn
+        e2 = engine.Para2dSpmm(world, pm, pn, a0, ac, ac, bc, *slices(rp, ci, va, a0, me), plan_only=True)
+        p = e2.rp.plan()
+        # oracle: the column communicator of pj holds the pm panels, n_loc columns
+        n_loc = int(bc[pj + 1] - bc[pj])
+        panels = [slices(rp, ci, va, ac, i) for i in range(pm)]
+        o = orc.rp_plan_all(panels, ac, n_loc)[pi]
+        for key in ("A_rowptr", "A_colidx", "A_val", "rB_nrow", "rB_sridxs", "rB_rridxs", "rB_rcnts", "rB_scnts"):
+            assert np.array_equal(np.asarray(p[key]), np.asarray(o[key])), (me, pm, pn, key)
+        assert e2.rA_cost == int(float(rp[-1]) * (pn - 1) * 1.5)
+        col_comm = None
+        for c in list(crp_comm._live.values()):
+            if c.nproc == pm and c is not world and c.rank == pi:
+                col_comm = c
+        B_loc = np.ascontiguousarray(B[ac[pi]:ac[pi + 1], bc[pj]:bc[pj + 1]])
+        if n_loc > 0:
+            C_loc = emulate_exec(p, col_comm if pm > 1 else world, B_loc, n_loc, orc) if pm > 1 else \
+                orc.spmm_csr(p["A_rowptr"], p["dev_colidx"], p["A_val"], B_loc, n=n_loc)
+            assert orc.rel_fro_err(C_ref[ac[pi]:ac[pi + 1], bc[pj]:bc[pj + 1]], C_loc) <= 1e-13, (me, pm, pn)
+        e2.free()
+        dist.barrier()
+    dist.barrier()
+    if me == 0:
+        print("DIST_WORKER_OK world=%d" % P)
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

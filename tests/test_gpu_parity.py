@@ -1,0 +1,247 @@
+"""GPU (MI355X): parity of the HIP hot path, called through the C ABI, against the
+oracle, the MKL golden fixtures and size-independent properties.
+Tolerance: relative Frobenius error <= 1e-12 (BASELINE.json north_star, fp64);
+byte-moving kernels (gather / scatter / transpose) must be bit-exact."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import FP64_TOL, GOLDEN, GOLDEN_NAMES, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(x, dev):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+
+
+def _spmm(crp, dev, rp, ci, va, k, B, n, layout=0, B1=None, ldpad=0):
+    import torch
+    from crp_spmm_amd import hip
+    A = hip.CsrDev(len(rp) - 1, k, rp, ci, va)
+    m = len(rp) - 1
+    if layout == 0:
+        Bd = torch.zeros((B.shape[0], n + ldpad), dtype=torch.float64, device=dev)
+        Bd[:, :n] = _t(B[:, :n], dev)
+        Cd = torch.full((m, n + ldpad), float("nan"), dtype=torch.float64, device=dev)
+        B1d = None
+        if B1 is not None:
+            B1d = _t(B1[:, :n], dev)
+        hip.spmm_csr(A, Bd[:, :n] if ldpad else Bd, Cd[:, :n] if ldpad else Cd, n=n, B1=B1d)
+        torch.cuda.synchronize()
+        out = Cd.cpu().numpy()
+        if ldpad:
+            assert np.isnan(out[:, n:]).all()       # padding between rows is never written
+        A.free()
+        return out[:, :n]
+    # column-major: operands as (n, ld)
+    ldb, ldc = B.shape[0] + 3, m + 2
+    Bd = torch.zeros((n, ldb), dtype=torch.float64, device=dev)
+    Bd[:, :B.shape[0]] = _t(B[:, :n].T, dev)
+    Cd = torch.full((n, ldc), float("nan"), dtype=torch.float64, device=dev)
+    hip.spmm_csr(A, Bd, Cd, n=n, layout=1)
+    torch.cuda.synchronize()
+    out = Cd.cpu().numpy()
+    assert np.isnan(out[:, m:]).all()
+    A.free()
+    return out[:, :m].T
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 7, 8, 16, 31, 32, 33, 64, 100, 128, 129, 256, 300, 512])
+def test_kernel_vs_oracle_all_widths(crp, orc, gpu, n):
+    from crp_spmm_amd import gen
+    m, k = 777, 1234
+    rp, ci, va = gen.random_csr(m, k, 70, seed=n, empty_every=13)
+    B = np.random.default_rng(n).uniform(-2, 2, size=(k, n))
+    ref = orc.spmm_csr(rp, ci, va, B)
+    for ldpad in (0, 1, 2):
+        got = _spmm(crp, gpu, rp, ci, va, k, B, n, ldpad=ldpad)
+        assert orc.rel_fro_err(ref, got) <= FP64_TOL, (n, ldpad)
+        assert not got[::13].any()                     # empty rows: exact zeros
+
+
+@pytest.mark.parametrize("name", GOLDEN_NAMES)
+def test_kernel_vs_mkl_golden(crp, orc, gpu, name):
+    g, s = load_golden(name, "csr"), load_golden(name, "spmm")
+    k = int(g["k"])
+    for n in (4, 33):
+        got = _spmm(crp, gpu, g["rowptr"], g["colidx"], g["val"], k, orc.fill_B(0, k, 0, n), n)
+        assert orc.rel_fro_err(s["C_fillB_n%d" % n], got) <= FP64_TOL
+    got = _spmm(crp, gpu, g["rowptr"], g["colidx"], g["val"], k, s["B2"], 6)
+    assert orc.rel_fro_err(s["C_B2"], got) <= FP64_TOL
+    got = _spmm(crp, gpu, g["rowptr"], g["colidx"], g["val"], k, orc.fill_B(0, k, 0, 5), 5, layout=1)
+    assert orc.rel_fro_err(s["C_fillB_colmajor_n5"].T, got) <= FP64_TOL
+
+
+def test_kernel_two_source_index(crp, orc, gpu):
+    """c >= 0 reads the local block, c < 0 reads row ~c of the receive buffer."""
+    from crp_spmm_amd import gen
+    m, k = 500, 900
+    rp, ci, va = gen.random_csr(m, k, 30, seed=2)
+    n = 48
+    B = np.random.default_rng(0).normal(size=(k, n))
+    lo, hi = 300, 650                                   # rows [lo, hi) are "local", the rest "received"
+    remote_rows = np.concatenate([np.arange(0, lo), np.arange(hi, k)])
+    pos = np.full(k, -1)
+    pos[remote_rows] = np.arange(remote_rows.size)
+    c2 = np.where((ci >= lo) & (ci < hi), ci - lo, ~pos[ci]).astype(np.int32)
+    got = _spmm(crp, gpu, rp, c2, va, hi - lo, B[lo:hi], n, B1=B[remote_rows])
+    assert orc.rel_fro_err(orc.spmm_csr(rp, ci, va, B), got) <= FP64_TOL
+
+
+def test_kernel_edge_shapes(crp, orc, gpu):
+    import torch
+    from crp_spmm_amd import hip
+    # zero rows, zero columns of B/C, zero nnz
+    A = hip.CsrDev(0, 5, np.zeros(1, np.int32), np.zeros(0, np.int32), np.zeros(0))
+    hip.spmm_csr(A, torch.zeros((5, 4), dtype=torch.float64, device=gpu), torch.zeros((0, 4), dtype=torch.float64, device=gpu), n=4)
+    A.free()
+    A = hip.CsrDev(6, 5, np.zeros(7, np.int32), np.zeros(0, np.int32), np.zeros(0))
+    Cd = torch.full((6, 4), 7.0, dtype=torch.float64, device=gpu)
+    hip.spmm_csr(A, torch.ones((5, 4), dtype=torch.float64, device=gpu), Cd, n=4)
+    torch.cuda.synchronize()
+    assert not Cd.cpu().numpy().any()                   # beta = 0: C overwritten with zeros
+    A.free()
+    # one long row (> 64 nonzeros, several broadcast rounds) and duplicates / explicit zeros
+    k = 400
+    ci = np.sort(np.concatenate([np.arange(k), np.array([3, 3, 77])])).astype(np.int32)
+    va = np.linspace(-1, 1, ci.size)
+    va[5] = 0.0
+    rp = np.array([0, ci.size], dtype=np.int32)
+    B = np.random.default_rng(4).normal(size=(k, 20))
+    got = _spmm(crp, gpu, rp, ci, va, k, B, 20)
+    assert orc.rel_fro_err(orc.spmm_csr(rp, ci, va, B), got) <= FP64_TOL
+    # bad arguments are reported, not executed
+    lib = crp.load()
+    assert lib.crp_spmm_csr_f64(None, 0, 4, None, 0, None, 0, None, 0, 0, None) != 0
+
+
+def test_row_kernels_bit_exact(crp, gpu):
+    import torch
+    from crp_spmm_amd import hip
+    rng = np.random.default_rng(1)
+    for n in (1, 6, 7, 256):
+        src = rng.normal(size=(300, n))
+        idx = rng.integers(0, 300, size=411).astype(np.int32)
+        sd, id_ = _t(src, gpu), _t(idx, gpu)
+        dst = torch.zeros((411, n), dtype=torch.float64, device=gpu)
+        hip.gather_rows(id_, sd, dst)
+        assert np.array_equal(dst.cpu().numpy(), src[idx])
+        perm = rng.permutation(300).astype(np.int32)
+        out = torch.zeros((300, n), dtype=torch.float64, device=gpu)
+        hip.gather_rows(_t(perm, gpu), sd, out, scatter=True)
+        exp = np.zeros_like(src)
+        exp[perm] = src
+        assert np.array_equal(out.cpu().numpy(), exp)
+        # column-major gather: operands (n, ld)
+        srcT = _t(np.ascontiguousarray(src.T), gpu)
+        dstT = torch.zeros((n, 411), dtype=torch.float64, device=gpu)
+        hip.gather_rows(id_, srcT, dstT, layout=1)
+        assert np.array_equal(dstT.cpu().numpy(), src[idx].T)
+    for (r, c) in [(1, 1), (33, 65), (300, 7), (64, 64)]:
+        x = rng.normal(size=(r, c))
+        y = torch.zeros((c, r), dtype=torch.float64, device=gpu)
+        hip.transpose(_t(x, gpu), y)
+        assert np.array_equal(y.cpu().numpy(), x.T)
+
+
+@pytest.mark.parametrize("layout", [0, 1])
+@pytest.mark.parametrize("where", ["device", "host"])
+def test_rp_engine_single_rank(crp, orc, gpu, layout, where):
+    """rp_spmm protocol of examples/test_rp_spmm.c:120-145 at one rank, B = fill_B."""
+    import torch
+    from crp_spmm_amd import comm, engine, gen
+    m = k = 3000
+    rp, ci, va = gen.banded_fem(m, offsets=(1, 2, 5, 90, 700), seed=3)
+    n = 40
+    B = orc.fill_B(0, k, 0, n)
+    ref = orc.spmm_csr(rp, ci, va, B)
+    sc = comm.SelfComm()
+    e = engine.RpSpmm(0, m, rp, ci, va, [0, k], n, sc)
+    if layout == 0:
+        Bh, Ch = B.copy(), np.full((m, n), np.nan)
+    else:
+        Bh, Ch = np.ascontiguousarray(B.T), np.full((n, m), np.nan)
+    if where == "device":
+        Bx, Cx = _t(Bh, gpu), _t(Ch, gpu)
+    else:
+        Bx, Cx = Bh, Ch
+    e.exec(layout, Bx, Cx)          # warm-up, like the reference driver
+    e.clear_stat()
+    for _ in range(2):
+        e.exec(layout, Bx, Cx)
+    if where == "device":
+        torch.cuda.synchronize()
+        Cx = Cx.cpu().numpy()
+    got = Cx if layout == 0 else Cx.T
+    assert orc.rel_fro_err(ref, got) <= FP64_TOL
+    v = e.plan()
+    assert v["n_exec"] == 2 and v["t_exec"] > 0 and v["t_spmm"] > 0 and v["t_unpack"] == 0
+    e.print_stat()
+    e.free()
+    sc.free()
+
+
+def test_para2d_engine_single_rank_no_deadlock(crp, orc, gpu):
+    """para2d at one rank (the reference self-sends and hangs: src/para2d_spmm.c:102-109)."""
+    import torch
+    from crp_spmm_amd import comm, engine, gen, planner
+    m, k = 900, 900
+    rp, ci, va = gen.random_csr(m, k, 25, seed=8)
+    n = 16
+    rb = planner.csr_mat_row_partition(rp, 1)
+    pl = planner.calc_spmm_part2d_from_1d(1, m, n, k, rb, rp, ci)
+    assert (pl["pm"], pl["pn"]) == (1, 1)
+    sc = comm.SelfComm()
+    e = engine.Para2dSpmm(sc, 1, 1, pl["A0_rowptr"], pl["B_rowptr"], pl["AC_rowptr"], pl["BC_colptr"], rp, ci, va)
+    B = orc.fill_B(0, k, 0, n)
+    Cd = torch.zeros((m, n), dtype=torch.float64, device=gpu)
+    e.exec(0, _t(B, gpu), Cd)
+    torch.cuda.synchronize()
+    assert orc.rel_fro_err(orc.spmm_csr(rp, ci, va, B), Cd.cpu().numpy()) <= FP64_TOL
+    assert e.rA_cost == 0
+    e.print_stat()
+    e.free()
+    sc.free()
+
+
+def test_full_size_properties_pwtk_standin(crp, orc, gpu):
+    """BASELINE config 2 size (pwtk stand-in, n = 256): closed form for fill_B, linearity,
+    and a sampled-row comparison with the oracle (the full oracle product would take minutes)."""
+    import torch
+    from crp_spmm_amd import gen, hip
+    m = k = 217918
+    n = 256
+    rp, ci, va = gen.banded_fem(m)
+    assert rp[-1] == 11102984
+    A = hip.CsrDev(m, k, rp, ci, va)
+    i = torch.arange(k, dtype=torch.float64, device=gpu)[:, None]
+    j = torch.arange(n, dtype=torch.float64, device=gpu)[None, :]
+    B = i * 0.19 + j * 0.24                                   # fill_B on the device
+    C1 = torch.empty((m, n), dtype=torch.float64, device=gpu)
+    hip.spmm_csr(A, B, C1)
+    rows = np.repeat(np.arange(m), np.diff(rp))
+    s1 = np.bincount(rows, weights=va * ci, minlength=m)
+    s0 = np.bincount(rows, weights=va, minlength=m)
+    expect = 0.19 * s1[:, None] + 0.24 * np.arange(n)[None, :] * s0[:, None]
+    got = C1.cpu().numpy()
+    assert np.linalg.norm(got - expect) / np.linalg.norm(expect) <= 1e-12
+    # sampled rows against the oracle
+    pick = np.unique(np.random.default_rng(0).integers(0, m, size=400))
+    sub_rp = np.concatenate([[0], np.cumsum(rp[pick + 1] - rp[pick])]).astype(np.int32)
+    sel = np.concatenate([np.arange(rp[r], rp[r + 1]) for r in pick])
+    ref = orc.spmm_csr(sub_rp, ci[sel], va[sel], B.cpu().numpy())
+    assert orc.rel_fro_err(ref, got[pick]) <= FP64_TOL
+    # linearity: A(2X - 3Y) == 2AX - 3AY
+    g = torch.Generator(device=gpu).manual_seed(1)
+    X = torch.rand((k, n), dtype=torch.float64, device=gpu, generator=g)
+    Y = torch.rand((k, n), dtype=torch.float64, device=gpu, generator=g)
+    CX, CY, CZ = (torch.empty((m, n), dtype=torch.float64, device=gpu) for _ in range(3))
+    hip.spmm_csr(A, X, CX)
+    hip.spmm_csr(A, Y, CY)
+    hip.spmm_csr(A, 2 * X - 3 * Y, CZ)
+    lin = 2 * CX - 3 * CY
+    assert (torch.linalg.norm(CZ - lin) / torch.linalg.norm(lin)).item() <= 1e-12
+    A.free()

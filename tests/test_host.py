@@ -1,0 +1,217 @@
+"""CPU: host logic of the product library (planner, ingest, exchange plan, C ABI
+surface) against the oracle and the golden fixtures.  No device calls."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, GOLDEN_NAMES, ROOT, load_golden
+
+PS = (1, 2, 3, 4, 6, 8)
+NS = (1, 4, 64, 128, 512)
+
+
+def test_library_exports_every_declared_symbol(crp):
+    """Every function declared in include/*.h is exported by the C-ABI library and
+    bound in _lib.SIGNATURES (MPI-typed facade headers are checked against libcrpspmm.so)."""
+    from crp_spmm_amd import _lib
+    inc = os.path.join(ROOT, "include")
+    core = ["crpspmm_hip.h", "crp_comm.h", "crp_engine.h", "utils.h", "spmat_part.h", "mmio_utils.h"]
+    pat = re.compile(r"^\s*(?:const\s+)?[A-Za-z_][\w\s\*]*?\b(\w+)\s*\(", re.M)
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln}
+    declared = set()
+    for h in core:
+        txt = open(os.path.join(inc, h)).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        txt = re.sub(r"#define[^\n]*(\\\n[^\n]*)*", "", txt)
+        body = txt.replace("\n", " ")
+        for stmt in body.split(";"):
+            mm = re.match(r"\s*(?:extern\s+\"C\"\s*\{)?\s*((?:const\s+)?(?:unsigned\s+)?[A-Za-z_]\w*(?:\s+[A-Za-z_]\w*)*[\s\*]+)(\w+)\s*\(", stmt)
+            if mm and "(*" not in stmt.split("(")[0] and mm.group(2) not in ("defined",) and "typedef" not in stmt.split("(")[0]:
+                declared.add(mm.group(2))
+    declared = {d for d in declared if not d.startswith("__")}
+    assert len(declared) > 60, sorted(declared)
+    missing = sorted(d for d in declared if d not in exported)
+    assert not missing, "declared but not exported: %s" % missing
+    unbound = sorted(d for d in declared if d not in _lib.SIGNATURES)
+    assert not unbound, "declared but not bound in _lib.SIGNATURES: %s" % unbound
+
+
+def test_missing_library_fails_loudly(crp, monkeypatch):
+    from crp_spmm_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libcrpspmm_hip.so")
+    with pytest.raises(_lib.CrpLibraryError):
+        _lib.load()
+
+
+def test_product_does_not_reference_oracle():
+    """The product tree never imports / links the oracle."""
+    pkg = os.path.join(ROOT, "crp-spmm_amd")
+    for base, _dirs, files in os.walk(pkg):
+        if os.sep + "build" in base or os.sep + "lib" in base:
+            continue
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", "Makefile")):
+                txt = open(os.path.join(base, f), errors="ignore").read()
+                assert "import oracle" not in txt and "liborc" not in txt and "from oracle" not in txt, f
+
+
+@pytest.mark.parametrize("name", GOLDEN_NAMES)
+def test_ingest_vs_golden(crp, name):
+    from crp_spmm_amd import mmio
+    g = load_golden(name, "csr")
+    m, k, rp, ci, cv = mmio.read_mtx_csr(os.path.join(GOLDEN, name + ".mtx"), verbose=False)
+    assert (m, k) == (int(g["m"]), int(g["k"]))
+    assert np.array_equal(rp, g["rowptr"]) and np.array_equal(ci, g["colidx"])
+    # values: identical except the order of exact duplicates (same row, same column), which the
+    # reference's unstable quicksort leaves unspecified -> compare per-(row, col) multisets
+    rows = np.repeat(np.arange(m), np.diff(rp))
+    a = np.lexsort((cv, ci, rows))
+    b = np.lexsort((g["val"], g["colidx"], rows))
+    assert np.array_equal(cv[a], g["val"][b])
+
+
+def test_ingest_rejects_what_the_reference_rejects(crp, tmp_path, orc):
+    from crp_spmm_amd import mmio
+    cases = {
+        "complex.mtx": "%%MatrixMarket matrix coordinate complex general\n2 2 1\n1 1 1.0 0.0\n",
+        "skew.mtx": "%%MatrixMarket matrix coordinate real skew-symmetric\n2 2 1\n2 1 1.0\n",
+        "herm.mtx": "%%MatrixMarket matrix coordinate real hermitian\n2 2 1\n2 1 1.0\n",
+        "array.mtx": "%%MatrixMarket matrix array real general\n2 2\n1\n2\n3\n4\n",
+        "nobanner.mtx": "2 2 1\n1 1 1.0\n",
+        "badtype.mtx": "%%MatrixMarket matrix coordinate quaternion general\n2 2 1\n1 1 1.0\n",
+    }
+    for fn, txt in cases.items():
+        p = tmp_path / fn
+        p.write_text(txt)
+        assert mmio.mm_read_sparse_RPI(str(p))[0] == -1, fn
+        assert orc.mm_read(str(p))[0] == -1, fn
+        if orc.ref() is not None:
+            assert orc.ref_mm_read(str(p))[0] == -1, fn
+    assert mmio.mm_read_sparse_RPI(str(tmp_path / "does_not_exist.mtx"))[0] == -1
+    # need_symm on a general file (METIS path of the drivers, examples/test_rp_spmm.c:21-22)
+    assert mmio.mm_read_sparse_RPI(os.path.join(GOLDEN, "g_gen.mtx"), need_symm=1)[0] == -1
+    # accepted: upper-case banner tokens, comment lines, blank line before the size line
+    ok = tmp_path / "ok.mtx"
+    ok.write_text("%%MatrixMarket MATRIX Coordinate REAL Symmetric\n% c1\n% c2\n\n3 3 2\n2 1 1.5\n3 3 -2\n")
+    st, m, k, r, c, v = mmio.mm_read_sparse_RPI(str(ok))
+    assert st == 0 and (m, k) == (3, 3)
+    assert list(r) == [1, 2, 0] and list(c) == [0, 2, 1] and list(v) == [1.5, -2.0, 1.5]
+    assert [list(x) for x in orc.mm_read(str(ok))[3:]] == [[1, 2, 0], [0, 2, 1], [1.5, -2.0, 1.5]]
+
+
+@pytest.mark.parametrize("name", GOLDEN_NAMES)
+def test_planner_vs_golden(crp, name):
+    from crp_spmm_amd import planner
+    g, p = load_golden(name, "csr"), load_golden(name, "plan")
+    m, k = int(g["m"]), int(g["k"])
+    for P in PS:
+        rb = planner.csr_mat_row_partition(g["rowptr"], P)
+        assert np.array_equal(rb, p["rb_P%d" % P])
+        for n in NS:
+            r = planner.calc_spmm_part2d_from_1d(P, m, n, k, rb, g["rowptr"], g["colidx"])
+            key = "P%d_n%d_" % (P, n)
+            assert [r["pm"], r["pn"]] == list(p[key + "grid"]) and r["comm_cost"] == int(p[key + "cost"][0])
+            for a in ("A0_rowptr", "B_rowptr", "AC_rowptr", "BC_colptr"):
+                assert np.array_equal(r[a], p[key + a]), (P, n, a)
+
+
+def test_planner_vs_oracle_random(crp, orc):
+    from crp_spmm_amd import gen, planner
+    for seed, (m, k) in enumerate([(2000, 2000), (700, 1900), (1900, 700), (50, 50)]):
+        rp, ci, va = gen.random_csr(m, k, 14, seed=seed + 20, empty_every=11 if seed % 2 else 0)
+        for P in (1, 2, 3, 4, 5, 6, 7, 8, 12, 16):
+            a = planner.csr_mat_row_partition(rp, P)
+            assert np.array_equal(a, orc.csr_row_partition(rp, P))
+            x = a if m == k else planner.even_displs(k, P)
+            s1, t1 = planner.csr_mat_row_part_comm_size(k, rp, ci, a, x)
+            s2, t2 = orc.csr_row_part_comm_size(k, rp, ci, a, x)
+            assert np.array_equal(s1, s2) and t1 == t2
+            for n in (1, 8, 100, 1024):
+                for rA in (1, 3):
+                    r1 = planner.calc_spmm_part2d_from_1d(P, m, n, k, a, rp, ci, rA=rA)
+                    r2 = orc.part2d_from_1d(P, m, n, k, a, rp, ci, rA=rA)
+                    for key in r1:
+                        assert np.array_equal(np.asarray(r1[key]), np.asarray(r2[key])), (P, n, key)
+    assert planner.prime_factorization(360) == [2, 2, 2, 3, 3, 5] and planner.prime_factorization(1) == []
+    assert planner.prime_factorization(97) == [97]
+    for length, nblk in [(10, 3), (7, 7), (5, 8), (0, 2)]:
+        for i in range(-1, nblk + 2):
+            assert planner.calc_block_spos_size(length, nblk, i) == orc.block_spos(length, nblk, i)
+
+
+def test_utils_abi(crp, orc):
+    lib = crp.load()
+    x0 = np.linspace(-1, 2, 1001)
+    x1 = x0 + 1e-9 * np.cos(np.arange(1001))
+    a, e = C.c_double(), C.c_double()
+    lib.calc_err_2norm(1001, x0.ctypes.data_as(C.POINTER(C.c_double)), x1.ctypes.data_as(C.POINTER(C.c_double)),
+                       C.byref(a), C.byref(e))
+    assert (a.value, e.value) == orc.err_2norm(x0, x1)
+    assert lib.calc_2norm(1001, x0.ctypes.data_as(C.POINTER(C.c_double))) == a.value
+    src = np.arange(35, dtype=np.float64).reshape(5, 7)
+    dst = np.zeros((5, 9))
+    for omp in (0, 1):
+        dst[:] = 0
+        lib.copy_matrix(8, 5, 4, src.ctypes.data, 7, dst.ctypes.data, 9, omp)
+        assert np.array_equal(dst[:, :4], src[:, :4]) and not dst[:, 4:].any()
+    t0 = lib.get_wtime_sec()
+    assert lib.get_wtime_sec() >= t0 > 1e9
+    p = lib.malloc_aligned(100, 64)
+    assert p % 64 == 0
+    lib.free_aligned(p)
+
+
+def test_rp_plan_single_rank_vs_oracle(crp, orc):
+    from crp_spmm_amd import comm, engine, gen
+    sc = comm.SelfComm()
+    for seed, (m, k) in enumerate([(800, 800), (300, 900)]):
+        rp, ci, va = gen.random_csr(m, k, 12, seed=seed + 3, empty_every=17)
+        e = engine.RpSpmm(0, m, rp, ci, va, [0, k], 8, sc, plan_only=True)
+        p = e.plan()
+        o = orc.rp_plan_all([(rp, ci, va)], [0, k], 8)[0]
+        for key in ("A_rowptr", "A_colidx", "A_val", "rB_nrow", "rB_self_nrow", "rB_self_src_offset",
+                    "rB_self_dst_offset", "rB_self_src_ridxs", "rB_sridxs", "rB_rridxs", "rB_rcnts", "rB_scnts",
+                    "rB_rdispls", "rB_sdispls", "rB_recv_size"):
+            assert np.array_equal(np.asarray(p[key]), np.asarray(o[key])), key
+        assert np.array_equal(p["dev_colidx"], ci)         # one rank: every column is a local B row
+        assert e.alg_bytes() == 12 * ci.size + 4 * (m + 1) + 8 * 8 * np.unique(ci).size + 8 * 8 * m
+        e.free()
+    # empty matrix / empty rank
+    e = engine.RpSpmm(0, 5, np.zeros(6, np.int32), np.zeros(0, np.int32), np.zeros(0), [0, 9], 4, sc, plan_only=True)
+    p = e.plan()
+    assert p["rB_nrow"] == 0 and p["rB_self_nrow"] == 0 and p["A_colidx"].size == 0
+    e.free()
+    sc.free()
+
+
+def test_rp_plan_env_knobs(crp, orc, monkeypatch, capfd):
+    from crp_spmm_amd import comm, engine, gen
+    rp, ci, va = gen.random_csr(200, 200, 6, seed=1)
+    ci = ci.copy()
+    sel = ci < 20
+    ci[sel] += 20                                 # leave a hole at the low end so reidx=0 differs
+    order = np.concatenate([np.sort(ci[rp[i]:rp[i + 1]]) for i in range(200)])
+    sc = comm.SelfComm()
+    monkeypatch.setenv("RP_SPMM_REIDX", "0")
+    monkeypatch.setenv("RP_SPMM_P2P", "0")
+    e = engine.RpSpmm(0, 200, rp, order, va, [0, 200], 4, sc, plan_only=True)
+    p = e.plan()
+    o = orc.rp_plan_all([(rp, order, va)], [0, 200], 4, reidx=0)[0]
+    assert p["rB_reidx"] == 0 and p["rB_p2p"] == 0
+    for key in ("A_colidx", "rB_nrow", "rB_self_dst_offset", "rB_self_src_offset", "rB_self_nrow"):
+        assert np.array_equal(np.asarray(p[key]), np.asarray(o[key])), key
+    out = capfd.readouterr().out
+    assert "Overriding parameter rB_reidx: 1 (default) --> 0 (runtime)" in out     # src/utils.h:79-83
+    assert "Overriding parameter rB_p2p: 1 (default) --> 0 (runtime)" in out
+    e.free()
+    monkeypatch.setenv("RP_SPMM_REIDX", "7")      # out of range -> default, no message
+    e = engine.RpSpmm(0, 200, rp, order, va, [0, 200], 4, sc, plan_only=True)
+    assert e.plan()["rB_reidx"] == 1
+    e.free()
+    sc.free()
