@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", type=int, default=1)
+    ap.add_argument("--sweep-variants", action="store_true", help="also time kernel variants 1..3 (stderr)")
     args = ap.parse_args()
 
     import torch
@@ -147,6 +148,22 @@ def main():
         err = np.linalg.norm(got - expect) / max(np.linalg.norm(expect), 1e-300)
         if not err <= 1e-12:
             raise SystemExit("rank %d: result check failed, rel. Frobenius error %.3e" % (rank, err))
+
+    if args.sweep_variants and not distributed:
+        for v in range(1, lib.crp_spmm_variant_count()):
+            rp_eng.set_variant(v)
+            step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                step()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / 20
+            print("variant %d (%s): %.4f ms/step wall" % (v, lib.crp_spmm_variant_name(v).decode(), dt * 1e3),
+                  file=sys.stderr)
+        rp_eng.set_variant(args.variant)
+        step()
+        torch.cuda.synchronize()
 
     # ---- timed region: K steps between barrier + synchronize; HIP events per step on the launch stream
     ev = [(C.c_void_p(), C.c_void_p()) for _ in range(args.steps)]

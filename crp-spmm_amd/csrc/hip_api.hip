@@ -6,17 +6,36 @@
 #include <stdlib.h>
 #include <string.h>
 #include <new>
+#include <vector>
 #include "crpspmm_hip.h"
 #include "kernels.h"
+#include "panel_format.h"
+
+// device copy of one row-panel format (panel_format.h)
+struct PanelDev
+{
+    bool      built = false;
+    int       R = 0, npanel = 0;
+    int      *pptr = nullptr, *pcol = nullptr;
+    uint32_t *pmask4 = nullptr;
+    double   *pval = nullptr;
+    double    fill = 0.0;
+    long long entries = 0;
+};
 
 struct crp_csr_dev
 {
-    int       nrow;
-    int       ncol;
-    long long nnz;
-    int      *rowptr;
-    int      *colidx;
-    double   *val;
+    int       nrow = 0;
+    int       ncol = 0;
+    long long nnz = 0;
+    int      *rowptr = nullptr;
+    int      *colidx = nullptr;
+    double   *val = nullptr;
+    // host copy kept for building further formats on demand
+    std::vector<int>    h_rowptr, h_colidx;
+    std::vector<double> h_val;
+    PanelDev pan[2];          // [0]: R = 4, [1]: R = 8
+    int      auto_variant = 1; // what variant 0 resolves to (1 rowgroup, 2 panel R4, 3 panel R8)
 };
 
 #define CRP_TRY(expr)                                 \
@@ -25,6 +44,32 @@ struct crp_csr_dev
         hipError_t e__ = (expr);                      \
         if (e__ != hipSuccess) return (int) e__;      \
     } while (0)
+
+// Build (once) and upload the row-panel format with R = 4 (idx 0) or 8 (idx 1). Blocking.
+static int ensure_panel(crp_csr_dev *A, int idx)
+{
+    PanelDev &d = A->pan[idx];
+    if (d.built) return 0;
+    crp::PanelHost h;
+    crp::build_panels(A->nrow, A->h_rowptr.data(), A->h_colidx.data(), A->h_val.data(), idx == 0 ? 4 : 8, &h);
+    d.R = h.R;
+    d.npanel = h.npanel;
+    d.fill = h.fill();
+    d.entries = (long long) h.pcol.size();
+    hipError_t e = hipMalloc((void **) &d.pptr, sizeof(int) * h.pptr.size());
+    if (e == hipSuccess) e = hipMalloc((void **) &d.pcol, sizeof(int) * (h.pcol.size() + 4));
+    if (e == hipSuccess) e = hipMalloc((void **) &d.pmask4, sizeof(uint32_t) * h.pmask4.size());
+    if (e == hipSuccess) e = hipMalloc((void **) &d.pval, sizeof(double) * (h.pval.size() + 8));
+    if (e == hipSuccess) e = hipMemcpy(d.pptr, h.pptr.data(), sizeof(int) * h.pptr.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess && !h.pcol.empty())
+        e = hipMemcpy(d.pcol, h.pcol.data(), sizeof(int) * h.pcol.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d.pmask4, h.pmask4.data(), sizeof(uint32_t) * h.pmask4.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess && !h.pval.empty())
+        e = hipMemcpy(d.pval, h.pval.data(), sizeof(double) * h.pval.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return (int) e;
+    d.built = true;
+    return 0;
+}
 
 extern "C" {
 
@@ -152,7 +197,6 @@ int crp_csr_dev_create(int nrow, int ncol, const int *rowptr, const int *colidx,
     if (nnz > 0 && (colidx == NULL || val == NULL)) return -1;
     crp_csr_dev *A = new (std::nothrow) crp_csr_dev;
     if (A == NULL) return -3;
-    memset(A, 0, sizeof(*A));
     A->nrow = nrow;
     A->ncol = ncol;
     A->nnz  = nnz;
@@ -169,6 +213,35 @@ int crp_csr_dev_create(int nrow, int ncol, const int *rowptr, const int *colidx,
         crp_csr_dev_destroy(&tmp);
         return (int) e;
     }
+    A->h_rowptr.assign(rowptr, rowptr + nrow + 1);
+    if (nnz > 0)
+    {
+        A->h_colidx.assign(colidx, colidx + nnz);
+        A->h_val.assign(val, val + nnz);
+    }
+    // Pick the kernel family variant 0 resolves to.  The panel kernels pay off when rows of a
+    // panel share columns (banded / FEM / block structure); with no sharing (fill -> 1/R) the
+    // plain CSR kernel moves fewer bytes.  CRPSPMM_SPMM_VARIANT overrides (1, 2 or 3).
+    A->auto_variant = 1;
+    if (nnz > 0 && nrow >= 8)
+    {
+        const long long e4 = crp::count_panel_entries(nrow, rowptr, colidx, 4);
+        const long long e8 = crp::count_panel_entries(nrow, rowptr, colidx, 8);
+        const double fill4 = (double) nnz / (4.0 * (double) e4);
+        if (fill4 >= 0.45) A->auto_variant = ((double) e8 <= 0.72 * (double) e4) ? 3 : 2;
+    }
+    const char *env = getenv("CRPSPMM_SPMM_VARIANT");
+    if (env != NULL && atoi(env) >= 1 && atoi(env) <= 3) A->auto_variant = atoi(env);
+    if (A->auto_variant >= 2)
+    {
+        int rc = ensure_panel(A, A->auto_variant - 2);
+        if (rc != 0)
+        {
+            crp_csr_dev_p tmp = A;
+            crp_csr_dev_destroy(&tmp);
+            return rc;
+        }
+    }
     *out = A;
     return 0;
 }
@@ -177,6 +250,13 @@ int crp_csr_dev_destroy(crp_csr_dev_p *A_)
 {
     if (A_ == NULL || *A_ == NULL) return 0;
     crp_csr_dev *A = *A_;
+    for (int i = 0; i < 2; i++)
+    {
+        if (A->pan[i].pptr) (void) hipFree(A->pan[i].pptr);
+        if (A->pan[i].pcol) (void) hipFree(A->pan[i].pcol);
+        if (A->pan[i].pmask4) (void) hipFree(A->pan[i].pmask4);
+        if (A->pan[i].pval) (void) hipFree(A->pan[i].pval);
+    }
     if (A->rowptr) (void) hipFree(A->rowptr);
     if (A->colidx) (void) hipFree(A->colidx);
     if (A->val) (void) hipFree(A->val);
@@ -189,7 +269,7 @@ int crp_csr_dev_nrow(crp_csr_dev_p A) { return A ? A->nrow : -1; }
 long long crp_csr_dev_nnz(crp_csr_dev_p A) { return A ? A->nnz : -1; }
 long long crp_csr_dev_bytes(crp_csr_dev_p A) { return A ? 12LL * A->nnz + 4LL * ((long long) A->nrow + 1) : -1; }
 
-static const char *k_variant_names[] = {"auto", "rowgroup"};
+static const char *k_variant_names[] = {"auto", "csr-rowgroup", "rowpanel-R4", "rowpanel-R8"};
 int crp_spmm_variant_count(void) { return (int) (sizeof(k_variant_names) / sizeof(k_variant_names[0])); }
 const char *crp_spmm_variant_name(int variant)
 {
@@ -212,9 +292,41 @@ int crp_spmm_csr_f64(crp_csr_dev_p A, int layout, int n, const double *B0, long 
     a.rowptr = A->rowptr; a.colidx = A->colidx; a.val = A->val;
     a.B0 = B0; a.ldB0 = ldB0; a.B1 = B1; a.ldB1 = ldB1; a.C = C; a.ldC = ldC;
     hipError_t e;
-    if (layout == CRP_LAYOUT_COL_MAJOR) e = crp::spmm_cm_f64(a, (hipStream_t) stream);
+    if (layout == CRP_LAYOUT_COL_MAJOR) return (int) crp::spmm_cm_f64(a, (hipStream_t) stream);
+    int v = (variant == 0) ? A->auto_variant : variant;
+    if (v >= 2 && (!crp::spmm_panel_applicable(a) || A->nnz == 0)) v = 1;   // narrow / unaligned operands
+    if (v >= 2)
+    {
+        const int rc = ensure_panel(A, v - 2);       // no-op unless an explicit variant asks for a new format
+        if (rc != 0) return rc;
+        const PanelDev &d = A->pan[v - 2];
+        crp::PanelArgs p;
+        p.R = d.R; p.npanel = d.npanel; p.pptr = d.pptr; p.pcol = d.pcol; p.pmask4 = d.pmask4; p.pval = d.pval;
+        e = crp::spmm_rm_f64_panel(p, a, (hipStream_t) stream);
+    }
     else e = crp::spmm_rm_f64_rowgroup(a, (hipStream_t) stream);
     return (int) e;
+}
+
+int crp_csr_dev_auto_variant(crp_csr_dev_p A) { return A ? A->auto_variant : -1; }
+
+int crp_panel_format_host(int nrow, const int *rowptr, const int *colidx, const double *val, int R, int *npanel,
+                          int **pptr, int **pcol, unsigned **pmask4, double **pval, long long *real_entries)
+{
+    if (nrow < 0 || rowptr == NULL || (R != 4 && R != 8) || !npanel || !pptr || !pcol || !pmask4 || !pval) return -1;
+    crp::PanelHost h;
+    crp::build_panels(nrow, rowptr, colidx, val, R, &h);
+    *npanel = h.npanel;
+    *pptr = (int *) malloc(sizeof(int) * h.pptr.size());
+    *pcol = (int *) malloc(sizeof(int) * (h.pcol.size() + 1));
+    *pmask4 = (unsigned *) malloc(sizeof(unsigned) * h.pmask4.size());
+    *pval = (double *) malloc(sizeof(double) * (h.pval.size() + 1));
+    memcpy(*pptr, h.pptr.data(), sizeof(int) * h.pptr.size());
+    if (!h.pcol.empty()) memcpy(*pcol, h.pcol.data(), sizeof(int) * h.pcol.size());
+    memcpy(*pmask4, h.pmask4.data(), sizeof(unsigned) * h.pmask4.size());
+    if (!h.pval.empty()) memcpy(*pval, h.pval.data(), sizeof(double) * h.pval.size());
+    if (real_entries) *real_entries = h.real_entries;
+    return 0;
 }
 
 int crp_gather_rows_f64(int layout, int nidx, int n, const int *ridx, const double *src, long long lds,

@@ -21,9 +21,21 @@ struct SpmmArgs
     int64_t       ldC;
 };
 
+struct PanelArgs
+{
+    int R;
+    int npanel;
+    const int      *pptr;
+    const int      *pcol;
+    const uint32_t *pmask4;
+    const double   *pval;
+};
+
 // spmm_kernels.hip
 hipError_t spmm_rm_f64_rowgroup(const SpmmArgs &a, hipStream_t s);
 hipError_t spmm_cm_f64(const SpmmArgs &a, hipStream_t s);
+bool spmm_panel_applicable(const SpmmArgs &a);
+hipError_t spmm_rm_f64_panel(const PanelArgs &p, const SpmmArgs &a, hipStream_t s);
 
 // row_kernels.hip
 hipError_t gather_rows_f64(int layout, int nidx, int n, const int *ridx, const double *src, int64_t lds,

@@ -1,0 +1,41 @@
+// panel_format.h -- row-panel storage of A used by the register-blocked SpMM
+// kernels (internal; built once at crp_csr_dev_create time, the inspector step
+// the reference leaves to MKL inside mkl_sparse_d_mm,
+// /root/reference/src/rowpara_spmm.c:398-408).
+//
+// Rows are grouped into panels of R consecutive rows.  A panel stores the
+// union of its rows' column indices once ("entries"); every entry carries R
+// values and an R-bit presence mask, so one load of a B row slice feeds up to
+// R rows of C.  Absent (row, column) pairs are skipped through the mask -- they
+// are never multiplied by zero, which keeps 0 * Inf out of the result -- and an
+// entry is split when a row holds the same column twice.  Entry counts are
+// padded to a multiple of PANEL_PAD with mask-0 entries so that the kernels
+// can fetch index / mask groups with aligned scalar loads.
+#pragma once
+#include <stdint.h>
+#include <vector>
+
+namespace crp {
+
+constexpr int PANEL_PAD = 4;
+
+struct PanelHost
+{
+    int R = 0;
+    int npanel = 0;
+    std::vector<int>      pptr;    // npanel + 1, entry offsets (multiples of PANEL_PAD)
+    std::vector<int>      pcol;    // entries: two-source column index
+    std::vector<uint32_t> pmask4;  // entries / 4 words: byte u of word g = mask of entry 4g + u
+    std::vector<double>   pval;    // entries * R, value of row r of entry q at q*R + r
+    long long real_entries = 0;    // entries before padding
+    double fill() const;           // nnz / (real_entries * R)
+    long long nnz = 0;
+};
+
+// Number of panel entries (before padding) a given R would need: cheap pass used
+// to pick R.  colidx may carry the two-source encoding.
+long long count_panel_entries(int nrow, const int *rowptr, const int *colidx, int R);
+
+void build_panels(int nrow, const int *rowptr, const int *colidx, const double *val, int R, PanelHost *out);
+
+}  // namespace crp

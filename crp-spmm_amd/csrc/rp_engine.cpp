@@ -47,6 +47,9 @@ struct crp_rp_spmm
     // staging (host-pointer API) and column-major temporaries, grown on demand
     double *B_stage = nullptr, *C_stage = nullptr, *B_rm = nullptr, *C_rm = nullptr;
     size_t  B_stage_sz = 0, C_stage_sz = 0, B_rm_sz = 0, C_rm_sz = 0;
+    // last operands seen and where they live (the pointer-attribute query is not free)
+    const void *last_B = nullptr, *last_C = nullptr;
+    int last_B_dev = 0, last_C_dev = 0;
 };
 
 #define HIP_OK(call)                                                              \
@@ -272,14 +275,26 @@ void crp_rp_spmm_exec_ex(crp_rp_spmm_p e, int BC_layout, const double *B, long l
     ASSERT_PRINTF(!e->plan_only, "rp_spmm_exec on a plan-only engine (no device state)\n");
     ASSERT_PRINTF(BC_layout == 0 || BC_layout == 1, "BC_layout must be 0 or 1\n");
     const double t_begin = get_wtime_sec();
-    void *s = stream_ ? stream_ : e->stream;
+    void *s = stream_;   // taken literally: NULL is the HIP null stream (torch's default stream)
     const int n = e->glb_n, kb = e->loc_B_nrow, m = e->A_nrow;
     const bool timing = e->timing != 0;
     double t0, t1;
 
     int B_on_dev = 0, C_on_dev = 0;
-    HIP_OK(crp_dev_ptr_is_device(B, &B_on_dev));
-    HIP_OK(crp_dev_ptr_is_device(C, &C_on_dev));
+    if (B == e->last_B && B != NULL) B_on_dev = e->last_B_dev;
+    else
+    {
+        HIP_OK(crp_dev_ptr_is_device(B, &B_on_dev));
+        e->last_B = B;
+        e->last_B_dev = B_on_dev;
+    }
+    if (C == e->last_C && C != NULL) C_on_dev = e->last_C_dev;
+    else
+    {
+        HIP_OK(crp_dev_ptr_is_device(C, &C_on_dev));
+        e->last_C = C;
+        e->last_C_dev = C_on_dev;
+    }
 
     // ---- bring B to a device-resident row-major view (Bd, ldBd)
     const double *Bd = B;
@@ -389,7 +404,7 @@ void crp_rp_spmm_exec_ex(crp_rp_spmm_p e, int BC_layout, const double *B, long l
 
 void crp_rp_spmm_exec(crp_rp_spmm_p e, int BC_layout, const double *B, int ldB, double *C, int ldC)
 {
-    crp_rp_spmm_exec_ex(e, BC_layout, B, (long long) ldB, C, (long long) ldC, NULL);
+    crp_rp_spmm_exec_ex(e, BC_layout, B, (long long) ldB, C, (long long) ldC, e ? e->stream : NULL);
 }
 
 void crp_rp_spmm_print_stat(crp_rp_spmm_p e)

@@ -82,3 +82,28 @@ def device_info(dev=0):
     cu, mem = C.c_int(), C.c_size_t()
     L.check(lib.crp_hip_device_info(dev, name, C.byref(cu), C.byref(mem)), "crp_hip_device_info")
     return name.value.decode(), cu.value, mem.value
+
+
+def panel_format_host(rowptr, colidx, val, R):
+    """Host-only view of the row-panel format (crp_panel_format_host) as numpy arrays."""
+    lib = L.load()
+    rp = np.ascontiguousarray(rowptr, dtype=np.int32)
+    ci = np.ascontiguousarray(colidx, dtype=np.int32)
+    va = np.ascontiguousarray(val, dtype=np.float64)
+    if ci.size == 0:
+        ci, va = np.zeros(1, np.int32), np.zeros(1, np.float64)
+    npanel, ent = C.c_int(), C.c_longlong()
+    pptr, pcol, pmask, pval = L.c_int_p(), L.c_int_p(), C.POINTER(C.c_uint)(), L.c_dbl_p()
+    L.check(lib.crp_panel_format_host(rp.size - 1, rp.ctypes.data_as(L.c_int_p), ci.ctypes.data_as(L.c_int_p),
+                                      va.ctypes.data_as(L.c_dbl_p), R, C.byref(npanel), C.byref(pptr), C.byref(pcol),
+                                      C.byref(pmask), C.byref(pval), C.byref(ent)), "crp_panel_format_host")
+    P = npanel.value
+    pp = np.ctypeslib.as_array(pptr, (P + 1,)).copy()
+    tot = int(pp[P])
+    out = dict(R=R, npanel=P, pptr=pp, real_entries=ent.value,
+               pcol=np.ctypeslib.as_array(pcol, (max(tot, 1),))[:tot].copy(),
+               pmask4=np.ctypeslib.as_array(pmask, (tot // 4 + 1,)).copy(),
+               pval=np.ctypeslib.as_array(pval, (max(tot * R, 1),))[:tot * R].copy().reshape(tot, R))
+    for p in (pptr, pcol, pmask, pval):
+        L.c_free(C.cast(p, C.c_void_p))
+    return out

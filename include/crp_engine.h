@@ -76,8 +76,9 @@ void crp_rp_spmm_free(crp_rp_spmm_p *rp_spmm);
  * (src/rowpara_spmm.c:217). */
 void crp_rp_spmm_exec(crp_rp_spmm_p rp_spmm, int BC_layout, const double *B, int ldB,
                       double *C, int ldC);
-/* Same, 64-bit leading dimensions and an explicit stream (NULL = the engine's
- * own stream).  With device pointers and timing off nothing synchronises. */
+/* Same, 64-bit leading dimensions and an explicit HIP stream, taken literally
+ * (NULL = the null stream; crp_rp_spmm_exec uses a stream the engine owns).
+ * With device pointers and timing off nothing synchronises. */
 void crp_rp_spmm_exec_ex(crp_rp_spmm_p rp_spmm, int BC_layout, const double *B, long long ldB,
                          double *C, long long ldC, void *stream);
 void crp_rp_spmm_print_stat(crp_rp_spmm_p rp_spmm);

@@ -79,6 +79,19 @@ long long crp_csr_dev_nnz(crp_csr_dev_p A);
 /* bytes of HBM the kernel must touch for A itself: 12*nnz + 4*(nrow+1). */
 long long crp_csr_dev_bytes(crp_csr_dev_p A);
 
+/* what variant 0 resolves to for this matrix: 1 csr-rowgroup, 2 rowpanel-R4, 3 rowpanel-R8
+ * (chosen at create time from how many columns the rows of a panel share;
+ * CRPSPMM_SPMM_VARIANT=1|2|3 overrides). */
+int crp_csr_dev_auto_variant(crp_csr_dev_p A);
+/* Host-only: build the row-panel format the rowpanel kernels consume (R = 4 or 8)
+ * and return malloc'd copies (caller frees).  Panel p owns entries pptr[p] .. pptr[p+1]
+ * (padded to multiples of 4 with mask-0 entries); entry q has column pcol[q] (two-source
+ * encoding), row-presence mask byte (pmask4[q/4] >> 8*(q%4)) & 0xFF and values
+ * pval[q*R .. q*R+R-1].  Used by the CPU tests of the format. */
+int crp_panel_format_host(int nrow, const int *rowptr, const int *colidx, const double *val, int R,
+                          int *npanel, int **pptr, int **pcol, unsigned **pmask4, double **pval,
+                          long long *real_entries);
+
 /* ---- the hot kernel --------------------------------------------------------
  * C[nrow x n] := A * B (alpha = 1, beta = 0; C is overwritten, never read),
  * the arithmetic of mkl_sparse_d_mm as called at src/rowpara_spmm.c:403-406:

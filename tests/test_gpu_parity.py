@@ -17,7 +17,7 @@ def _t(x, dev):
     return torch.from_numpy(np.ascontiguousarray(x)).to(dev)
 
 
-def _spmm(crp, dev, rp, ci, va, k, B, n, layout=0, B1=None, ldpad=0):
+def _spmm(crp, dev, rp, ci, va, k, B, n, layout=0, B1=None, ldpad=0, variant=0):
     import torch
     from crp_spmm_amd import hip
     A = hip.CsrDev(len(rp) - 1, k, rp, ci, va)
@@ -29,7 +29,7 @@ def _spmm(crp, dev, rp, ci, va, k, B, n, layout=0, B1=None, ldpad=0):
         B1d = None
         if B1 is not None:
             B1d = _t(B1[:, :n], dev)
-        hip.spmm_csr(A, Bd[:, :n] if ldpad else Bd, Cd[:, :n] if ldpad else Cd, n=n, B1=B1d)
+        hip.spmm_csr(A, Bd[:, :n] if ldpad else Bd, Cd[:, :n] if ldpad else Cd, n=n, B1=B1d, variant=variant)
         torch.cuda.synchronize()
         out = Cd.cpu().numpy()
         if ldpad:
@@ -56,10 +56,35 @@ def test_kernel_vs_oracle_all_widths(crp, orc, gpu, n):
     rp, ci, va = gen.random_csr(m, k, 70, seed=n, empty_every=13)
     B = np.random.default_rng(n).uniform(-2, 2, size=(k, n))
     ref = orc.spmm_csr(rp, ci, va, B)
-    for ldpad in (0, 1, 2):
-        got = _spmm(crp, gpu, rp, ci, va, k, B, n, ldpad=ldpad)
-        assert orc.rel_fro_err(ref, got) <= FP64_TOL, (n, ldpad)
-        assert not got[::13].any()                     # empty rows: exact zeros
+    for variant in (0, 1, 2, 3):                       # auto, csr-rowgroup, rowpanel-R4, rowpanel-R8
+        for ldpad in (0, 1, 2):
+            got = _spmm(crp, gpu, rp, ci, va, k, B, n, ldpad=ldpad, variant=variant)
+            assert orc.rel_fro_err(ref, got) <= FP64_TOL, (n, ldpad, variant)
+            assert not got[::13].any()                 # empty rows: exact zeros
+
+
+@pytest.mark.parametrize("variant", [1, 2, 3])
+def test_kernel_variants_banded_and_nonfinite(crp, orc, gpu, variant):
+    """Banded (column-sharing) matrix through every kernel family, duplicates included, and
+    the 0 * Inf corner: an Inf / NaN in a B row must only reach the rows that reference it."""
+    from crp_spmm_amd import gen
+    m = k = 2500
+    rp, ci, va = gen.banded_fem(m, offsets=(1, 2, 3, 4, 60, 61, 900), seed=4)
+    ci = ci.copy()
+    ci[rp[10] + 1] = ci[rp[10]]                        # a duplicated column inside row 10
+    n = 256
+    B = np.random.default_rng(3).uniform(-1, 1, size=(k, n))
+    ref = orc.spmm_csr(rp, ci, va, B)
+    got = _spmm(crp, gpu, rp, ci, va, k, B, n, variant=variant)
+    assert orc.rel_fro_err(ref, got) <= FP64_TOL
+    B[1234, 7] = np.inf
+    B[1300, 9] = np.nan
+    ref = orc.spmm_csr(rp, ci, va, B)
+    got = _spmm(crp, gpu, rp, ci, va, k, B, n, variant=variant)
+    assert np.array_equal(np.isfinite(ref), np.isfinite(got))
+    assert np.array_equal(np.isnan(ref), np.isnan(got))
+    fin = np.isfinite(ref)
+    assert np.abs(ref[fin] - got[fin]).max() <= 1e-12 * np.abs(ref[fin]).max()
 
 
 @pytest.mark.parametrize("name", GOLDEN_NAMES)
@@ -87,8 +112,10 @@ def test_kernel_two_source_index(crp, orc, gpu):
     pos = np.full(k, -1)
     pos[remote_rows] = np.arange(remote_rows.size)
     c2 = np.where((ci >= lo) & (ci < hi), ci - lo, ~pos[ci]).astype(np.int32)
-    got = _spmm(crp, gpu, rp, c2, va, hi - lo, B[lo:hi], n, B1=B[remote_rows])
-    assert orc.rel_fro_err(orc.spmm_csr(rp, ci, va, B), got) <= FP64_TOL
+    for n_, variant in ((n, 1), (200, 1), (200, 2), (200, 3)):
+        B = np.random.default_rng(n_).normal(size=(k, n_))
+        got = _spmm(crp, gpu, rp, c2, va, hi - lo, B[lo:hi], n_, B1=B[remote_rows], variant=variant)
+        assert orc.rel_fro_err(orc.spmm_csr(rp, ci, va, B), got) <= FP64_TOL, (n_, variant)
 
 
 def test_kernel_edge_shapes(crp, orc, gpu):

@@ -215,3 +215,48 @@ def test_rp_plan_env_knobs(crp, orc, monkeypatch, capfd):
     assert e.plan()["rB_reidx"] == 1
     e.free()
     sc.free()
+
+
+@pytest.mark.parametrize("R", [4, 8])
+def test_panel_format_host(crp, orc, R):
+    """The row-panel format is a lossless regrouping of the CSR: expanding it entry by entry
+    (mask-selected rows only, in entry order) reproduces A * B, including duplicates,
+    explicit zeros, empty rows / panels and the two-source column encoding."""
+    from crp_spmm_amd import gen, hip
+    for seed, (m, k) in enumerate([(103, 90), (800, 800), (37, 500)]):
+        rp, ci, va = gen.random_csr(m, k, 9, seed=seed, empty_every=5 if seed else 0)
+        ci, va = ci.copy(), va.copy()
+        if seed == 1:
+            rp2, ci2, va2 = gen.banded_fem(m, offsets=(1, 2, 3, 10), seed=2)
+            rp, ci, va = rp2, ci2.copy(), va2.copy()
+            va[::7] = 0.0                                     # explicit zeros stay entries
+        if seed == 0:                                          # duplicates: repeat a column inside some rows
+            for r in range(0, m, 3):
+                if rp[r + 1] - rp[r] >= 2:
+                    ci[rp[r] + 1] = ci[rp[r]]
+        if seed == 2:                                          # two-source encoding: columns >= 300 come from B1
+            ci = np.where(ci >= 300, ~(ci - 300), ci).astype(np.int32)
+        f = hip.panel_format_host(rp, ci, va, R)
+        assert f["npanel"] == (m + R - 1) // R and (f["pptr"] % 4 == 0).all()
+        n = 3
+        B0 = np.random.default_rng(seed).normal(size=(k, n))
+        B1 = np.random.default_rng(seed + 9).normal(size=(k, n))
+        stacked = np.vstack([B0, B1])
+        cc = np.where(ci >= 0, ci, k + (~ci))
+        ref = orc.spmm_csr(rp, cc.astype(np.int32), va, stacked)
+        got = np.zeros((f["npanel"] * R, n))
+        nnz_seen = 0
+        for p in range(f["npanel"]):
+            for q in range(f["pptr"][p], f["pptr"][p + 1]):
+                mask = (int(f["pmask4"][q >> 2]) >> (8 * (q & 3))) & 0xFF
+                c = int(f["pcol"][q])
+                brow = B0[c] if c >= 0 else B1[~c]
+                for r in range(R):
+                    if mask >> r & 1:
+                        got[p * R + r] += f["pval"][q, r] * brow
+                        nnz_seen += 1
+                    else:
+                        assert f["pval"][q, r] == 0.0
+        assert nnz_seen == rp[-1]
+        assert not got[m:].any()
+        assert orc.rel_fro_err(ref, got[:m]) <= 1e-14
