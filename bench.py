@@ -34,6 +34,11 @@ def build_matrix(name):
     if name == "pwtk":
         rp, ci, va = gen.banded_fem(217918)
         return "pwtk-standin banded_fem(217918, seed 20261004)", 217918, 217918, rp, ci, va
+    if name == "pwtk_l2":
+        # diagnostic only: same row structure, every column folded into the first 1024 rows of B
+        # (2 MiB at n = 256) so that B is always L2-resident
+        rp, ci, va = gen.banded_fem(217918)
+        return "pwtk-standin with columns mod 1024 (L2-resident B; diagnostic)", 217918, 217918, rp, (ci % 1024).astype(np.int32), va
     if name == "small":
         rp, ci, va = gen.banded_fem(20000, offsets=(1, 2, 3, 4, 5, 6, 100, 101, 3000))
         return "banded_fem(20000) smoke-size", 20000, 20000, rp, ci, va

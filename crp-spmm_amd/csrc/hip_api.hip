@@ -36,6 +36,7 @@ struct crp_csr_dev
     std::vector<double> h_val;
     PanelDev pan[2];          // [0]: R = 4, [1]: R = 8
     int      auto_variant = 1; // what variant 0 resolves to (1 rowgroup, 2 panel R4, 3 panel R8)
+    long long b0_rows = 0, b1_rows = 0;   // 1 + largest local / receive-buffer row a column index addresses
 };
 
 #define CRP_TRY(expr)                                 \
@@ -57,9 +58,9 @@ static int ensure_panel(crp_csr_dev *A, int idx)
     d.fill = h.fill();
     d.entries = (long long) h.pcol.size();
     hipError_t e = hipMalloc((void **) &d.pptr, sizeof(int) * h.pptr.size());
-    if (e == hipSuccess) e = hipMalloc((void **) &d.pcol, sizeof(int) * (h.pcol.size() + 4));
-    if (e == hipSuccess) e = hipMalloc((void **) &d.pmask4, sizeof(uint32_t) * h.pmask4.size());
-    if (e == hipSuccess) e = hipMalloc((void **) &d.pval, sizeof(double) * (h.pval.size() + 8));
+    if (e == hipSuccess) e = hipMalloc((void **) &d.pcol, sizeof(int) * (h.pcol.size() + 64));
+    if (e == hipSuccess) e = hipMalloc((void **) &d.pmask4, sizeof(uint32_t) * (h.pmask4.size() + 16));
+    if (e == hipSuccess) e = hipMalloc((void **) &d.pval, sizeof(double) * (h.pval.size() + 512));
     if (e == hipSuccess) e = hipMemcpy(d.pptr, h.pptr.data(), sizeof(int) * h.pptr.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess && !h.pcol.empty())
         e = hipMemcpy(d.pcol, h.pcol.data(), sizeof(int) * h.pcol.size(), hipMemcpyHostToDevice);
@@ -213,6 +214,18 @@ int crp_csr_dev_create(int nrow, int ncol, const int *rowptr, const int *colidx,
         crp_csr_dev_destroy(&tmp);
         return (int) e;
     }
+    for (long long p = 0; p < nnz; p++)
+    {
+        const int c = colidx[p];
+        if (c >= 0) { if (c + 1LL > A->b0_rows) A->b0_rows = c + 1LL; }
+        else if ((long long) (~c) + 1 > A->b1_rows) A->b1_rows = (long long) (~c) + 1;
+    }
+    if (A->b0_rows > ncol && ncol > 0)
+    {
+        crp_csr_dev_p tmp = A;
+        crp_csr_dev_destroy(&tmp);
+        return -2;                         // a column index addresses a row past B0
+    }
     A->h_rowptr.assign(rowptr, rowptr + nrow + 1);
     if (nnz > 0)
     {
@@ -302,6 +315,7 @@ int crp_spmm_csr_f64(crp_csr_dev_p A, int layout, int n, const double *B0, long 
         const PanelDev &d = A->pan[v - 2];
         crp::PanelArgs p;
         p.R = d.R; p.npanel = d.npanel; p.pptr = d.pptr; p.pcol = d.pcol; p.pmask4 = d.pmask4; p.pval = d.pval;
+        p.b0_rows = A->b0_rows; p.b1_rows = A->b1_rows;
         e = crp::spmm_rm_f64_panel(p, a, (hipStream_t) stream);
     }
     else e = crp::spmm_rm_f64_rowgroup(a, (hipStream_t) stream);

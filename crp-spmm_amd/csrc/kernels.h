@@ -29,6 +29,8 @@ struct PanelArgs
     const int      *pcol;
     const uint32_t *pmask4;
     const double   *pval;
+    long long       b0_rows;   // rows of B0 / B1 the column indices can address (for the 4 GiB check)
+    long long       b1_rows;
 };
 
 // spmm_kernels.hip

@@ -120,7 +120,7 @@ void build_panels(int nrow, const int *rowptr, const int *colidx, const double *
     out->real_entries = real;
     const size_t total = (size_t) out->pptr[npanel];
     out->pcol.assign(total, 0);
-    out->pmask4.assign(total / 4 + 1, 0u);
+    out->pmask4.assign(total / 4 + 2, 0u);
     out->pval.assign(total * (size_t) R, 0.0);
     // pass 2: fill
     parallel_chunks(npanel, 512, [&](long long b, long long e, int) {

@@ -9,15 +9,16 @@
 // R rows of C.  Absent (row, column) pairs are skipped through the mask -- they
 // are never multiplied by zero, which keeps 0 * Inf out of the result -- and an
 // entry is split when a row holds the same column twice.  Entry counts are
-// padded to a multiple of PANEL_PAD with mask-0 entries so that the kernels
-// can fetch index / mask groups with aligned scalar loads.
+// padded to a multiple of PANEL_PAD with mask-0 entries (column = the panel's last
+// real column, a valid address) so that the kernels' register ring needs no guards
+// and fetches index / mask groups with aligned scalar loads.
 #pragma once
 #include <stdint.h>
 #include <vector>
 
 namespace crp {
 
-constexpr int PANEL_PAD = 4;
+constexpr int PANEL_PAD = 8;   // = PANEL_RING of the kernels (spmm_kernels.hip)
 
 struct PanelHost
 {

@@ -195,63 +195,105 @@ hipError_t spmm_rm_f64_rowgroup(const SpmmArgs &a, hipStream_t s)
 // Row-panel kernel (panel_format.h): one wavefront per panel of R rows and a
 // TW = 128*NV wide slice of C.  For every panel entry (one column index shared by
 // up to R rows) the wave loads the B row slice ONCE -- 16 bytes per lane per NV --
-// and feeds it to the accumulators of the rows whose mask bit is set.  Entry
-// indices, masks and values are wave-uniform, so they travel through scalar loads
-// and SGPRs; the vector memory path carries only B and C.  Entries are consumed in
-// groups of four with the next group's B loads issued before the current group's
-// FMAs (two register sets, counted vmcnt), so ~8 KiB per wave stay in flight.
+// and feeds it to the accumulators of the rows whose mask bit is set.
+//
+// Register ring: RING entries' B slices live in VGPRs; slot k is consumed (FMAs) and
+// immediately refilled with the entry RING positions ahead, so RING-1 entries
+// (~2 KiB each at NV = 2) stay in flight per wave behind counted vmcnt waits.  The
+// VGPR file (512 KiB per CU) is the largest buffer on the CU to keep bytes in flight,
+// three times the LDS.  Panel entry counts are padded to a multiple of RING (mask-0
+// entries), and the last round is peeled, so the rounds are straight-line code.
+//
+// Operand delivery per entry:
+//   column index, mask : wave-uniform scalar loads, fetched one round (RING entries) ahead;
+//   R values           : staged per wave through LDS in chunks of PANEL_CHUNK entries
+//                        (coalesced vector loads, one entry per lane), then read back with
+//                        uniform-address ds_read (broadcast).  A scalar load per entry would
+//                        expose its full latency every entry (SMEM completes out of order,
+//                        so every wait is lgkmcnt(0));
+//   B row slice        : buffer_load_dwordx4 with the row offset in the SGPR soffset operand
+//                        (one s_mul per entry, no per-lane address arithmetic); ADDR64 falls
+//                        back to 64-bit global addresses when a B block exceeds 4 GiB.
 // ---------------------------------------------------------------------------
-template <int R, int NV>
-struct PanelGroup
+constexpr int PANEL_RING  = 8;
+constexpr int PANEL_CHUNK = 64;
+
+template <bool ADDR64>
+struct BSource
 {
-    d2 b[4][NV];
+    __amdgpu_buffer_rsrc_t rsrc;
+    const double *base;
+    uint32_t ldbytes;
+    int64_t  ld;
 };
 
-template <int R, int NV>
-__device__ __forceinline__ void panel_issue(PanelGroup<R, NV> &g, const int q, const int *__restrict__ pcol,
-                                            const double *__restrict__ B0, const int64_t ldB0,
-                                            const double *__restrict__ B1, const int64_t ldB1, const int (&coff)[NV])
+template <bool ADDR64, bool HAS_B1, int NV>
+__device__ __forceinline__ void panel_issue1(d2 (&slot)[NV], const int cj, const BSource<ADDR64> &s0,
+                                             const BSource<ADDR64> &s1, const int (&voff)[NV])
 {
-#pragma unroll
-    for (int u = 0; u < 4; u++)
+    const bool remote = HAS_B1 && (cj < 0);
+    const uint32_t row = remote ? (uint32_t) (~cj) : (uint32_t) cj;
+    if constexpr (ADDR64)
     {
-        const int cj = pcol[q + u];     // uniform address -> scalar load
-        const double *brow = (cj >= 0) ? (B0 + (int64_t) cj * ldB0) : (B1 + (int64_t) (~cj) * ldB1);
+        const double *brow = remote ? (s1.base + (int64_t) row * s1.ld) : (s0.base + (int64_t) row * s0.ld);
 #pragma unroll
-        for (int v = 0; v < NV; v++) g.b[u][v] = *reinterpret_cast<const d2 *>(brow + coff[v]);
+        for (int v = 0; v < NV; v++)
+            slot[v] = *reinterpret_cast<const d2 *>(reinterpret_cast<const char *>(brow) + voff[v]);
+    }
+    else
+    {
+        if (remote)
+        {
+            const uint32_t soff = row * s1.ldbytes;
+#pragma unroll
+            for (int v = 0; v < NV; v++)
+                slot[v] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(s1.rsrc, voff[v], soff, 0));
+        }
+        else
+        {
+            const uint32_t soff = row * s0.ldbytes;
+#pragma unroll
+            for (int v = 0; v < NV; v++)
+                slot[v] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(s0.rsrc, voff[v], soff, 0));
+        }
     }
 }
 
 template <int R, int NV>
-__device__ __forceinline__ void panel_consume(const PanelGroup<R, NV> &g, const int q,
-                                              const uint32_t *__restrict__ pmask4, const double *__restrict__ pval,
-                                              double (&acc)[R][NV][2])
+__device__ __forceinline__ void panel_consume1(const d2 (&slot)[NV], const uint32_t mask, const double (&a)[R],
+                                               double (&acc)[R][NV][2])
 {
-    const uint32_t m4 = pmask4[q >> 2];
-#pragma unroll
-    for (int u = 0; u < 4; u++)
+    if (mask == ((1u << R) - 1u))
     {
-        const double *pv = pval + (int64_t) (q + u) * R;
-        double a[R];
+        // every row of the panel holds this column: straight-line FMAs
 #pragma unroll
-        for (int r = 0; r < R; r++) a[r] = pv[r];      // uniform -> SGPRs
+        for (int r = 0; r < R; r++)
+#pragma unroll
+            for (int v = 0; v < NV; v++)
+            {
+                acc[r][v][0] = fma(a[r], slot[v].x, acc[r][v][0]);
+                acc[r][v][1] = fma(a[r], slot[v].y, acc[r][v][1]);
+            }
+    }
+    else
+    {
 #pragma unroll
         for (int r = 0; r < R; r++)
         {
-            if (m4 & (1u << (8 * u + r)))              // wave-uniform branch: absent pairs cost no FMA
+            if (mask & (1u << r))          // wave-uniform branch: absent (row, column) pairs cost no FMA
             {
 #pragma unroll
                 for (int v = 0; v < NV; v++)
                 {
-                    acc[r][v][0] = fma(a[r], g.b[u][v].x, acc[r][v][0]);
-                    acc[r][v][1] = fma(a[r], g.b[u][v].y, acc[r][v][1]);
+                    acc[r][v][0] = fma(a[r], slot[v].x, acc[r][v][0]);
+                    acc[r][v][1] = fma(a[r], slot[v].y, acc[r][v][1]);
                 }
             }
         }
     }
 }
 
-template <int R, int NV>
+template <int R, int NV, bool ADDR64, bool HAS_B1>
 __global__ __launch_bounds__(256) void spmm_panel_f64_kernel(
     const int npanel, const int nrow, const int n,
     const int *__restrict__ pptr, const int *__restrict__ pcol, const uint32_t *__restrict__ pmask4,
@@ -260,41 +302,96 @@ __global__ __launch_bounds__(256) void spmm_panel_f64_kernel(
     double *__restrict__ C, const int64_t ldC)
 {
     constexpr int TW = 128 * NV;
-    const int lane  = threadIdx.x & 63;
-    const int panel = __builtin_amdgcn_readfirstlane((int) (blockIdx.x * 4 + (threadIdx.x >> 6)));
+    constexpr int RING = PANEL_RING;
+    constexpr int CHUNK = PANEL_CHUNK;
+    __shared__ __attribute__((aligned(16))) double lds_vals[4][CHUNK * R];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    // XCD-aware placement: workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share
+    // one), so give XCD x the contiguous block range [x*cpx, (x+1)*cpx): neighbouring panels
+    // read neighbouring B rows and then meet in the same 4 MiB L2 instead of pulling every B
+    // row into all eight.  Placement only affects speed, never the result.
+    const int cpx   = (gridDim.x + 7) >> 3;
+    const int wg    = (blockIdx.x & 7) * cpx + (blockIdx.x >> 3);
+    const int panel = __builtin_amdgcn_readfirstlane((int) (wg * 4 + wave));
     if (panel >= npanel) return;
+    double *myvals = lds_vals[__builtin_amdgcn_readfirstlane(wave)];
+
     const int col0 = blockIdx.y * TW + lane * 2;
     bool ok[NV];
-    int  coff[NV];
+    int  coff[NV], voff[NV];
 #pragma unroll
     for (int v = 0; v < NV; v++)
     {
         const int c = col0 + v * 128;
         ok[v]   = (c + 1) < n;
         coff[v] = ok[v] ? c : 0;
+        voff[v] = coff[v] * 8;
     }
+    BSource<ADDR64> s0, s1;
+    s0.base = B0; s0.ld = ldB0; s0.ldbytes = (uint32_t) (ldB0 * 8);
+    s1.base = B1; s1.ld = ldB1; s1.ldbytes = (uint32_t) (ldB1 * 8);
+    if constexpr (!ADDR64)
+    {
+        s0.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(B0), 0, 0xFFFFFFFFu, 0x00020000);
+        s1.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(HAS_B1 ? B1 : B0), 0, 0xFFFFFFFFu, 0x00020000);
+    }
+
     double acc[R][NV][2];
 #pragma unroll
     for (int r = 0; r < R; r++)
 #pragma unroll
         for (int v = 0; v < NV; v++) acc[r][v][0] = acc[r][v][1] = 0.0;
 
-    int q = pptr[panel];
-    const int qe = pptr[panel + 1];
-    PanelGroup<R, NV> ga, gb;
-    if (q < qe)
+    const int q0 = pptr[panel];
+    const int qe = pptr[panel + 1];          // (qe - q0) is a multiple of RING
+    if (q0 < qe)
     {
-        panel_issue<R, NV>(ga, q, pcol, B0, ldB0, B1, ldB1, coff);
-        for (;;)
+        d2 ring[RING][NV];
+        int cnext[RING];
+#pragma unroll
+        for (int k = 0; k < RING; k++) cnext[k] = pcol[q0 + k];
+#pragma unroll
+        for (int k = 0; k < RING; k++) panel_issue1<ADDR64, HAS_B1, NV>(ring[k], cnext[k], s0, s1, voff);
+
+        // one round = RING consecutive entries starting at q (inside the staged chunk at qc)
+        auto round = [&](const int q, const int qc, const bool refill) {
+            if (refill)
+            {
+#pragma unroll
+                for (int k = 0; k < RING; k++) cnext[k] = pcol[q + RING + k];   // scalar loads, a round ahead
+            }
+            const uint32_t m_lo = pmask4[(q >> 2)], m_hi = pmask4[(q >> 2) + 1];
+            const double *lv = myvals + (q - qc) * R;
+#pragma unroll
+            for (int k = 0; k < RING; k++)
+            {
+                double a[R];
+#pragma unroll
+                for (int r = 0; r < R; r++) a[r] = lv[k * R + r];            // uniform-address LDS broadcast
+                const uint32_t mask = ((k < 4 ? m_lo : m_hi) >> (8 * (k & 3))) & 0xFFu;
+                panel_consume1<R, NV>(ring[k], mask, a, acc);
+                if (refill) panel_issue1<ADDR64, HAS_B1, NV>(ring[k], cnext[k], s0, s1, voff);
+            }
+        };
+
+        for (int qc = q0; qc < qe; qc += CHUNK)
         {
-            if (q + 4 < qe) panel_issue<R, NV>(gb, q + 4, pcol, B0, ldB0, B1, ldB1, coff);
-            panel_consume<R, NV>(ga, q, pmask4, pval, acc);
-            q += 4;
-            if (q >= qe) break;
-            if (q + 4 < qe) panel_issue<R, NV>(ga, q + 4, pcol, B0, ldB0, B1, ldB1, coff);
-            panel_consume<R, NV>(gb, q, pmask4, pval, acc);
-            q += 4;
-            if (q >= qe) break;
+            const int nent = min(CHUNK, qe - qc);
+            // stage this chunk's values: lane t owns entry qc + t (R contiguous doubles)
+            if (lane < nent)
+            {
+                const double *src = pval + (int64_t) (qc + lane) * R;
+                double *dst = myvals + lane * R;
+#pragma unroll
+                for (int r = 0; r < R; r += 2)
+                    *reinterpret_cast<d2 *>(dst + r) = *reinterpret_cast<const d2 *>(src + r);
+            }
+            const int qend = qc + nent;
+            int q = qc;
+            for (; q + RING < qe && q < qend; q += RING) round(q, qc, true);
+            if (q < qend) round(q, qc, false);       // the panel's last round: nothing left to prefetch
         }
     }
 #pragma unroll
@@ -317,14 +414,26 @@ __global__ __launch_bounds__(256) void spmm_panel_f64_kernel(
     }
 }
 
-template <int R, int NV>
+template <int R, int NV, bool ADDR64, bool HAS_B1>
 static hipError_t launch_panel(const PanelArgs &p, const SpmmArgs &a, hipStream_t s)
 {
     constexpr int TW = 128 * NV;
-    dim3 grid((p.npanel + 3) / 4, (a.n + TW - 1) / TW);
-    hipLaunchKernelGGL((spmm_panel_f64_kernel<R, NV>), grid, dim3(256), 0, s, p.npanel, a.nrow, a.n, p.pptr, p.pcol,
-                       p.pmask4, p.pval, a.B0, a.ldB0, a.B1, a.ldB1, a.C, a.ldC);
+    const int nwg = (p.npanel + 3) / 4;
+    dim3 grid((nwg + 7) / 8 * 8, (a.n + TW - 1) / TW);      // multiple of 8 for the XCD remap
+    hipLaunchKernelGGL((spmm_panel_f64_kernel<R, NV, ADDR64, HAS_B1>), grid, dim3(256), 0, s, p.npanel, a.nrow, a.n,
+                       p.pptr, p.pcol, p.pmask4, p.pval, a.B0, a.ldB0, a.B1, a.ldB1, a.C, a.ldC);
     return hipGetLastError();
+}
+
+template <int R, int NV>
+static hipError_t launch_panel_addr(const PanelArgs &p, const SpmmArgs &a, hipStream_t s)
+{
+    // 32-bit buffer offsets need every addressed byte of B0 / B1 below 4 GiB
+    const bool has_b1 = (a.B1 != nullptr) && (p.b1_rows > 0);
+    const bool small = ((uint64_t) p.b0_rows * (uint64_t) a.ldB0 * 8ull < (1ull << 32)) &&
+                       (!has_b1 || (uint64_t) p.b1_rows * (uint64_t) a.ldB1 * 8ull < (1ull << 32));
+    if (small) return has_b1 ? launch_panel<R, NV, false, true>(p, a, s) : launch_panel<R, NV, false, false>(p, a, s);
+    return has_b1 ? launch_panel<R, NV, true, true>(p, a, s) : launch_panel<R, NV, true, false>(p, a, s);
 }
 
 bool spmm_panel_applicable(const SpmmArgs &a)
@@ -337,8 +446,8 @@ bool spmm_panel_applicable(const SpmmArgs &a)
 hipError_t spmm_rm_f64_panel(const PanelArgs &p, const SpmmArgs &a, hipStream_t s)
 {
     const bool wide = a.n > 128;
-    if (p.R == 4) return wide ? launch_panel<4, 2>(p, a, s) : launch_panel<4, 1>(p, a, s);
-    if (p.R == 8) return wide ? launch_panel<8, 2>(p, a, s) : launch_panel<8, 1>(p, a, s);
+    if (p.R == 4) return wide ? launch_panel_addr<4, 2>(p, a, s) : launch_panel_addr<4, 1>(p, a, s);
+    if (p.R == 8) return wide ? launch_panel_addr<8, 2>(p, a, s) : launch_panel_addr<8, 1>(p, a, s);
     return hipErrorInvalidValue;
 }
 

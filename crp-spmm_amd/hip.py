@@ -102,7 +102,7 @@ def panel_format_host(rowptr, colidx, val, R):
     tot = int(pp[P])
     out = dict(R=R, npanel=P, pptr=pp, real_entries=ent.value,
                pcol=np.ctypeslib.as_array(pcol, (max(tot, 1),))[:tot].copy(),
-               pmask4=np.ctypeslib.as_array(pmask, (tot // 4 + 1,)).copy(),
+               pmask4=np.ctypeslib.as_array(pmask, (tot // 4 + 2,)).copy(),
                pval=np.ctypeslib.as_array(pval, (max(tot * R, 1),))[:tot * R].copy().reshape(tot, R))
     for p in (pptr, pcol, pmask, pval):
         L.c_free(C.cast(p, C.c_void_p))

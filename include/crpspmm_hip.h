@@ -85,7 +85,7 @@ long long crp_csr_dev_bytes(crp_csr_dev_p A);
 int crp_csr_dev_auto_variant(crp_csr_dev_p A);
 /* Host-only: build the row-panel format the rowpanel kernels consume (R = 4 or 8)
  * and return malloc'd copies (caller frees).  Panel p owns entries pptr[p] .. pptr[p+1]
- * (padded to multiples of 4 with mask-0 entries); entry q has column pcol[q] (two-source
+ * (padded to multiples of 8 with mask-0 entries); entry q has column pcol[q] (two-source
  * encoding), row-presence mask byte (pmask4[q/4] >> 8*(q%4)) & 0xFF and values
  * pval[q*R .. q*R+R-1].  Used by the CPU tests of the format. */
 int crp_panel_format_host(int nrow, const int *rowptr, const int *colidx, const double *val, int R,

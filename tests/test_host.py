@@ -237,7 +237,7 @@ def test_panel_format_host(crp, orc, R):
         if seed == 2:                                          # two-source encoding: columns >= 300 come from B1
             ci = np.where(ci >= 300, ~(ci - 300), ci).astype(np.int32)
         f = hip.panel_format_host(rp, ci, va, R)
-        assert f["npanel"] == (m + R - 1) // R and (f["pptr"] % 4 == 0).all()
+        assert f["npanel"] == (m + R - 1) // R and (f["pptr"] % 8 == 0).all()
         n = 3
         B0 = np.random.default_rng(seed).normal(size=(k, n))
         B1 = np.random.default_rng(seed + 9).normal(size=(k, n))
