@@ -22,6 +22,20 @@ _live = {}        # address of CrpComm struct -> TorchComm (keeps callbacks aliv
 _retired = []     # freed communicators: a callback object must not be destroyed while it runs
 
 
+def exchange_mode():
+    """How device payloads travel: "nccl" (RCCL over xGMI, one GPU per rank) or "host"
+    (device -> pinned host -> gloo -> device).  "host" is chosen automatically when the ranks of
+    this node outnumber its GPUs (RCCL refuses two ranks on one device) -- the rehearsal mode used
+    to test the N > 1 GPU path on a single-GPU box -- or with CRPSPMM_EXCHANGE=host."""
+    env = os.environ.get("CRPSPMM_EXCHANGE", "").lower()
+    if env in ("host", "nccl"):
+        return env
+    if not torch.cuda.is_available():
+        return "host"
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+    return "host" if local_world > torch.cuda.device_count() else "nccl"
+
+
 def init_process_group(device=None):
     """One process per GPU; reads RANK / WORLD_SIZE / MASTER_* from the env."""
     if dist.is_initialized():
@@ -29,12 +43,13 @@ def init_process_group(device=None):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    use_cuda = torch.cuda.is_available()
-    backend = "cpu:gloo,cuda:nccl" if use_cuda else "gloo"
-    kw = {}
-    if use_cuda and device is not None:
-        kw["device_id"] = torch.device("cuda", device)
-    dist.init_process_group(backend=backend, **kw)
+    if exchange_mode() == "nccl":
+        kw = {}
+        if device is not None:
+            kw["device_id"] = torch.device("cuda", device)
+        dist.init_process_group(backend="cpu:gloo,cuda:nccl", **kw)
+    else:
+        dist.init_process_group(backend="gloo")
 
 
 def _np_from_ptr(ptr, count, dtype):
@@ -140,7 +155,18 @@ class TorchComm:
         if ns == 0 and nr == 0:
             # nothing to move for this rank, but the collective must still be entered
             pass
-        if torch.cuda.is_available():
+        if torch.cuda.is_available() and exchange_mode() == "host":
+            # staged exchange: the same collective on host copies (gloo), ordered on `stream`
+            dev = torch.device("cuda", torch.cuda.current_device())
+            ext = torch.cuda.ExternalStream(int(stream)) if stream else torch.cuda.current_stream()
+            with torch.cuda.stream(ext):
+                src_d = torch.as_tensor(_CudaView(send, ns), device=dev) if ns else torch.empty(0, dtype=torch.float64, device=dev)
+                src = src_d.cpu()                      # synchronises with `stream`
+                dst = torch.empty(nr, dtype=torch.float64)
+                dist.all_to_all_single(dst, src, output_split_sizes=rc, input_split_sizes=sc, group=self.group)
+                if nr:
+                    torch.as_tensor(_CudaView(recv, nr), device=dev).copy_(dst)
+        elif torch.cuda.is_available():
             dev = torch.device("cuda", torch.cuda.current_device())
             src = torch.as_tensor(_CudaView(send, ns), device=dev) if ns else torch.empty(0, dtype=torch.float64, device=dev)
             dst = torch.as_tensor(_CudaView(recv, nr), device=dev) if nr else torch.empty(0, dtype=torch.float64, device=dev)

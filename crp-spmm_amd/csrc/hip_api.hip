@@ -307,6 +307,9 @@ int crp_spmm_csr_f64(crp_csr_dev_p A, int layout, int n, const double *B0, long 
     hipError_t e;
     if (layout == CRP_LAYOUT_COL_MAJOR) return (int) crp::spmm_cm_f64(a, (hipStream_t) stream);
     int v = (variant == 0) ? A->auto_variant : variant;
+    // measured on MI355X (pwtk stand-in): R = 8 wins from 256 columns up, R = 4 below (the wider
+    // accumulator tile of R = 8 costs occupancy that narrow tiles cannot pay back)
+    if (variant == 0 && v == 3 && n <= 128 && getenv("CRPSPMM_SPMM_VARIANT") == NULL) v = 2;
     if (v >= 2 && (!crp::spmm_panel_applicable(a) || A->nnz == 0)) v = 1;   // narrow / unaligned operands
     if (v >= 2)
     {

@@ -227,10 +227,25 @@ struct BSource
     int64_t  ld;
 };
 
-template <bool ADDR64, bool HAS_B1, int NV>
-__device__ __forceinline__ void panel_issue1(d2 (&slot)[NV], const int cj, const BSource<ADDR64> &s0,
+typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+
+// one slot element: VW = 2 -> 16-byte load (two columns per lane), VW = 1 -> 8-byte load
+template <int VW> struct SlotT;
+template <> struct SlotT<2> { typedef d2 type; };
+template <> struct SlotT<1> { typedef double type; };
+
+template <int VW>
+__device__ __forceinline__ typename SlotT<VW>::type buf_load(const __amdgpu_buffer_rsrc_t rsrc, const int voff, const uint32_t soff)
+{
+    if constexpr (VW == 2) return __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0));
+    else return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, soff, 0));
+}
+
+template <bool ADDR64, bool HAS_B1, int NV, int VW>
+__device__ __forceinline__ void panel_issue1(typename SlotT<VW>::type (&slot)[NV], const int cj, const BSource<ADDR64> &s0,
                                              const BSource<ADDR64> &s1, const int (&voff)[NV])
 {
+    typedef typename SlotT<VW>::type ST;
     const bool remote = HAS_B1 && (cj < 0);
     const uint32_t row = remote ? (uint32_t) (~cj) : (uint32_t) cj;
     if constexpr (ADDR64)
@@ -238,7 +253,7 @@ __device__ __forceinline__ void panel_issue1(d2 (&slot)[NV], const int cj, const
         const double *brow = remote ? (s1.base + (int64_t) row * s1.ld) : (s0.base + (int64_t) row * s0.ld);
 #pragma unroll
         for (int v = 0; v < NV; v++)
-            slot[v] = *reinterpret_cast<const d2 *>(reinterpret_cast<const char *>(brow) + voff[v]);
+            slot[v] = *reinterpret_cast<const ST *>(reinterpret_cast<const char *>(brow) + voff[v]);
     }
     else
     {
@@ -247,21 +262,28 @@ __device__ __forceinline__ void panel_issue1(d2 (&slot)[NV], const int cj, const
             const uint32_t soff = row * s1.ldbytes;
 #pragma unroll
             for (int v = 0; v < NV; v++)
-                slot[v] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(s1.rsrc, voff[v], soff, 0));
+                slot[v] = buf_load<VW>(s1.rsrc, voff[v], soff);
         }
         else
         {
             const uint32_t soff = row * s0.ldbytes;
 #pragma unroll
             for (int v = 0; v < NV; v++)
-                slot[v] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(s0.rsrc, voff[v], soff, 0));
+                slot[v] = buf_load<VW>(s0.rsrc, voff[v], soff);
         }
     }
 }
 
-template <int R, int NV>
-__device__ __forceinline__ void panel_consume1(const d2 (&slot)[NV], const uint32_t mask, const double (&a)[R],
-                                               double (&acc)[R][NV][2])
+template <int VW>
+__device__ __forceinline__ double slot_elem(const typename SlotT<VW>::type &s, const int w)
+{
+    if constexpr (VW == 2) return w == 0 ? s.x : s.y;
+    else return s;
+}
+
+template <int R, int NV, int VW>
+__device__ __forceinline__ void panel_consume1(const typename SlotT<VW>::type (&slot)[NV], const uint32_t mask,
+                                               const double (&a)[R], double (&acc)[R][NV][VW])
 {
     if (mask == ((1u << R) - 1u))
     {
@@ -270,10 +292,8 @@ __device__ __forceinline__ void panel_consume1(const d2 (&slot)[NV], const uint3
         for (int r = 0; r < R; r++)
 #pragma unroll
             for (int v = 0; v < NV; v++)
-            {
-                acc[r][v][0] = fma(a[r], slot[v].x, acc[r][v][0]);
-                acc[r][v][1] = fma(a[r], slot[v].y, acc[r][v][1]);
-            }
+#pragma unroll
+                for (int w = 0; w < VW; w++) acc[r][v][w] = fma(a[r], slot_elem<VW>(slot[v], w), acc[r][v][w]);
     }
     else
     {
@@ -284,16 +304,14 @@ __device__ __forceinline__ void panel_consume1(const d2 (&slot)[NV], const uint3
             {
 #pragma unroll
                 for (int v = 0; v < NV; v++)
-                {
-                    acc[r][v][0] = fma(a[r], slot[v].x, acc[r][v][0]);
-                    acc[r][v][1] = fma(a[r], slot[v].y, acc[r][v][1]);
-                }
+#pragma unroll
+                    for (int w = 0; w < VW; w++) acc[r][v][w] = fma(a[r], slot_elem<VW>(slot[v], w), acc[r][v][w]);
             }
         }
     }
 }
 
-template <int R, int NV, bool ADDR64, bool HAS_B1>
+template <int R, int NV, int VW, bool ADDR64, bool HAS_B1>
 __global__ __launch_bounds__(256) void spmm_panel_f64_kernel(
     const int npanel, const int nrow, const int n,
     const int *__restrict__ pptr, const int *__restrict__ pcol, const uint32_t *__restrict__ pmask4,
@@ -301,9 +319,10 @@ __global__ __launch_bounds__(256) void spmm_panel_f64_kernel(
     const double *__restrict__ B0, const int64_t ldB0, const double *__restrict__ B1, const int64_t ldB1,
     double *__restrict__ C, const int64_t ldC)
 {
-    constexpr int TW = 128 * NV;
+    constexpr int TW = 64 * VW * NV;
     constexpr int RING = PANEL_RING;
     constexpr int CHUNK = PANEL_CHUNK;
+    typedef typename SlotT<VW>::type ST;
     __shared__ __attribute__((aligned(16))) double lds_vals[4][CHUNK * R];
 
     const int lane = threadIdx.x & 63;
@@ -318,14 +337,14 @@ __global__ __launch_bounds__(256) void spmm_panel_f64_kernel(
     if (panel >= npanel) return;
     double *myvals = lds_vals[__builtin_amdgcn_readfirstlane(wave)];
 
-    const int col0 = blockIdx.y * TW + lane * 2;
+    const int col0 = blockIdx.y * TW + lane * VW;
     bool ok[NV];
     int  coff[NV], voff[NV];
 #pragma unroll
     for (int v = 0; v < NV; v++)
     {
-        const int c = col0 + v * 128;
-        ok[v]   = (c + 1) < n;
+        const int c = col0 + v * 64 * VW;
+        ok[v]   = (c + VW - 1) < n;
         coff[v] = ok[v] ? c : 0;
         voff[v] = coff[v] * 8;
     }
@@ -338,22 +357,24 @@ __global__ __launch_bounds__(256) void spmm_panel_f64_kernel(
         s1.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(HAS_B1 ? B1 : B0), 0, 0xFFFFFFFFu, 0x00020000);
     }
 
-    double acc[R][NV][2];
+    double acc[R][NV][VW];
 #pragma unroll
     for (int r = 0; r < R; r++)
 #pragma unroll
-        for (int v = 0; v < NV; v++) acc[r][v][0] = acc[r][v][1] = 0.0;
+        for (int v = 0; v < NV; v++)
+#pragma unroll
+            for (int w = 0; w < VW; w++) acc[r][v][w] = 0.0;
 
     const int q0 = pptr[panel];
     const int qe = pptr[panel + 1];          // (qe - q0) is a multiple of RING
     if (q0 < qe)
     {
-        d2 ring[RING][NV];
+        ST ring[RING][NV];
         int cnext[RING];
 #pragma unroll
         for (int k = 0; k < RING; k++) cnext[k] = pcol[q0 + k];
 #pragma unroll
-        for (int k = 0; k < RING; k++) panel_issue1<ADDR64, HAS_B1, NV>(ring[k], cnext[k], s0, s1, voff);
+        for (int k = 0; k < RING; k++) panel_issue1<ADDR64, HAS_B1, NV, VW>(ring[k], cnext[k], s0, s1, voff);
 
         // one round = RING consecutive entries starting at q (inside the staged chunk at qc)
         auto round = [&](const int q, const int qc, const bool refill) {
@@ -371,8 +392,8 @@ __global__ __launch_bounds__(256) void spmm_panel_f64_kernel(
 #pragma unroll
                 for (int r = 0; r < R; r++) a[r] = lv[k * R + r];            // uniform-address LDS broadcast
                 const uint32_t mask = ((k < 4 ? m_lo : m_hi) >> (8 * (k & 3))) & 0xFFu;
-                panel_consume1<R, NV>(ring[k], mask, a, acc);
-                if (refill) panel_issue1<ADDR64, HAS_B1, NV>(ring[k], cnext[k], s0, s1, voff);
+                panel_consume1<R, NV, VW>(ring[k], mask, a, acc);
+                if (refill) panel_issue1<ADDR64, HAS_B1, NV, VW>(ring[k], cnext[k], s0, s1, voff);
             }
         };
 
@@ -405,49 +426,61 @@ __global__ __launch_bounds__(256) void spmm_panel_f64_kernel(
             for (int v = 0; v < NV; v++)
                 if (ok[v])
                 {
-                    d2 t;
-                    t.x = acc[r][v][0];
-                    t.y = acc[r][v][1];
-                    __builtin_nontemporal_store(t, reinterpret_cast<d2 *>(crow + coff[v]));
+                    if constexpr (VW == 2)
+                    {
+                        d2 t;
+                        t.x = acc[r][v][0];
+                        t.y = acc[r][v][1];
+                        __builtin_nontemporal_store(t, reinterpret_cast<d2 *>(crow + coff[v]));
+                    }
+                    else __builtin_nontemporal_store(acc[r][v][0], crow + coff[v]);
                 }
         }
     }
 }
 
-template <int R, int NV, bool ADDR64, bool HAS_B1>
+template <int R, int NV, int VW, bool ADDR64, bool HAS_B1>
 static hipError_t launch_panel(const PanelArgs &p, const SpmmArgs &a, hipStream_t s)
 {
-    constexpr int TW = 128 * NV;
+    constexpr int TW = 64 * VW * NV;
     const int nwg = (p.npanel + 3) / 4;
     dim3 grid((nwg + 7) / 8 * 8, (a.n + TW - 1) / TW);      // multiple of 8 for the XCD remap
-    hipLaunchKernelGGL((spmm_panel_f64_kernel<R, NV, ADDR64, HAS_B1>), grid, dim3(256), 0, s, p.npanel, a.nrow, a.n,
+    hipLaunchKernelGGL((spmm_panel_f64_kernel<R, NV, VW, ADDR64, HAS_B1>), grid, dim3(256), 0, s, p.npanel, a.nrow, a.n,
                        p.pptr, p.pcol, p.pmask4, p.pval, a.B0, a.ldB0, a.B1, a.ldB1, a.C, a.ldC);
     return hipGetLastError();
 }
 
-template <int R, int NV>
+template <int R, int NV, int VW>
 static hipError_t launch_panel_addr(const PanelArgs &p, const SpmmArgs &a, hipStream_t s)
 {
     // 32-bit buffer offsets need every addressed byte of B0 / B1 below 4 GiB
     const bool has_b1 = (a.B1 != nullptr) && (p.b1_rows > 0);
     const bool small = ((uint64_t) p.b0_rows * (uint64_t) a.ldB0 * 8ull < (1ull << 32)) &&
                        (!has_b1 || (uint64_t) p.b1_rows * (uint64_t) a.ldB1 * 8ull < (1ull << 32));
-    if (small) return has_b1 ? launch_panel<R, NV, false, true>(p, a, s) : launch_panel<R, NV, false, false>(p, a, s);
-    return has_b1 ? launch_panel<R, NV, true, true>(p, a, s) : launch_panel<R, NV, true, false>(p, a, s);
+    if (small)
+        return has_b1 ? launch_panel<R, NV, VW, false, true>(p, a, s) : launch_panel<R, NV, VW, false, false>(p, a, s);
+    return has_b1 ? launch_panel<R, NV, VW, true, true>(p, a, s) : launch_panel<R, NV, VW, true, false>(p, a, s);
 }
 
-bool spmm_panel_applicable(const SpmmArgs &a)
+// The row-panel kernels need one lane per column (pair): below ~24 columns most lanes of the
+// wave would idle and the CSR row-group kernel (several rows per wave) is the better shape.
+bool spmm_panel_applicable(const SpmmArgs &a) { return a.n >= 24; }
+
+template <int R>
+static hipError_t launch_panel_shape(const PanelArgs &p, const SpmmArgs &a, hipStream_t s)
 {
-    return (a.n > 64) && (a.n % 2 == 0) && (a.ldB0 % 2 == 0) && (a.ldC % 2 == 0) &&
-           (a.B1 == nullptr || a.ldB1 % 2 == 0) &&
-           (((uintptr_t) a.B0 | (uintptr_t) a.B1 | (uintptr_t) a.C) % 16 == 0);
+    const bool vec2 = (a.n % 2 == 0) && (a.ldB0 % 2 == 0) && (a.ldC % 2 == 0) && (a.B1 == nullptr || a.ldB1 % 2 == 0) &&
+                      (((uintptr_t) a.B0 | (uintptr_t) a.B1 | (uintptr_t) a.C) % 16 == 0);
+    if (vec2 && a.n > 128) return launch_panel_addr<R, 2, 2>(p, a, s);   // 256-column tiles, 16 B per lane
+    if (vec2 && a.n > 64)  return launch_panel_addr<R, 1, 2>(p, a, s);   // 128-column tile
+    if (a.n > 64) return launch_panel_addr<R, 2, 1>(p, a, s);            // odd / unaligned operands: 8 B per lane
+    return launch_panel_addr<R, 1, 1>(p, a, s);                          // n <= 64: one column per lane
 }
 
 hipError_t spmm_rm_f64_panel(const PanelArgs &p, const SpmmArgs &a, hipStream_t s)
 {
-    const bool wide = a.n > 128;
-    if (p.R == 4) return wide ? launch_panel_addr<4, 2>(p, a, s) : launch_panel_addr<4, 1>(p, a, s);
-    if (p.R == 8) return wide ? launch_panel_addr<8, 2>(p, a, s) : launch_panel_addr<8, 1>(p, a, s);
+    if (p.R == 4) return launch_panel_shape<4>(p, a, s);
+    if (p.R == 8) return launch_panel_shape<8>(p, a, s);
     return hipErrorInvalidValue;
 }
 

@@ -1,0 +1,72 @@
+"""Worker for tests/test_gpu_dist.py: N ranks sharing ONE GPU (rehearsal of the N > 1 device
+path: RCCL refuses two ranks on one device, so device payloads are staged through the host and
+gloo -- every kernel, plan and buffer is the real one)."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import torch
+    import torch.distributed as dist
+    import oracle as orc
+    from crp_spmm_amd import comm as crp_comm, engine, gen, planner
+
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    crp_comm.init_process_group()
+    assert crp_comm.exchange_mode() == "host"
+    world = crp_comm.TorchComm()
+    P, me = world.nproc, world.rank
+    m = k = 6000
+    rp, ci, va = gen.banded_fem(m, offsets=(1, 2, 3, 4, 50, 51, 1400), seed=5)
+    for n in (24, 256):
+        B = orc.fill_B(0, k, 0, n)
+        C_ref = orc.spmm_csr(rp, ci, va, B)
+        rb = planner.csr_mat_row_partition(rp, P)
+        # ---- 1D engine, layout 0 and 1, device operands
+        s, e = int(rb[me]), int(rb[me + 1])
+        eng = engine.RpSpmm(s, e - s, rp[s:e + 1], ci[rp[s]:rp[e]], va[rp[s]:rp[e]], rb, n, world)
+        Bd = torch.from_numpy(B[s:e].copy()).to(dev)
+        Cd = torch.full((e - s, n), float("nan"), dtype=torch.float64, device=dev)
+        eng.exec(0, Bd, Cd)
+        eng.exec(0, Bd, Cd)
+        torch.cuda.synchronize()
+        assert orc.rel_fro_err(C_ref[s:e], Cd.cpu().numpy()) <= 1e-12, (me, n, "1D rm")
+        Ch = np.full((n, e - s), np.nan)
+        eng.exec(1, np.ascontiguousarray(B[s:e].T), Ch)            # host pointers, column-major
+        assert orc.rel_fro_err(C_ref[s:e], Ch.T) <= 1e-12, (me, n, "1D cm host")
+        eng.print_stat()
+        eng.free()
+        # ---- 2D engine on every grid of P ranks
+        for pn in [d for d in range(1, P + 1) if P % d == 0]:
+            pm = P // pn
+            ac = np.array([rb[i * pn] for i in range(pm + 1)], dtype=np.int32)
+            a0 = np.zeros(P + 1, dtype=np.int32)
+            for i in range(pm):
+                a0[i * pn:(i + 1) * pn + 1] = planner.csr_mat_row_partition(rp[ac[i]:ac[i + 1] + 1] - rp[ac[i]], pn) + ac[i]
+            bc = planner.even_displs(n, pn)
+            pi, pj = me // pn, me % pn
+            s0, e0 = int(a0[me]), int(a0[me + 1])
+            e2 = engine.Para2dSpmm(world, pm, pn, a0, ac, ac, bc, rp[s0:e0 + 1], ci[rp[s0]:rp[e0]], va[rp[s0]:rp[e0]])
+            e2.rp.set_timing(False)
+            Bl = torch.from_numpy(np.ascontiguousarray(B[ac[pi]:ac[pi + 1], bc[pj]:bc[pj + 1]])).to(dev)
+            Cl = torch.full((int(ac[pi + 1] - ac[pi]), int(bc[pj + 1] - bc[pj])), float("nan"), dtype=torch.float64, device=dev)
+            for _ in range(3):
+                e2.exec(0, Bl, Cl)
+            torch.cuda.synchronize()
+            assert orc.rel_fro_err(C_ref[ac[pi]:ac[pi + 1], bc[pj]:bc[pj + 1]], Cl.cpu().numpy()) <= 1e-12, (me, n, pm, pn)
+            e2.print_stat()
+            e2.free()
+            dist.barrier()
+    if me == 0:
+        print("GPU_DIST_WORKER_OK world=%d" % P)
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
