@@ -33,6 +33,7 @@ BARRIER_FN = C.CFUNCTYPE(None, C.c_void_p)
 RED_F64_FN = C.CFUNCTYPE(None, C.c_void_p, c_dbl_p, c_dbl_p, C.c_int, C.c_int)
 RED_U64_FN = C.CFUNCTYPE(None, C.c_void_p, c_u64_p, c_u64_p, C.c_int, C.c_int)
 A2AV_DEV_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, c_ll_p, c_ll_p, C.c_void_p, c_ll_p, c_ll_p, C.c_void_p)
+A2AV_BYTES_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, c_sz_p, c_sz_p, C.c_void_p, c_sz_p, c_sz_p)
 
 
 class CrpComm(C.Structure):
@@ -45,7 +46,7 @@ CrpComm._fields_ = [
     ("ctx", C.c_void_p), ("nproc", C.c_int), ("rank", C.c_int),
     ("alltoall_i32", A2A_FN), ("alltoallv_i32", A2AV_FN), ("allgatherv_bytes", AGV_FN),
     ("barrier", BARRIER_FN), ("reduce_f64", RED_F64_FN), ("reduce_u64", RED_U64_FN),
-    ("alltoallv_dev_f64", A2AV_DEV_FN), ("split", SPLIT_FN), ("free", FREE_FN),
+    ("alltoallv_dev_f64", A2AV_DEV_FN), ("alltoallv_bytes", A2AV_BYTES_FN), ("split", SPLIT_FN), ("free", FREE_FN),
 ]
 
 
@@ -63,6 +64,15 @@ class RpPlanView(C.Structure):
         ("t_init", C.c_double), ("t_pack", C.c_double), ("t_a2a", C.c_double), ("t_unpack", C.c_double),
         ("t_spmm", C.c_double), ("t_exec", C.c_double),
     ]
+
+
+class MatRedistView(C.Structure):
+    _fields_ = [(k, C.c_int) for k in ("nproc", "rank", "src_srow", "src_scol", "src_nrow", "src_ncol", "req_srow",
+                                       "req_scol", "req_nrow", "req_ncol", "n_proc_send", "n_proc_recv", "send_cnt",
+                                       "recv_cnt")] + \
+               [(k, c_int_p) for k in ("send_ranks", "send_sizes", "send_displs", "sblk_sizes", "recv_ranks",
+                                       "recv_sizes", "recv_displs", "rblk_sizes")] + \
+               [("dt_size", C.c_size_t), ("dev_type", C.c_int), ("hd_trans_ms", C.c_double)]
 
 
 _V = C.c_void_p
@@ -83,6 +93,9 @@ SIGNATURES = {
     "crp_dev_free": (_I, [_V]),
     "crp_dev_memset": (_I, [_V, _I, C.c_size_t, _V]),
     "crp_dev_memcpy": (_I, [_V, _V, C.c_size_t, _I, _V]),
+    "crp_dev_memcpy2d": (_I, [_V, C.c_size_t, _V, C.c_size_t, C.c_size_t, C.c_size_t, _I, _V]),
+    "crp_host_malloc": (_I, [C.POINTER(_V), C.c_size_t]),
+    "crp_host_free": (_I, [_V]),
     "crp_dev_ptr_is_device": (_I, [_V, c_int_p]),
     "crp_stream_create": (_I, [C.POINTER(_V)]),
     "crp_stream_destroy": (_I, [_V]),
@@ -136,6 +149,19 @@ SIGNATURES = {
     "crp_para2d_spmm_rp": (_V, [_V]),
     "crp_para2d_spmm_rA_cost": (C.c_size_t, [_V]),
     "crp_para2d_spmm_t_ag_A": (C.c_double, [_V]),
+    "crp_mat_redist_init": (None, [_I] * 8 + [C.POINTER(CrpComm), C.c_size_t, _I, C.POINTER(_V), c_sz_p]),
+    "crp_mat_redist_attach_workbuf": (None, [_V, _V, _V]),
+    "crp_mat_redist_exec": (None, [_V, _V, _I, _V, _I]),
+    "crp_mat_redist_free": (None, [C.POINTER(_V)]),
+    "crp_mat_redist_get_view": (None, [_V, C.POINTER(MatRedistView)]),
+    # dev_type.h
+    "is_dev_type_valid": (_I, [_I]),
+    "dev_type_malloc": (_V, [C.c_size_t, _I]),
+    "dev_type_free": (None, [_V, _I]),
+    "dev_type_realloc": (None, [c_sz_p, C.c_size_t, _I, C.POINTER(_V)]),
+    "dev_type_memset": (None, [_V, _I, C.c_size_t, _I]),
+    "dev_type_memcpy": (None, [_V, _V, C.c_size_t, _I, _I]),
+    "dev_type_copy_matrix": (None, [C.c_size_t, _I, _I, _V, _I, _V, _I, _I]),
     # utils.h
     "get_wtime_sec": (C.c_double, []),
     "calc_block_spos_size": (None, [_I, _I, _I, c_int_p, c_int_p]),

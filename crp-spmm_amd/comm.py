@@ -85,9 +85,10 @@ class TorchComm:
         # keep the CFUNCTYPE objects referenced from self
         self._cbs = (L.A2A_FN(self._alltoall_i32), L.A2AV_FN(self._alltoallv_i32), L.AGV_FN(self._allgatherv_bytes),
                      L.BARRIER_FN(self._barrier), L.RED_F64_FN(self._reduce_f64), L.RED_U64_FN(self._reduce_u64),
-                     L.A2AV_DEV_FN(self._alltoallv_dev_f64), L.SPLIT_FN(self._split), L.FREE_FN(self._free))
+                     L.A2AV_DEV_FN(self._alltoallv_dev_f64), L.A2AV_BYTES_FN(self._alltoallv_bytes),
+                     L.SPLIT_FN(self._split), L.FREE_FN(self._free))
         (s.alltoall_i32, s.alltoallv_i32, s.allgatherv_bytes, s.barrier, s.reduce_f64, s.reduce_u64,
-         s.alltoallv_dev_f64, s.split, s.free) = self._cbs
+         s.alltoallv_dev_f64, s.alltoallv_bytes, s.split, s.free) = self._cbs
         self.struct = s
         self.ptr = C.pointer(s)
         _live[C.addressof(s)] = self
@@ -177,6 +178,23 @@ class TorchComm:
             src = torch.from_numpy(_np_from_ptr(send, ns, np.float64))
             dst = torch.from_numpy(_np_from_ptr(recv, nr, np.float64))
             dist.all_to_all_single(dst, src, output_split_sizes=rc, input_split_sizes=sc, group=self.group)
+
+    def _alltoallv_bytes(self, ctx, send, scnts, sdispls, recv, rcnts, rdispls):
+        P = self.nproc
+        sc = [int(scnts[i]) for i in range(P)]
+        sd = [int(sdispls[i]) for i in range(P)]
+        rc = [int(rcnts[i]) for i in range(P)]
+        rd = [int(rdispls[i]) for i in range(P)]
+        sbuf = _np_from_ptr(send, max((sd[i] + sc[i] for i in range(P)), default=0), np.uint8)
+        parts = [sbuf[sd[i]:sd[i] + sc[i]] for i in range(P)]
+        src = torch.from_numpy(np.concatenate(parts).astype(np.uint8) if parts else np.zeros(0, np.uint8))
+        dst = torch.empty(sum(rc), dtype=torch.uint8)
+        dist.all_to_all_single(dst, src, output_split_sizes=rc, input_split_sizes=sc, group=self.group)
+        out = _np_from_ptr(recv, max((rd[i] + rc[i] for i in range(P)), default=0), np.uint8)
+        off, d = 0, dst.numpy()
+        for i in range(P):
+            out[rd[i]:rd[i] + rc[i]] = d[off:off + rc[i]]
+            off += rc[i]
 
     # ---- split / free ---------------------------------------------------------
     def _split(self, ctx, color, key):

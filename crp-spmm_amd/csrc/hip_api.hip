@@ -135,6 +135,35 @@ int crp_dev_memcpy(void *dst, const void *src, size_t bytes, int kind, void *str
     return 0;
 }
 
+int crp_dev_memcpy2d(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width_bytes, size_t height,
+                     int kind, void *stream)
+{
+    if (width_bytes == 0 || height == 0) return 0;
+    hipMemcpyKind k;
+    if (kind == 0) k = hipMemcpyHostToDevice;
+    else if (kind == 1) k = hipMemcpyDeviceToHost;
+    else if (kind == 2) k = hipMemcpyDeviceToDevice;
+    else return -1;
+    CRP_TRY(hipMemcpy2DAsync(dst, dpitch, src, spitch, width_bytes, height, k, (hipStream_t) stream));
+    return 0;
+}
+
+int crp_host_malloc(void **ptr, size_t bytes)
+{
+    if (ptr == NULL) return -1;
+    *ptr = NULL;
+    if (bytes == 0) return 0;
+    CRP_TRY(hipHostMalloc(ptr, bytes, hipHostMallocDefault));
+    return 0;
+}
+
+int crp_host_free(void *ptr)
+{
+    if (ptr == NULL) return 0;
+    CRP_TRY(hipHostFree(ptr));
+    return 0;
+}
+
 int crp_dev_ptr_is_device(const void *ptr, int *is_dev)
 {
     if (is_dev == NULL) return -1;

@@ -16,6 +16,7 @@
 #include <mpi.h>
 #include "crp_engine.h"
 #include "crpspmm_hip.h"
+#include "mat_redist.h"
 #include "para2d_spmm.h"
 #include "rowpara_spmm.h"
 #include "utils.h"
@@ -109,6 +110,22 @@ void m_alltoallv_dev(void *c, const double *send_dev, const long long *sc, const
     }
 }
 
+void m_alltoallv_bytes(void *c, const void *s, const size_t *sc, const size_t *sd, void *r, const size_t *rc,
+                       const size_t *rd)
+{
+    MpiCtx *x = (MpiCtx *) c;
+    int P;
+    MPI_Comm_size(x->comm, &P);
+    std::vector<int> isc(P), isd(P), irc(P), ird(P);
+    for (int i = 0; i < P; i++)
+    {
+        ASSERT_PRINTF(sc[i] <= INT_MAX && sd[i] <= INT_MAX && rc[i] <= INT_MAX && rd[i] <= INT_MAX,
+                      "alltoallv piece exceeds 2 GiB\n");
+        isc[i] = (int) sc[i]; isd[i] = (int) sd[i]; irc[i] = (int) rc[i]; ird[i] = (int) rd[i];
+    }
+    MPI_Alltoallv(s, isc.data(), isd.data(), MPI_BYTE, r, irc.data(), ird.data(), MPI_BYTE, x->comm);
+}
+
 crp_comm_t *wrap(MPI_Comm comm, bool owned);
 
 crp_comm_t *m_split(void *c, int color, int key)
@@ -143,6 +160,7 @@ crp_comm_t *wrap(MPI_Comm comm, bool owned)
     c->reduce_f64 = m_red_f64;
     c->reduce_u64 = m_red_u64;
     c->alltoallv_dev_f64 = m_alltoallv_dev;
+    c->alltoallv_bytes = m_alltoallv_bytes;
     c->split = m_split;
     c->free = m_free;
     return c;
@@ -196,6 +214,28 @@ void sync_public(rp_spmm_p s)
     s->rB_recv_size = v.rB_recv_size; s->n_exec = v.n_exec;
     s->t_init = v.t_init; s->t_pack = v.t_pack; s->t_a2a = v.t_a2a; s->t_unpack = v.t_unpack;
     s->t_spmm = v.t_spmm; s->t_exec = v.t_exec;
+}
+
+struct RdGlue
+{
+    crp_mat_redist_p eng = nullptr;
+    crp_comm_t      *comm = nullptr;
+};
+
+void rd_sync_public(mat_redist_engine_p s)
+{
+    RdGlue *g = (RdGlue *) s->impl;
+    crp_mat_redist_view_t v;
+    crp_mat_redist_get_view(g->eng, &v);
+    s->nproc = v.nproc; s->rank = v.rank;
+    s->src_srow = v.src_srow; s->src_scol = v.src_scol; s->src_nrow = v.src_nrow; s->src_ncol = v.src_ncol;
+    s->req_srow = v.req_srow; s->req_scol = v.req_scol; s->req_nrow = v.req_nrow; s->req_ncol = v.req_ncol;
+    s->n_proc_send = v.n_proc_send; s->n_proc_recv = v.n_proc_recv; s->send_cnt = v.send_cnt; s->recv_cnt = v.recv_cnt;
+    s->send_ranks = (int *) v.send_ranks; s->send_sizes = (int *) v.send_sizes;
+    s->send_displs = (int *) v.send_displs; s->sblk_sizes = (int *) v.sblk_sizes;
+    s->recv_ranks = (int *) v.recv_ranks; s->recv_sizes = (int *) v.recv_sizes;
+    s->recv_displs = (int *) v.recv_displs; s->rblk_sizes = (int *) v.rblk_sizes;
+    s->hd_trans_ms = v.hd_trans_ms;
 }
 
 struct P2dGlue
@@ -253,6 +293,75 @@ void rp_spmm_clear_stat(rp_spmm_p s)
     if (s == NULL) return;
     crp_rp_spmm_clear_stat(((RpGlue *) s->impl)->eng);
     sync_public(s);
+}
+
+void mat_redist_engine_init(const int src_srow, const int src_scol, const int src_nrow, const int src_ncol,
+                            const int req_srow, const int req_scol, const int req_nrow, const int req_ncol,
+                            MPI_Comm comm, MPI_Datatype dtype, const size_t dt_size, dev_type_t dev_type,
+                            mat_redist_engine_p *engine_, size_t *workbuf_bytes)
+{
+    if (is_dev_type_valid(dev_type) == 0)
+    {
+        ERROR_PRINTF("Invalid device type %d\n", dev_type);
+        return;
+    }
+    if (dev_type != DEV_TYPE_HOST) select_device_once();
+    mat_redist_engine_p s = (mat_redist_engine_p) calloc(1, sizeof(mat_redist_engine_s));
+    RdGlue *g = new RdGlue;
+    g->comm = wrap(comm, false);
+    crp_mat_redist_init(src_srow, src_scol, src_nrow, src_ncol, req_srow, req_scol, req_nrow, req_ncol, g->comm,
+                        dt_size, (int) dev_type, &g->eng, workbuf_bytes);
+    if (g->eng == NULL)
+    {
+        g->comm->free(g->comm);
+        delete g;
+        free(s);
+        return;
+    }
+    s->impl = g;
+    s->graph_comm = MPI_COMM_NULL;
+    s->dtype = dtype;
+    s->dt_size = dt_size;
+    s->dev_type = dev_type;
+    s->alloc_workbuf = (workbuf_bytes == NULL) ? 1 : 0;
+    rd_sync_public(s);
+    *engine_ = s;
+}
+
+void mat_redist_engine_attach_workbuf(mat_redist_engine_p s, void *workbuf_h, void *workbuf_d)
+{
+    if (s == NULL)
+    {
+        WARNING_PRINTF("mat_redist_engine not initialized\n");
+        return;
+    }
+    crp_mat_redist_attach_workbuf(((RdGlue *) s->impl)->eng, workbuf_h, workbuf_d);
+    s->workbuf_h = workbuf_h;
+    s->workbuf_d = workbuf_d;
+}
+
+void mat_redist_engine_exec(mat_redist_engine_p s, const void *src_blk, const int src_ld, void *dst_blk,
+                            const int dst_ld)
+{
+    if (s == NULL)
+    {
+        WARNING_PRINTF("mat_redist_engine not initialized\n");
+        return;
+    }
+    crp_mat_redist_exec(((RdGlue *) s->impl)->eng, src_blk, src_ld, dst_blk, dst_ld);
+    rd_sync_public(s);
+}
+
+void mat_redist_engine_free(mat_redist_engine_p *engine_)
+{
+    if (engine_ == NULL || *engine_ == NULL) return;
+    mat_redist_engine_p s = *engine_;
+    RdGlue *g = (RdGlue *) s->impl;
+    crp_mat_redist_free(&g->eng);
+    if (g->comm) g->comm->free(g->comm);
+    delete g;
+    free(s);
+    *engine_ = NULL;
 }
 
 void para2d_spmm_init(MPI_Comm comm, const int pm, const int pn, const int *A0_rowptr, const int *B_rowptr,

@@ -498,6 +498,11 @@ static void self_red_f64(void *, const double *in, double *out, int n, int) { me
 static void self_red_u64(void *, const uint64_t *in, uint64_t *out, int n, int) { memcpy(out, in, sizeof(uint64_t) * (size_t) n); }
 static void self_a2av_dev(void *, const double *, const long long *, const long long *, double *, const long long *,
                           const long long *, void *) {}
+static void self_a2av_bytes(void *, const void *s, const size_t *sc, const size_t *sd, void *r, const size_t *,
+                            const size_t *rd)
+{
+    memcpy((char *) r + rd[0], (const char *) s + sd[0], sc[0]);
+}
 static void self_free(crp_comm_t *c) { free(c); }
 static crp_comm_t *self_split(void *, int, int) { return crp_comm_self(); }
 
@@ -513,6 +518,7 @@ crp_comm_t *crp_comm_self(void)
     c->reduce_f64 = self_red_f64;
     c->reduce_u64 = self_red_u64;
     c->alltoallv_dev_f64 = self_a2av_dev;
+    c->alltoallv_bytes = self_a2av_bytes;
     c->split = self_split;
     c->free = self_free;
     return c;

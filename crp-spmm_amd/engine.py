@@ -207,3 +207,65 @@ class Para2dSpmm:
             self.free()
         except Exception:
             pass
+
+
+class MatRedist:
+    """Generic dense 2D-block redistribution, arguments as mat_redist_engine_init
+    (/root/reference/src/mat_redist.h:53-74) with the communicator in place of MPI_Comm / MPI_Datatype.
+    dev_type: 0 host, 1 device staged through the host, 2 device to device."""
+
+    def __init__(self, src_srow, src_scol, src_nrow, src_ncol, req_srow, req_scol, req_nrow, req_ncol, comm,
+                 dt_size=8, dev_type=0):
+        lib = L.load()
+        self._lib, self.comm = lib, comm
+        self.handle = C.c_void_p()
+        lib.crp_mat_redist_init(src_srow, src_scol, src_nrow, src_ncol, req_srow, req_scol, req_nrow, req_ncol,
+                                comm.ptr, dt_size, dev_type, C.byref(self.handle), None)
+        if not self.handle:
+            raise ValueError("mat_redist_engine_init rejected the arguments (invalid dev_type?)")
+        self.dt_size, self.dev_type = dt_size, dev_type
+        self.req_shape = (req_nrow, req_ncol)
+
+    def exec(self, src_blk, dst_blk):
+        """src_blk / dst_blk: 2-D row-major numpy arrays (dev_type 0) or cuda tensors (1, 2)."""
+        sp, sld, _a = _ptr_ld_any(src_blk)
+        dp, dld, _b = _ptr_ld_any(dst_blk)
+        self._lib.crp_mat_redist_exec(self.handle, sp, sld, dp, dld)
+
+    def view(self):
+        v = L.MatRedistView()
+        self._lib.crp_mat_redist_get_view(self.handle, C.byref(v))
+
+        def arr(p, n):
+            return np.ctypeslib.as_array(p, (n,)).copy() if n > 0 else np.zeros(0, np.int32)
+        d = {k: getattr(v, k) for k in ("nproc", "rank", "n_proc_send", "n_proc_recv", "send_cnt", "recv_cnt", "hd_trans_ms")}
+        d["send_ranks"], d["send_sizes"] = arr(v.send_ranks, v.n_proc_send), arr(v.send_sizes, v.n_proc_send)
+        d["send_displs"], d["sblk_sizes"] = arr(v.send_displs, v.n_proc_send + 1), arr(v.sblk_sizes, 4 * v.n_proc_send)
+        d["recv_ranks"], d["recv_sizes"] = arr(v.recv_ranks, v.n_proc_recv), arr(v.recv_sizes, v.n_proc_recv)
+        d["recv_displs"], d["rblk_sizes"] = arr(v.recv_displs, v.n_proc_recv + 1), arr(v.rblk_sizes, 4 * v.n_proc_recv)
+        return d
+
+    def free(self):
+        if getattr(self, "handle", None) is not None and self.handle:
+            self._lib.crp_mat_redist_free(C.byref(self.handle))
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _ptr_ld_any(x):
+    """(address, leading dimension in elements, keepalive) of a 2-D row-major operand of any dtype."""
+    try:
+        import torch
+        if isinstance(x, torch.Tensor):
+            assert x.dim() == 2 and (x.shape[1] <= 1 or x.stride(1) == 1)
+            return x.data_ptr(), x.stride(0) if x.shape[0] > 1 else max(x.shape[1], 1), x
+    except ImportError:
+        pass
+    assert isinstance(x, np.ndarray) and x.ndim == 2 and (x.shape[1] <= 1 or x.strides[1] == x.itemsize)
+    ld = x.strides[0] // x.itemsize if x.shape[0] > 1 else max(x.shape[1], 1)
+    return x.ctypes.data, ld, x

@@ -56,6 +56,11 @@ struct crp_comm
                               const long long *sdispls, double *recv_dev, const long long *rcnts,
                               const long long *rdispls, void *stream);
 
+    /* Host all-to-all of raw bytes (counts / displs in bytes, nproc entries each): the payload
+     * of the generic redistribution, MPI_Neighbor_alltoallv in src/mat_redist.c:357-360. */
+    void (*alltoallv_bytes)(void *ctx, const void *send, const size_t *scnts, const size_t *sdispls,
+                            void *recv, const size_t *rcnts, const size_t *rdispls);
+
     /* MPI_Comm_split(color, key)                           src/para2d_spmm.c:41-43.
      * Returns a new communicator owned by the caller (release with ->free). */
     crp_comm_t *(*split)(void *ctx, int color, int key);

@@ -112,6 +112,36 @@ crp_rp_spmm_p crp_para2d_spmm_rp(crp_para2d_spmm_p para2d_spmm);
 size_t crp_para2d_spmm_rA_cost(crp_para2d_spmm_p para2d_spmm);
 double crp_para2d_spmm_t_ag_A(crp_para2d_spmm_p para2d_spmm);
 
+/* ---- generic dense 2D-block redistribution (src/mat_redist.h:7-100) over a crp_comm_t --------
+ * Every rank owns the rectangle (src_srow, src_scol, src_nrow, src_ncol) of a global row-major
+ * matrix (owners must not overlap) and asks for (req_srow, req_scol, req_nrow, req_ncol).  init
+ * gathers all rectangles, intersects them (src/mat_redist.c:9-41, 81-153) and records, in rank
+ * order, which rectangles go to / come from whom; exec packs the send rectangles contiguously
+ * (row-major, ld = ncol), exchanges them, and unpacks into dst.  dev_type (include/dev_type.h):
+ * 0 host buffers; 1 device buffers, exchange staged through pinned host memory; 2 device buffers,
+ * exchanged device to device (dt_size 8 only; otherwise staged).  Pure byte movement: bit-exact. */
+typedef struct crp_mat_redist *crp_mat_redist_p;
+typedef struct crp_mat_redist_view
+{
+    int nproc, rank, src_srow, src_scol, src_nrow, src_ncol, req_srow, req_scol, req_nrow, req_ncol;
+    int n_proc_send, n_proc_recv, send_cnt, recv_cnt;      /* counts in elements                      */
+    const int *send_ranks, *send_sizes, *send_displs, *sblk_sizes;   /* as src/mat_redist.h:27-30     */
+    const int *recv_ranks, *recv_sizes, *recv_displs, *rblk_sizes;   /* as src/mat_redist.h:31-34     */
+    size_t dt_size;
+    int    dev_type;
+    double hd_trans_ms;
+} crp_mat_redist_view_t;
+/* *engine is left untouched (NULL) on an invalid dev_type, after the reference's "[ERROR] ...
+ * Invalid device type" message (src/mat_redist.c:51-55).  workbuf_bytes != NULL: the size of the
+ * work buffer is returned and the caller attaches one; NULL: the engine allocates it. */
+void crp_mat_redist_init(int src_srow, int src_scol, int src_nrow, int src_ncol, int req_srow, int req_scol,
+                         int req_nrow, int req_ncol, crp_comm_t *comm, size_t dt_size, int dev_type,
+                         crp_mat_redist_p *engine, size_t *workbuf_bytes);
+void crp_mat_redist_attach_workbuf(crp_mat_redist_p engine, void *workbuf_h, void *workbuf_d);
+void crp_mat_redist_exec(crp_mat_redist_p engine, const void *src_blk, int src_ld, void *dst_blk, int dst_ld);
+void crp_mat_redist_free(crp_mat_redist_p *engine);
+void crp_mat_redist_get_view(crp_mat_redist_p engine, crp_mat_redist_view_t *view);
+
 /* ---- host-only pieces exposed for tests (no GPU needed) -------------------
  * Build only the exchange plan (everything rp_spmm_init computes on the host,
  * including the alltoall of needed row ids) without touching the device.

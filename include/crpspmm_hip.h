@@ -54,6 +54,12 @@ int crp_dev_memset(void *ptr, int value, size_t bytes, void *stream);
 /* kind: 0 host->device, 1 device->host, 2 device->device.  Asynchronous on
  * `stream` when the host side is pinned; crp_stream_sync() to wait. */
 int crp_dev_memcpy(void *dst, const void *src, size_t bytes, int kind, void *stream);
+/* strided copy of `height` rows of `width_bytes` bytes (hipMemcpy2DAsync); pitches in bytes. */
+int crp_dev_memcpy2d(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width_bytes,
+                     size_t height, int kind, void *stream);
+/* pinned host memory (hipHostMalloc / hipHostFree) */
+int crp_host_malloc(void **ptr, size_t bytes);
+int crp_host_free(void *ptr);
 /* returns 1 in *is_dev when ptr is device memory, 0 for host memory. */
 int crp_dev_ptr_is_device(const void *ptr, int *is_dev);
 

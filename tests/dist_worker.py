@@ -36,6 +36,48 @@ def emulate_exec(plan, comm, B_loc, n, orc):
     return orc.spmm_csr(plan["A_rowptr"], cc.astype(np.int32), plan["A_val"], stacked, n=n)
 
 
+def check_mat_redist(world, orc):
+    """crp_mat_redist_* (host mode) against the fixture produced by the REFERENCE's own engine
+    (tests/golden/mat_redist_P*.json) and against direct slicing of the global matrix."""
+    import json
+    from crp_spmm_amd import engine
+    P, me = world.nproc, world.rank
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "mat_redist_P%d.json" % P)))
+    M, N = fx["M"], fx["N"]
+    G = np.arange(M, dtype=np.float64)[:, None] * 4096.0 + np.arange(N, dtype=np.float64)[None, :]
+    for si, sc in enumerate(fx["scenarios"]):
+        r = sc[me]
+        for dt in (np.float64, np.int32):
+            e = engine.MatRedist(*r, world, dt_size=np.dtype(dt).itemsize, dev_type=0)
+            v = e.view()
+            exp = fx["expected"][str(si)][str(me)]
+            for key in ("n_proc_send", "n_proc_recv", "send_cnt", "recv_cnt"):
+                assert v[key] == exp[key], (si, me, key)
+            for key in ("send_ranks", "send_sizes", "send_displs", "sblk_sizes", "recv_ranks", "recv_sizes",
+                        "recv_displs", "rblk_sizes"):
+                assert list(v[key]) == exp[key], (si, me, key, list(v[key]), exp[key])
+            src = np.zeros((max(r[2], 1), r[3] + 1), dtype=dt)
+            src[:r[2], :r[3]] = G[r[0]:r[0] + r[2], r[1]:r[1] + r[3]].astype(dt)
+            dst = np.full((max(r[6], 1), r[7] + 2), -1, dtype=dt)
+            e.exec(src[:, :max(r[3], 1)] if r[3] else src, dst[:, :max(r[7], 1)] if r[7] else dst)
+            got = dst[:r[6], :r[7]]
+            assert list(got.astype(np.float64).reshape(-1)) == [float(x) for x in exp["dst"]], (si, me, "vs reference")
+            # every requested cell that some rank owns must equal the global matrix
+            owned = np.zeros((M, N), dtype=bool)
+            for q in sc:
+                owned[q[0]:q[0] + q[2], q[1]:q[1] + q[3]] = True
+            sub = owned[r[4]:r[4] + r[6], r[5]:r[5] + r[7]]
+            assert np.array_equal(got[sub], G[r[4]:r[4] + r[6], r[5]:r[5] + r[7]].astype(dt)[sub])
+            assert (dst[:r[6], r[7]:] == -1).all()          # padding columns untouched
+            e.free()
+    # invalid dev_type: message + engine left unset (src/mat_redist.c:51-55)
+    try:
+        engine.MatRedist(0, 0, 1, 1, 0, 0, 1, 1, world, dev_type=7)
+        raise AssertionError("invalid dev_type accepted")
+    except ValueError:
+        pass
+
+
 def main():
     import torch.distributed as dist
     import oracle as orc
@@ -100,6 +142,8 @@ def main():
             assert orc.rel_fro_err(C_ref[ac[pi]:ac[pi + 1], bc[pj]:bc[pj + 1]], C_loc) <= 1e-13, (me, pm, pn)
         e2.free()
         dist.barrier()
+    dist.barrier()
+    check_mat_redist(world, orc)
     dist.barrier()
     if me == 0:
         print("DIST_WORKER_OK world=%d" % P)
