@@ -16,7 +16,7 @@ struct PanelDev
 {
     bool      built = false;
     int       R = 0, npanel = 0;
-    int      *pptr = nullptr, *pcol = nullptr;
+    int      *pptr = nullptr, *pcol = nullptr, *porder = nullptr;
     uint32_t *pmask4 = nullptr;
     double   *pval = nullptr;
     double    fill = 0.0;
@@ -61,6 +61,9 @@ static int ensure_panel(crp_csr_dev *A, int idx)
     if (e == hipSuccess) e = hipMalloc((void **) &d.pcol, sizeof(int) * (h.pcol.size() + 64));
     if (e == hipSuccess) e = hipMalloc((void **) &d.pmask4, sizeof(uint32_t) * (h.pmask4.size() + 16));
     if (e == hipSuccess) e = hipMalloc((void **) &d.pval, sizeof(double) * (h.pval.size() + 512));
+    if (e == hipSuccess) e = hipMalloc((void **) &d.porder, sizeof(int) * (h.porder.size() + 1));
+    if (e == hipSuccess && !h.porder.empty())
+        e = hipMemcpy(d.porder, h.porder.data(), sizeof(int) * h.porder.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d.pptr, h.pptr.data(), sizeof(int) * h.pptr.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess && !h.pcol.empty())
         e = hipMemcpy(d.pcol, h.pcol.data(), sizeof(int) * h.pcol.size(), hipMemcpyHostToDevice);
@@ -295,6 +298,7 @@ int crp_csr_dev_destroy(crp_csr_dev_p *A_)
     for (int i = 0; i < 2; i++)
     {
         if (A->pan[i].pptr) (void) hipFree(A->pan[i].pptr);
+        if (A->pan[i].porder) (void) hipFree(A->pan[i].porder);
         if (A->pan[i].pcol) (void) hipFree(A->pan[i].pcol);
         if (A->pan[i].pmask4) (void) hipFree(A->pan[i].pmask4);
         if (A->pan[i].pval) (void) hipFree(A->pan[i].pval);
@@ -336,9 +340,6 @@ int crp_spmm_csr_f64(crp_csr_dev_p A, int layout, int n, const double *B0, long 
     hipError_t e;
     if (layout == CRP_LAYOUT_COL_MAJOR) return (int) crp::spmm_cm_f64(a, (hipStream_t) stream);
     int v = (variant == 0) ? A->auto_variant : variant;
-    // measured on MI355X (pwtk stand-in): R = 8 wins from 256 columns up, R = 4 below (the wider
-    // accumulator tile of R = 8 costs occupancy that narrow tiles cannot pay back)
-    if (variant == 0 && v == 3 && n <= 128 && getenv("CRPSPMM_SPMM_VARIANT") == NULL) v = 2;
     if (v >= 2 && (!crp::spmm_panel_applicable(a) || A->nnz == 0)) v = 1;   // narrow / unaligned operands
     if (v >= 2)
     {
@@ -346,7 +347,8 @@ int crp_spmm_csr_f64(crp_csr_dev_p A, int layout, int n, const double *B0, long 
         if (rc != 0) return rc;
         const PanelDev &d = A->pan[v - 2];
         crp::PanelArgs p;
-        p.R = d.R; p.npanel = d.npanel; p.pptr = d.pptr; p.pcol = d.pcol; p.pmask4 = d.pmask4; p.pval = d.pval;
+        memset(&p, 0, sizeof(p));
+        p.R = d.R; p.npanel = d.npanel; p.pptr = d.pptr; p.porder = d.porder; p.pcol = d.pcol; p.pmask4 = d.pmask4; p.pval = d.pval;
         p.b0_rows = A->b0_rows; p.b1_rows = A->b1_rows;
         e = crp::spmm_rm_f64_panel(p, a, (hipStream_t) stream);
     }
@@ -357,7 +359,8 @@ int crp_spmm_csr_f64(crp_csr_dev_p A, int layout, int n, const double *B0, long 
 int crp_csr_dev_auto_variant(crp_csr_dev_p A) { return A ? A->auto_variant : -1; }
 
 int crp_panel_format_host(int nrow, const int *rowptr, const int *colidx, const double *val, int R, int *npanel,
-                          int **pptr, int **pcol, unsigned **pmask4, double **pval, long long *real_entries)
+                          int **pptr, int **pcol, unsigned **pmask4, double **pval, long long *real_entries,
+                          int **porder)
 {
     if (nrow < 0 || rowptr == NULL || (R != 4 && R != 8) || !npanel || !pptr || !pcol || !pmask4 || !pval) return -1;
     crp::PanelHost h;
@@ -372,6 +375,11 @@ int crp_panel_format_host(int nrow, const int *rowptr, const int *colidx, const 
     memcpy(*pmask4, h.pmask4.data(), sizeof(unsigned) * h.pmask4.size());
     if (!h.pval.empty()) memcpy(*pval, h.pval.data(), sizeof(double) * h.pval.size());
     if (real_entries) *real_entries = h.real_entries;
+    if (porder)
+    {
+        *porder = (int *) malloc(sizeof(int) * (h.porder.size() + 1));
+        if (!h.porder.empty()) memcpy(*porder, h.porder.data(), sizeof(int) * h.porder.size());
+    }
     return 0;
 }
 

@@ -26,6 +26,7 @@ struct PanelArgs
     int R;
     int npanel;
     const int      *pptr;
+    const int      *porder;    // processing order of the panels
     const int      *pcol;
     const uint32_t *pmask4;
     const double   *pval;

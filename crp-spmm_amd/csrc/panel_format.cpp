@@ -1,5 +1,6 @@
 // panel_format.cpp -- host construction of the row-panel format (panel_format.h).
 #include <algorithm>
+#include <stdlib.h>
 #include <string.h>
 #include "panel_format.h"
 #include "par.h"
@@ -142,6 +143,90 @@ void build_panels(int nrow, const int *rowptr, const int *colidx, const double *
             for (; q < qend; q++) out->pcol[q] = last_col;   // padding: valid address, mask 0
         }
     });
+    // processing order (CRPSPMM_PANEL_ORDER=0 keeps the natural order; CRPSPMM_PANEL_GROUP = panels per group)
+    const char *eo = getenv("CRPSPMM_PANEL_ORDER"), *eg = getenv("CRPSPMM_PANEL_GROUP");
+    const int group = (eg && atoi(eg) > 0) ? atoi(eg) : 16;
+    if (eo && atoi(eo) == 0)
+    {
+        out->porder.resize((size_t) npanel);
+        for (int i = 0; i < npanel; i++) out->porder[(size_t) i] = i;
+    }
+    else locality_order(*out, group, &out->porder);
+}
+
+void locality_order(const PanelHost &p, int group, std::vector<int> *order)
+{
+    const int np = p.npanel;
+    order->resize((size_t) np);
+    if (group < 1) group = 1;
+    const int ng = (np + group - 1) / group;
+    if (ng <= 2)
+    {
+        for (int i = 0; i < np; i++) (*order)[i] = i;
+        return;
+    }
+    // distinct B rows per group (column codes folded to a dense id space)
+    int max_loc = -1, max_rem = -1;
+    for (int c : p.pcol)
+    {
+        if (c >= 0) { if (c > max_loc) max_loc = c; }
+        else if (~c > max_rem) max_rem = ~c;
+    }
+    const long long nb = (long long) max_loc + 1 + (long long) max_rem + 1;
+    auto bid = [&](int c) -> long long { return c >= 0 ? c : (long long) max_loc + 1 + (~c); };
+    std::vector<std::vector<int>> rows_of((size_t) ng);
+    parallel_chunks(ng, 64, [&](long long b, long long e, int) {
+        for (long long g = b; g < e; g++)
+        {
+            const int pa = (int) g * group, pb = std::min(np, pa + group);
+            std::vector<int> &v = rows_of[(size_t) g];
+            for (int q = p.pptr[pa]; q < p.pptr[pb]; q++) v.push_back((int) bid(p.pcol[(size_t) q]));
+            std::sort(v.begin(), v.end());
+            v.erase(std::unique(v.begin(), v.end()), v.end());
+        }
+    });
+    // inverted index: B row -> groups touching it
+    std::vector<int> deg((size_t) nb + 1, 0);
+    for (int g = 0; g < ng; g++)
+        for (int c : rows_of[(size_t) g]) deg[(size_t) c + 1]++;
+    for (long long c = 0; c < nb; c++) deg[(size_t) c + 1] += deg[(size_t) c];
+    std::vector<int> inv((size_t) deg[(size_t) nb]), fillp(deg.begin(), deg.end() - 1);
+    for (int g = 0; g < ng; g++)
+        for (int c : rows_of[(size_t) g]) inv[(size_t) fillp[(size_t) c]++] = g;
+    // breadth-first over groups; B rows shared by very many groups (dense columns) say nothing
+    // about locality and are skipped
+    const int hub = 64;
+    std::vector<char> seen((size_t) ng, 0);
+    std::vector<int> gorder, nbrs;
+    gorder.reserve((size_t) ng);
+    size_t head = 0;
+    for (int start = 0; start < ng; start++)
+    {
+        if (seen[(size_t) start]) continue;
+        seen[(size_t) start] = 1;
+        gorder.push_back(start);
+        while (head < gorder.size())
+        {
+            const int u = gorder[head++];
+            nbrs.clear();
+            for (int c : rows_of[(size_t) u])
+            {
+                const int d0 = deg[(size_t) c], d1 = deg[(size_t) c + 1];
+                if (d1 - d0 > hub) continue;
+                for (int t = d0; t < d1; t++)
+                    if (!seen[(size_t) inv[(size_t) t]])
+                    {
+                        seen[(size_t) inv[(size_t) t]] = 1;
+                        nbrs.push_back(inv[(size_t) t]);
+                    }
+            }
+            std::sort(nbrs.begin(), nbrs.end());
+            gorder.insert(gorder.end(), nbrs.begin(), nbrs.end());
+        }
+    }
+    size_t w = 0;
+    for (int g : gorder)
+        for (int pn = g * group; pn < std::min(np, (g + 1) * group); pn++) (*order)[w++] = pn;
 }
 
 }  // namespace crp

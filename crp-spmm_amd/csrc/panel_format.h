@@ -28,10 +28,20 @@ struct PanelHost
     std::vector<int>      pcol;    // entries: two-source column index
     std::vector<uint32_t> pmask4;  // entries / 4 words: byte u of word g = mask of entry 4g + u
     std::vector<double>   pval;    // entries * R, value of row r of entry q at q*R + r
+    std::vector<int>      porder;  // npanel: processing order of the panels (locality_order())
     long long real_entries = 0;    // entries before padding
     double fill() const;           // nnz / (real_entries * R)
     long long nnz = 0;
 };
+
+// Processing order of the panels for temporal locality of B: panels are taken in groups of
+// `group` consecutive panels (neighbouring rows share most of their columns, so a group keeps its
+// B rows in L1 / L2 while it runs) and the groups are visited breadth-first over the "shares a B
+// row" relation, starting from group 0.  For a matrix from a 3D mesh in natural order (bands at
+// +-1, +-nx, +-nx*ny) this turns five temporally distant touches of every B row into touches a few
+// hundred groups apart, i.e. inside the 256 MiB Infinity Cache instead of HBM; for a narrow banded
+// matrix it reproduces the natural order.  Pure scheduling: which wave computes which panel.
+void locality_order(const PanelHost &p, int group, std::vector<int> *order);
 
 // Number of panel entries (before padding) a given R would need: cheap pass used
 // to pick R.  colidx may carry the two-source encoding.

@@ -12,6 +12,8 @@
 // c < 0 -> B1 row ~c.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <type_traits>
 #include "kernels.h"
 
 namespace crp {
@@ -218,14 +220,29 @@ hipError_t spmm_rm_f64_rowgroup(const SpmmArgs &a, hipStream_t s)
 constexpr int PANEL_RING  = 8;
 constexpr int PANEL_CHUNK = 64;
 
+typedef int i4v __attribute__((ext_vector_type(4)));
+
 template <bool ADDR64>
 struct BSource
 {
-    __amdgpu_buffer_rsrc_t rsrc;
+    i4v rsrc;              // raw buffer descriptor words (base, stride 0, num_records = 4 GiB - 1, flags)
     const double *base;
     uint32_t ldbytes;
     int64_t  ld;
 };
+
+// 128-bit buffer descriptor for a linear byte buffer at `p` (same words as
+// __builtin_amdgcn_make_buffer_rsrc(p, 0, 0xFFFFFFFF, 0x00020000)); every word is forced wave-uniform.
+__device__ __forceinline__ i4v make_rsrc(const void *p)
+{
+    const uint64_t a = (uint64_t) p;
+    i4v r;
+    r.x = __builtin_amdgcn_readfirstlane((int) (uint32_t) a);
+    r.y = __builtin_amdgcn_readfirstlane((int) ((uint32_t) (a >> 32) & 0xFFFFu));
+    r.z = (int) 0xFFFFFFFFu;
+    r.w = 0x00020000;
+    return r;
+}
 
 typedef unsigned int u2v __attribute__((ext_vector_type(2)));
 
@@ -234,26 +251,37 @@ template <int VW> struct SlotT;
 template <> struct SlotT<2> { typedef d2 type; };
 template <> struct SlotT<1> { typedef double type; };
 
+// B-slice loads are issued from inline asm so that the compiler does NOT know they are pending:
+// its waitcnt pass is conservative for loads that cross a loop back-edge (it drains the ring with
+// vmcnt(0) once per round), whereas the ring is consumed strictly in issue order and the number of
+// younger loads at every consume point is known exactly -- the consume blocks carry their own counted
+// s_waitcnt vmcnt(N).  Compiler-issued VMEM ops interleaved with these only make its own waits
+// stricter (in-order counter), never weaker.
 template <int VW>
-__device__ __forceinline__ typename SlotT<VW>::type buf_load(const __amdgpu_buffer_rsrc_t rsrc, const int voff, const uint32_t soff)
+__device__ __forceinline__ void buf_load_asm(typename SlotT<VW>::type &dst, const i4v rsrc, const int voff, const uint32_t soff)
 {
-    if constexpr (VW == 2) return __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0));
-    else return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, soff, 0));
+    if constexpr (VW == 2) asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(rsrc), "s"(soff));
+    else asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(rsrc), "s"(soff));
+}
+
+template <int VW>
+__device__ __forceinline__ void glb_load_asm(typename SlotT<VW>::type &dst, const void *addr)
+{
+    if constexpr (VW == 2) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(addr));
+    else asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(dst) : "v"(addr));
 }
 
 template <bool ADDR64, bool HAS_B1, int NV, int VW>
 __device__ __forceinline__ void panel_issue1(typename SlotT<VW>::type (&slot)[NV], const int cj, const BSource<ADDR64> &s0,
                                              const BSource<ADDR64> &s1, const int (&voff)[NV])
 {
-    typedef typename SlotT<VW>::type ST;
     const bool remote = HAS_B1 && (cj < 0);
     const uint32_t row = remote ? (uint32_t) (~cj) : (uint32_t) cj;
     if constexpr (ADDR64)
     {
         const double *brow = remote ? (s1.base + (int64_t) row * s1.ld) : (s0.base + (int64_t) row * s0.ld);
 #pragma unroll
-        for (int v = 0; v < NV; v++)
-            slot[v] = *reinterpret_cast<const ST *>(reinterpret_cast<const char *>(brow) + voff[v]);
+        for (int v = 0; v < NV; v++) glb_load_asm<VW>(slot[v], reinterpret_cast<const char *>(brow) + voff[v]);
     }
     else
     {
@@ -261,15 +289,13 @@ __device__ __forceinline__ void panel_issue1(typename SlotT<VW>::type (&slot)[NV
         {
             const uint32_t soff = row * s1.ldbytes;
 #pragma unroll
-            for (int v = 0; v < NV; v++)
-                slot[v] = buf_load<VW>(s1.rsrc, voff[v], soff);
+            for (int v = 0; v < NV; v++) buf_load_asm<VW>(slot[v], s1.rsrc, voff[v], soff);
         }
         else
         {
             const uint32_t soff = row * s0.ldbytes;
 #pragma unroll
-            for (int v = 0; v < NV; v++)
-                slot[v] = buf_load<VW>(s0.rsrc, voff[v], soff);
+            for (int v = 0; v < NV; v++) buf_load_asm<VW>(slot[v], s0.rsrc, voff[v], soff);
         }
     }
 }
@@ -281,39 +307,68 @@ __device__ __forceinline__ double slot_elem(const typename SlotT<VW>::type &s, c
     else return s;
 }
 
+// wait until at most N vector-memory operations of this wave are outstanding
+template <int N>
+__device__ __forceinline__ void wait_vmcnt()
+{
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// Masked in-place FMA of one panel row: if bit BIT of the (wave-uniform, SGPR) mask is set,
+// acc[v][w] += a * slot[v][w].  One inline-asm block holding the scalar test, the branch and the
+// v_fmac_f64 group: written in C (`if (mask & bit) acc = fma(..)`) hipcc keeps TWO copies of every
+// accumulator and emits one v_mov_b64 per accumulator in front of every branch (as many moves as
+// FMAs, twice the accumulator registers); the asm block is straight-line code to the compiler and
+// updates the accumulators in place.  Absent (row, column) pairs execute no FMA at all (so 0 * Inf
+// never appears), they cost one s_bitcmp + one taken s_cbranch.
+template <int NV, int VW, int BIT>
+__device__ __forceinline__ void fmac_row_masked(double (&acc)[NV][VW], const double a,
+                                                const typename SlotT<VW>::type (&slot)[NV], const uint32_t mask)
+{
+    if constexpr (NV == 2 && VW == 2)
+        asm volatile("s_bitcmp0_b32 %9, %10\n\ts_cbranch_scc1 1f\n\tv_fmac_f64 %0, %4, %5\n\tv_fmac_f64 %1, %4, %6\n\t"
+                     "v_fmac_f64 %2, %4, %7\n\tv_fmac_f64 %3, %4, %8\n1:"
+                     : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1])
+                     : "v"(a), "v"(slot[0].x), "v"(slot[0].y), "v"(slot[1].x), "v"(slot[1].y), "s"(mask), "n"(BIT)
+                     : "scc");
+    else if constexpr (NV == 1 && VW == 2)
+        asm volatile("s_bitcmp0_b32 %5, %6\n\ts_cbranch_scc1 1f\n\tv_fmac_f64 %0, %2, %3\n\tv_fmac_f64 %1, %2, %4\n1:"
+                     : "+v"(acc[0][0]), "+v"(acc[0][1])
+                     : "v"(a), "v"(slot[0].x), "v"(slot[0].y), "s"(mask), "n"(BIT)
+                     : "scc");
+    else if constexpr (NV == 2 && VW == 1)
+        asm volatile("s_bitcmp0_b32 %5, %6\n\ts_cbranch_scc1 1f\n\tv_fmac_f64 %0, %2, %3\n\tv_fmac_f64 %1, %2, %4\n1:"
+                     : "+v"(acc[0][0]), "+v"(acc[1][0])
+                     : "v"(a), "v"(slot[0]), "v"(slot[1]), "s"(mask), "n"(BIT)
+                     : "scc");
+    else
+    {
+        static_assert(NV == 1 && VW == 1, "unsupported tile shape");
+        asm volatile("s_bitcmp0_b32 %3, %4\n\ts_cbranch_scc1 1f\n\tv_fmac_f64 %0, %1, %2\n1:"
+                     : "+v"(acc[0][0])
+                     : "v"(a), "v"(slot[0]), "s"(mask), "n"(BIT)
+                     : "scc");
+    }
+}
+
+template <int R, int NV, int VW, int BIT = 0>
+__device__ __forceinline__ void fmac_rows(double (&acc)[R][NV][VW], const double (&a)[R],
+                                          const typename SlotT<VW>::type (&slot)[NV], const uint32_t mask)
+{
+    fmac_row_masked<NV, VW, BIT>(acc[BIT], a[BIT], slot, mask);
+    if constexpr (BIT + 1 < R) fmac_rows<R, NV, VW, BIT + 1>(acc, a, slot, mask);
+}
+
 template <int R, int NV, int VW>
 __device__ __forceinline__ void panel_consume1(const typename SlotT<VW>::type (&slot)[NV], const uint32_t mask,
                                                const double (&a)[R], double (&acc)[R][NV][VW])
 {
-    if (mask == ((1u << R) - 1u))
-    {
-        // every row of the panel holds this column: straight-line FMAs
-#pragma unroll
-        for (int r = 0; r < R; r++)
-#pragma unroll
-            for (int v = 0; v < NV; v++)
-#pragma unroll
-                for (int w = 0; w < VW; w++) acc[r][v][w] = fma(a[r], slot_elem<VW>(slot[v], w), acc[r][v][w]);
-    }
-    else
-    {
-#pragma unroll
-        for (int r = 0; r < R; r++)
-        {
-            if (mask & (1u << r))          // wave-uniform branch: absent (row, column) pairs cost no FMA
-            {
-#pragma unroll
-                for (int v = 0; v < NV; v++)
-#pragma unroll
-                    for (int w = 0; w < VW; w++) acc[r][v][w] = fma(a[r], slot_elem<VW>(slot[v], w), acc[r][v][w]);
-            }
-        }
-    }
+    fmac_rows<R, NV, VW>(acc, a, slot, (uint32_t) __builtin_amdgcn_readfirstlane((int) mask));
 }
 
 template <int R, int NV, int VW, bool ADDR64, bool HAS_B1>
 __global__ __launch_bounds__(256) void spmm_panel_f64_kernel(
-    const int npanel, const int nrow, const int n,
+    const int npanel, const int nrow, const int n, const int *__restrict__ porder,
     const int *__restrict__ pptr, const int *__restrict__ pcol, const uint32_t *__restrict__ pmask4,
     const double *__restrict__ pval,
     const double *__restrict__ B0, const int64_t ldB0, const double *__restrict__ B1, const int64_t ldB1,
@@ -333,8 +388,9 @@ __global__ __launch_bounds__(256) void spmm_panel_f64_kernel(
     // row into all eight.  Placement only affects speed, never the result.
     const int cpx   = (gridDim.x + 7) >> 3;
     const int wg    = (blockIdx.x & 7) * cpx + (blockIdx.x >> 3);
-    const int panel = __builtin_amdgcn_readfirstlane((int) (wg * 4 + wave));
-    if (panel >= npanel) return;
+    const int slot_id = __builtin_amdgcn_readfirstlane((int) (wg * 4 + wave));
+    if (slot_id >= npanel) return;
+    const int panel = porder[slot_id];       // which panel this wave computes (locality order)
     double *myvals = lds_vals[__builtin_amdgcn_readfirstlane(wave)];
 
     const int col0 = blockIdx.y * TW + lane * VW;
@@ -353,8 +409,8 @@ __global__ __launch_bounds__(256) void spmm_panel_f64_kernel(
     s1.base = B1; s1.ld = ldB1; s1.ldbytes = (uint32_t) (ldB1 * 8);
     if constexpr (!ADDR64)
     {
-        s0.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(B0), 0, 0xFFFFFFFFu, 0x00020000);
-        s1.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(HAS_B1 ? B1 : B0), 0, 0xFFFFFFFFu, 0x00020000);
+        s0.rsrc = make_rsrc(B0);
+        s1.rsrc = make_rsrc(HAS_B1 ? B1 : B0);
     }
 
     double acc[R][NV][VW];
@@ -385,15 +441,41 @@ __global__ __launch_bounds__(256) void spmm_panel_f64_kernel(
             }
             const uint32_t m_lo = pmask4[(q >> 2)], m_hi = pmask4[(q >> 2) + 1];
             const double *lv = myvals + (q - qc) * R;
+            // the values of entry k+1 are requested from LDS (uniform address: broadcast) before entry
+            // k's FMAs run, so the DS latency hides behind them (DS returns in order: counted lgkmcnt)
+            double a_cur[R], a_nxt[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) a_cur[r] = lv[r];
 #pragma unroll
             for (int k = 0; k < RING; k++)
             {
-                double a[R];
+                if (k + 1 < RING)
+                {
 #pragma unroll
-                for (int r = 0; r < R; r++) a[r] = lv[k * R + r];            // uniform-address LDS broadcast
+                    for (int r = 0; r < R; r++) a_nxt[r] = lv[(k + 1) * R + r];
+                }
                 const uint32_t mask = ((k < 4 ? m_lo : m_hi) >> (8 * (k & 3))) & 0xFFu;
-                panel_consume1<R, NV, VW>(ring[k], mask, a, acc);
+                // slot k was issued RING entries ago: in a refill round exactly RING-1 younger entries
+                // (NV loads each) may still be in flight, in the peeled last round only slots k+1..7
+                if (refill) wait_vmcnt<(RING - 1) * NV>();
+                else
+                {
+                    switch (k)
+                    {
+                        case 0: wait_vmcnt<7 * NV>(); break;
+                        case 1: wait_vmcnt<6 * NV>(); break;
+                        case 2: wait_vmcnt<5 * NV>(); break;
+                        case 3: wait_vmcnt<4 * NV>(); break;
+                        case 4: wait_vmcnt<3 * NV>(); break;
+                        case 5: wait_vmcnt<2 * NV>(); break;
+                        case 6: wait_vmcnt<1 * NV>(); break;
+                        default: wait_vmcnt<0>(); break;
+                    }
+                }
+                panel_consume1<R, NV, VW>(ring[k], mask, a_cur, acc);
                 if (refill) panel_issue1<ADDR64, HAS_B1, NV, VW>(ring[k], cnext[k], s0, s1, voff);
+#pragma unroll
+                for (int r = 0; r < R; r++) a_cur[r] = a_nxt[r];
             }
         };
 
@@ -446,7 +528,7 @@ static hipError_t launch_panel(const PanelArgs &p, const SpmmArgs &a, hipStream_
     const int nwg = (p.npanel + 3) / 4;
     dim3 grid((nwg + 7) / 8 * 8, (a.n + TW - 1) / TW);      // multiple of 8 for the XCD remap
     hipLaunchKernelGGL((spmm_panel_f64_kernel<R, NV, VW, ADDR64, HAS_B1>), grid, dim3(256), 0, s, p.npanel, a.nrow, a.n,
-                       p.pptr, p.pcol, p.pmask4, p.pval, a.B0, a.ldB0, a.B1, a.ldB1, a.C, a.ldC);
+                       p.porder, p.pptr, p.pcol, p.pmask4, p.pval, a.B0, a.ldB0, a.B1, a.ldB1, a.C, a.ldC);
     return hipGetLastError();
 }
 

@@ -93,17 +93,18 @@ def panel_format_host(rowptr, colidx, val, R):
     if ci.size == 0:
         ci, va = np.zeros(1, np.int32), np.zeros(1, np.float64)
     npanel, ent = C.c_int(), C.c_longlong()
-    pptr, pcol, pmask, pval = L.c_int_p(), L.c_int_p(), C.POINTER(C.c_uint)(), L.c_dbl_p()
+    pptr, pcol, pmask, pval, pord = L.c_int_p(), L.c_int_p(), C.POINTER(C.c_uint)(), L.c_dbl_p(), L.c_int_p()
     L.check(lib.crp_panel_format_host(rp.size - 1, rp.ctypes.data_as(L.c_int_p), ci.ctypes.data_as(L.c_int_p),
                                       va.ctypes.data_as(L.c_dbl_p), R, C.byref(npanel), C.byref(pptr), C.byref(pcol),
-                                      C.byref(pmask), C.byref(pval), C.byref(ent)), "crp_panel_format_host")
+                                      C.byref(pmask), C.byref(pval), C.byref(ent), C.byref(pord)), "crp_panel_format_host")
     P = npanel.value
     pp = np.ctypeslib.as_array(pptr, (P + 1,)).copy()
     tot = int(pp[P])
     out = dict(R=R, npanel=P, pptr=pp, real_entries=ent.value,
+               porder=np.ctypeslib.as_array(pord, (max(P, 1),))[:P].copy(),
                pcol=np.ctypeslib.as_array(pcol, (max(tot, 1),))[:tot].copy(),
                pmask4=np.ctypeslib.as_array(pmask, (tot // 4 + 2,)).copy(),
                pval=np.ctypeslib.as_array(pval, (max(tot * R, 1),))[:tot * R].copy().reshape(tot, R))
-    for p in (pptr, pcol, pmask, pval):
+    for p in (pptr, pcol, pmask, pval, pord):
         L.c_free(C.cast(p, C.c_void_p))
     return out

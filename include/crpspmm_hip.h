@@ -93,10 +93,13 @@ int crp_csr_dev_auto_variant(crp_csr_dev_p A);
  * and return malloc'd copies (caller frees).  Panel p owns entries pptr[p] .. pptr[p+1]
  * (padded to multiples of 8 with mask-0 entries); entry q has column pcol[q] (two-source
  * encoding), row-presence mask byte (pmask4[q/4] >> 8*(q%4)) & 0xFF and values
- * pval[q*R .. q*R+R-1].  Used by the CPU tests of the format. */
+ * pval[q*R .. q*R+R-1].  porder (optional) receives the order in which the kernel's waves take
+ * the panels: groups of consecutive panels visited breadth-first over shared B rows (temporal
+ * locality of B; CRPSPMM_PANEL_ORDER=0 disables, CRPSPMM_PANEL_GROUP sets the group size).
+ * Used by the CPU tests of the format. */
 int crp_panel_format_host(int nrow, const int *rowptr, const int *colidx, const double *val, int R,
                           int *npanel, int **pptr, int **pcol, unsigned **pmask4, double **pval,
-                          long long *real_entries);
+                          long long *real_entries, int **porder);
 
 /* ---- the hot kernel --------------------------------------------------------
  * C[nrow x n] := A * B (alpha = 1, beta = 0; C is overwritten, never read),

@@ -112,7 +112,7 @@ def test_kernel_two_source_index(crp, orc, gpu):
     pos = np.full(k, -1)
     pos[remote_rows] = np.arange(remote_rows.size)
     c2 = np.where((ci >= lo) & (ci < hi), ci - lo, ~pos[ci]).astype(np.int32)
-    for n_, variant in ((n, 1), (200, 1), (200, 2), (200, 3)):
+    for n_, variant in ((n, 1), (200, 1), (200, 2), (200, 3), (48, 3), (48, 2)):
         B = np.random.default_rng(n_).normal(size=(k, n_))
         got = _spmm(crp, gpu, rp, c2, va, hi - lo, B[lo:hi], n_, B1=B[remote_rows], variant=variant)
         assert orc.rel_fro_err(orc.spmm_csr(rp, ci, va, B), got) <= FP64_TOL, (n_, variant)

@@ -276,3 +276,29 @@ def test_panel_format_host(crp, orc, R):
         assert nnz_seen == rp[-1]
         assert not got[m:].any()
         assert orc.rel_fro_err(ref, got[:m]) <= 1e-14
+
+
+def test_panel_locality_order(crp, monkeypatch):
+    """The processing order is a permutation made of whole groups of consecutive panels; a narrow
+    band reproduces the natural order; for a 3D-mesh-like matrix (bands at +-1, +-nx, +-nx*ny) the
+    panels that share B rows across the far bands end up close together."""
+    from crp_spmm_amd import gen, hip
+    rp, ci, va = gen.banded_fem(4000, offsets=(1, 2), seed=1)
+    f = hip.panel_format_host(rp, ci, va, 4)
+    assert np.array_equal(f["porder"], np.arange(f["npanel"]))
+    nx, ny, nz = 64, 8, 6
+    m = nx * ny * nz
+    rp, ci, va = gen.banded_fem(m, offsets=(1, 2, nx, nx * ny), seed=2)
+    monkeypatch.setenv("CRPSPMM_PANEL_GROUP", "2")
+    f = hip.panel_format_host(rp, ci, va, 4)
+    po = f["porder"]
+    assert np.array_equal(np.sort(po), np.arange(f["npanel"]))
+    assert np.array_equal(po.reshape(-1, 2)[:, 1], po.reshape(-1, 2)[:, 0] + 1)      # groups stay whole
+    pos = np.empty_like(po)
+    pos[po] = np.arange(po.size)
+    far = (nx * ny) // 4                                   # panels one z-plane apart
+    d_nat = far
+    d_ord = np.median(np.abs(pos[far:] - pos[:-far]))
+    assert d_ord < 0.75 * d_nat, (d_ord, d_nat)    # (small mesh: BFS levels are wide; pwtk-size meshes gain far more)
+    monkeypatch.setenv("CRPSPMM_PANEL_ORDER", "0")
+    assert np.array_equal(hip.panel_format_host(rp, ci, va, 4)["porder"], np.arange(f["npanel"]))
