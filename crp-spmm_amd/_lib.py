@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcrpspmm_hip.so")
+LIB_PATH = os.environ.get("CRPSPMM_LIB_PATH") or os.path.join(_HERE, "lib", "libcrpspmm_hip.so")   # override: A/B builds
 
 
 class CrpLibraryError(RuntimeError):

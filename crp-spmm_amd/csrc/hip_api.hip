@@ -66,7 +66,13 @@ static int ensure_panel(crp_csr_dev *A, int idx)
         e = hipMemcpy(d.porder, h.porder.data(), sizeof(int) * h.porder.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d.pptr, h.pptr.data(), sizeof(int) * h.pptr.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess && !h.pcol.empty())
-        e = hipMemcpy(d.pcol, h.pcol.data(), sizeof(int) * h.pcol.size(), hipMemcpyHostToDevice);
+    {
+        // the kernels read column indices up to three rounds past a panel: the tail of the array
+        // repeats the last real column (an addressable row), never an arbitrary value
+        std::vector<int> padded(h.pcol);
+        padded.resize(h.pcol.size() + 64, h.pcol.back());
+        e = hipMemcpy(d.pcol, padded.data(), sizeof(int) * padded.size(), hipMemcpyHostToDevice);
+    }
     if (e == hipSuccess) e = hipMemcpy(d.pmask4, h.pmask4.data(), sizeof(uint32_t) * h.pmask4.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess && !h.pval.empty())
         e = hipMemcpy(d.pval, h.pval.data(), sizeof(double) * h.pval.size(), hipMemcpyHostToDevice);

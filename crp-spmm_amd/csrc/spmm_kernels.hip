@@ -218,7 +218,7 @@ hipError_t spmm_rm_f64_rowgroup(const SpmmArgs &a, hipStream_t s)
 //                        back to 64-bit global addresses when a B block exceeds 4 GiB.
 // ---------------------------------------------------------------------------
 constexpr int PANEL_RING  = 8;
-constexpr int PANEL_CHUNK = 64;
+constexpr int PANEL_CHUNK = 32;
 
 typedef int i4v __attribute__((ext_vector_type(4)));
 
@@ -363,10 +363,18 @@ template <int R, int NV, int VW>
 __device__ __forceinline__ void panel_consume1(const typename SlotT<VW>::type (&slot)[NV], const uint32_t mask,
                                                const double (&a)[R], double (&acc)[R][NV][VW])
 {
+#if defined(CRP_ABL_FULLMASK)   // timing experiment only: every row takes the FMA path (wrong results)
+    fmac_rows<R, NV, VW>(acc, a, slot, (uint32_t) __builtin_amdgcn_readfirstlane((int) (mask | 0xFFu)));
+#elif defined(CRP_ABL_NOFMA)    // timing experiment only: no row takes the FMA path
+    fmac_rows<R, NV, VW>(acc, a, slot, (uint32_t) __builtin_amdgcn_readfirstlane((int) (mask & 0u)));
+#else
     fmac_rows<R, NV, VW>(acc, a, slot, (uint32_t) __builtin_amdgcn_readfirstlane((int) mask));
+#endif
 }
 
-template <int R, int NV, int VW, bool ADDR64, bool HAS_B1>
+// DEPTH = number of 8-slot ring sets: round r lives in set r % DEPTH and is refilled, slot by
+// slot, with round r + DEPTH while it is consumed, so 8*DEPTH - 1 entries stay in flight.
+template <int R, int NV, int VW, int DEPTH, bool ADDR64, bool HAS_B1>
 __global__ __launch_bounds__(256) void spmm_panel_f64_kernel(
     const int npanel, const int nrow, const int n, const int *__restrict__ porder,
     const int *__restrict__ pptr, const int *__restrict__ pcol, const uint32_t *__restrict__ pmask4,
@@ -375,10 +383,13 @@ __global__ __launch_bounds__(256) void spmm_panel_f64_kernel(
     double *__restrict__ C, const int64_t ldC)
 {
     constexpr int TW = 64 * VW * NV;
-    constexpr int RING = PANEL_RING;
-    constexpr int CHUNK = PANEL_CHUNK;
+    constexpr int RING = PANEL_RING;             // entries per round = slots per ring set
+    constexpr int CHUNK = PANEL_CHUNK;           // entries whose values are staged in LDS at a time
+    constexpr int RPC = CHUNK / RING;            // rounds per chunk
+    constexpr int NS = (CHUNK * R) / 128;        // staging loads per lane and chunk (16 B each, 64 lanes)
+    static_assert(NS >= 1 && NS * 128 == CHUNK * R, "chunk must be a whole number of wave-wide 16-byte loads");
     typedef typename SlotT<VW>::type ST;
-    __shared__ __attribute__((aligned(16))) double lds_vals[4][CHUNK * R];
+    __shared__ __attribute__((aligned(16))) double lds_vals[4][2][CHUNK * R];
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -391,7 +402,7 @@ __global__ __launch_bounds__(256) void spmm_panel_f64_kernel(
     const int slot_id = __builtin_amdgcn_readfirstlane((int) (wg * 4 + wave));
     if (slot_id >= npanel) return;
     const int panel = porder[slot_id];       // which panel this wave computes (locality order)
-    double *myvals = lds_vals[__builtin_amdgcn_readfirstlane(wave)];
+    double *myvals = &lds_vals[__builtin_amdgcn_readfirstlane(wave)][0][0];
 
     const int col0 = blockIdx.y * TW + lane * VW;
     bool ok[NV];
@@ -422,42 +433,73 @@ __global__ __launch_bounds__(256) void spmm_panel_f64_kernel(
             for (int w = 0; w < VW; w++) acc[r][v][w] = 0.0;
 
     const int q0 = pptr[panel];
-    const int qe = pptr[panel + 1];          // (qe - q0) is a multiple of RING
-    if (q0 < qe)
+    const int nr = (pptr[panel + 1] - q0) / RING;      // rounds of this panel (entry counts are padded)
+    if (nr > 0)
     {
-        ST ring[RING][NV];
-        int cnext[RING];
-#pragma unroll
-        for (int k = 0; k < RING; k++) cnext[k] = pcol[q0 + k];
-#pragma unroll
-        for (int k = 0; k < RING; k++) panel_issue1<ADDR64, HAS_B1, NV, VW>(ring[k], cnext[k], s0, s1, voff);
+        ST ring[DEPTH][RING][NV];
+        d2 stage[NS];                                   // next chunk's values of entry `lane`, in flight
+        int cA[RING];                                   // column indices of the round refilled next
+        int cP[RING];                                   // ... and of the round after it (scalar loads run two rounds ahead)
 
-        // one round = RING consecutive entries starting at q (inside the staged chunk at qc)
-        auto round = [&](const int q, const int qc, const bool refill) {
-            if (refill)
+        // ---- prologue: values of chunk 0 (synchronous: nothing is in flight yet), rounds 0..DEPTH-1
+        {
+            // the chunk's CHUNK*R values are contiguous: lane l moves doubles [2*NS*l, 2*NS*(l+1))
+            const double *src = pval + (int64_t) q0 * R + lane * (2 * NS);
+            double *dst = myvals + lane * (2 * NS);
+#pragma unroll
+            for (int t = 0; t < NS; t++)
+                *reinterpret_cast<d2 *>(dst + 2 * t) = *reinterpret_cast<const d2 *>(src + 2 * t);
+        }
+#pragma unroll
+        for (int d = 0; d < DEPTH; d++)
+        {
+            if (d < nr)
             {
+                int c0[RING];
 #pragma unroll
-                for (int k = 0; k < RING; k++) cnext[k] = pcol[q + RING + k];   // scalar loads, a round ahead
+                for (int k = 0; k < RING; k++) c0[k] = pcol[q0 + d * RING + k];
+#pragma unroll
+                for (int k = 0; k < RING; k++) panel_issue1<ADDR64, HAS_B1, NV, VW>(ring[d][k], c0[k], s0, s1, voff);
             }
-            const uint32_t m_lo = pmask4[(q >> 2)], m_hi = pmask4[(q >> 2) + 1];
-            const double *lv = myvals + (q - qc) * R;
-            // the values of entry k+1 are requested from LDS (uniform address: broadcast) before entry
-            // k's FMAs run, so the DS latency hides behind them (DS returns in order: counted lgkmcnt)
-            double a_cur[R], a_nxt[R];
+        }
 #pragma unroll
-            for (int r = 0; r < R; r++) a_cur[r] = lv[r];
+        for (int k = 0; k < RING; k++) cA[k] = pcol[q0 + DEPTH * RING + k];     // (arrays are padded)
+#pragma unroll
+        for (int k = 0; k < RING; k++) cP[k] = pcol[q0 + (DEPTH + 1) * RING + k];
+
+        // One round: consume the 8 slots of ring set `set` (entries of round r) and, when `refill`,
+        // re-issue each slot for round r + DEPTH right after its FMAs.  All VMEM of the loop is issued
+        // from asm, so every wait below is hand-counted: N = loads YOUNGER than the one waited for.
+        auto round = [&](const int r, auto set_tag, auto refill_tag) {
+            constexpr int  set = decltype(set_tag)::value;
+            constexpr bool refill = decltype(refill_tag)::value;
+            const int q = q0 + r * RING;
+            int cB[RING];
+#pragma unroll
+            for (int k = 0; k < RING; k++) cB[k] = pcol[q + (DEPTH + 2) * RING + k];   // scalar loads, two rounds ahead
+            const uint32_t m_lo = pmask4[(q >> 2)], m_hi = pmask4[(q >> 2) + 1];
+            // values: chunk c = r / RPC sits in LDS buffer c & 1; the last round of a chunk fetches the
+            // next chunk (every lane one entry; reads past the panel are padded) before its refills ...
+            const bool last_of_chunk = ((r % RPC) == RPC - 1) && (r + 1 < nr);
+            if (last_of_chunk)
+            {
+                const char *src = reinterpret_cast<const char *>(pval + (int64_t) (q + RING) * R + lane * (2 * NS));
+#pragma unroll
+                for (int t = 0; t < NS; t++) glb_load_asm<2>(stage[t], src + 16 * t);
+            }
+            const double *lv = myvals + ((r / RPC) & 1) * (CHUNK * R) + (r % RPC) * (RING * R);
 #pragma unroll
             for (int k = 0; k < RING; k++)
             {
-                if (k + 1 < RING)
-                {
+                double a_cur[R];
 #pragma unroll
-                    for (int r = 0; r < R; r++) a_nxt[r] = lv[(k + 1) * R + r];
-                }
+                for (int rr = 0; rr < R; rr++) a_cur[rr] = lv[k * R + rr];      // uniform-address LDS broadcast
                 const uint32_t mask = ((k < 4 ? m_lo : m_hi) >> (8 * (k & 3))) & 0xFFu;
-                // slot k was issued RING entries ago: in a refill round exactly RING-1 younger entries
-                // (NV loads each) may still be in flight, in the peeled last round only slots k+1..7
-                if (refill) wait_vmcnt<(RING - 1) * NV>();
+                // younger than slot k of this round: slots k+1..7 of the round, the DEPTH-1 rounds issued
+                // after it, and (refill) the k slots re-issued so far; the staging loads of a chunk's
+                // last round are ignored (N too small only over-waits).  Rounds without refill use the
+                // bound that is exact for the panel's last round.
+                if constexpr (refill) wait_vmcnt<(RING * DEPTH - 1) * NV>();
                 else
                 {
                     switch (k)
@@ -472,29 +514,54 @@ __global__ __launch_bounds__(256) void spmm_panel_f64_kernel(
                         default: wait_vmcnt<0>(); break;
                     }
                 }
-                panel_consume1<R, NV, VW>(ring[k], mask, a_cur, acc);
-                if (refill) panel_issue1<ADDR64, HAS_B1, NV, VW>(ring[k], cnext[k], s0, s1, voff);
+                panel_consume1<R, NV, VW>(ring[set][k], mask, a_cur, acc);
+                if constexpr (refill) panel_issue1<ADDR64, HAS_B1, NV, VW>(ring[set][k], cA[k], s0, s1, voff);
+            }
+            if (last_of_chunk)
+            {
+                // ... and parks it in the other LDS buffer once it has landed: younger than the last
+                // staging load are exactly this round's refills
+                if constexpr (refill) wait_vmcnt<RING * NV>();
+                else wait_vmcnt<0>();
+                double *dst = myvals + (((r / RPC) + 1) & 1) * (CHUNK * R) + lane * (2 * NS);
 #pragma unroll
-                for (int r = 0; r < R; r++) a_cur[r] = a_nxt[r];
+                for (int t = 0; t < NS; t++) *reinterpret_cast<d2 *>(dst + 2 * t) = stage[t];
+            }
+#pragma unroll
+            for (int k = 0; k < RING; k++)
+            {
+                cA[k] = cP[k];
+                cP[k] = cB[k];
             }
         };
 
-        for (int qc = q0; qc < qe; qc += CHUNK)
+        int r = 0;
+        if constexpr (DEPTH == 1)
         {
-            const int nent = min(CHUNK, qe - qc);
-            // stage this chunk's values: lane t owns entry qc + t (R contiguous doubles)
-            if (lane < nent)
+            for (; r + 1 < nr; r++) round(r, std::integral_constant<int, 0>{}, std::true_type{});
+            round(r, std::integral_constant<int, 0>{}, std::false_type{});
+        }
+        else
+        {
+            static_assert(DEPTH == 2, "ring depth is 1 or 2 sets");
+            for (; r + 3 < nr; r += 2)
             {
-                const double *src = pval + (int64_t) (qc + lane) * R;
-                double *dst = myvals + lane * R;
-#pragma unroll
-                for (int r = 0; r < R; r += 2)
-                    *reinterpret_cast<d2 *>(dst + r) = *reinterpret_cast<const d2 *>(src + r);
+                round(r, std::integral_constant<int, 0>{}, std::true_type{});
+                round(r + 1, std::integral_constant<int, 1>{}, std::true_type{});
             }
-            const int qend = qc + nent;
-            int q = qc;
-            for (; q + RING < qe && q < qend; q += RING) round(q, qc, true);
-            if (q < qend) round(q, qc, false);       // the panel's last round: nothing left to prefetch
+            // tail: 1 to 3 rounds left; only a round that still has a successor DEPTH ahead refills
+            if (r + 2 < nr)
+            {
+                round(r, std::integral_constant<int, 0>{}, std::true_type{});
+                round(r + 1, std::integral_constant<int, 1>{}, std::false_type{});
+                round(r + 2, std::integral_constant<int, 0>{}, std::false_type{});
+            }
+            else if (r + 1 < nr)
+            {
+                round(r, std::integral_constant<int, 0>{}, std::false_type{});
+                round(r + 1, std::integral_constant<int, 1>{}, std::false_type{});
+            }
+            else round(r, std::integral_constant<int, 0>{}, std::false_type{});
         }
     }
 #pragma unroll
@@ -521,13 +588,13 @@ __global__ __launch_bounds__(256) void spmm_panel_f64_kernel(
     }
 }
 
-template <int R, int NV, int VW, bool ADDR64, bool HAS_B1>
+template <int R, int NV, int VW, int DEPTH, bool ADDR64, bool HAS_B1>
 static hipError_t launch_panel(const PanelArgs &p, const SpmmArgs &a, hipStream_t s)
 {
     constexpr int TW = 64 * VW * NV;
     const int nwg = (p.npanel + 3) / 4;
     dim3 grid((nwg + 7) / 8 * 8, (a.n + TW - 1) / TW);      // multiple of 8 for the XCD remap
-    hipLaunchKernelGGL((spmm_panel_f64_kernel<R, NV, VW, ADDR64, HAS_B1>), grid, dim3(256), 0, s, p.npanel, a.nrow, a.n,
+    hipLaunchKernelGGL((spmm_panel_f64_kernel<R, NV, VW, DEPTH, ADDR64, HAS_B1>), grid, dim3(256), 0, s, p.npanel, a.nrow, a.n,
                        p.porder, p.pptr, p.pcol, p.pmask4, p.pval, a.B0, a.ldB0, a.B1, a.ldB1, a.C, a.ldC);
     return hipGetLastError();
 }
@@ -539,9 +606,20 @@ static hipError_t launch_panel_addr(const PanelArgs &p, const SpmmArgs &a, hipSt
     const bool has_b1 = (a.B1 != nullptr) && (p.b1_rows > 0);
     const bool small = ((uint64_t) p.b0_rows * (uint64_t) a.ldB0 * 8ull < (1ull << 32)) &&
                        (!has_b1 || (uint64_t) p.b1_rows * (uint64_t) a.ldB1 * 8ull < (1ull << 32));
+    // ring depth: one set of 8 slots by default.  Two sets (15 entries in flight, CRPSPMM_PANEL_DEPTH=2,
+    // R = 8 wide tiles only) are kept as a measurement knob: hipcc needs 326 VGPRs for that body (one
+    // wave per SIMD) and it runs 40 % slower than the one-set body at three waves per SIMD.
+    static const int env_depth = getenv("CRPSPMM_PANEL_DEPTH") ? atoi(getenv("CRPSPMM_PANEL_DEPTH")) : 0;
+    const bool deep = (env_depth == 2);
+    if (deep && R == 8 && NV == 2 && VW == 2)
+    {
+        if (small)
+            return has_b1 ? launch_panel<R, NV, VW, 2, false, true>(p, a, s) : launch_panel<R, NV, VW, 2, false, false>(p, a, s);
+        return has_b1 ? launch_panel<R, NV, VW, 2, true, true>(p, a, s) : launch_panel<R, NV, VW, 2, true, false>(p, a, s);
+    }
     if (small)
-        return has_b1 ? launch_panel<R, NV, VW, false, true>(p, a, s) : launch_panel<R, NV, VW, false, false>(p, a, s);
-    return has_b1 ? launch_panel<R, NV, VW, true, true>(p, a, s) : launch_panel<R, NV, VW, true, false>(p, a, s);
+        return has_b1 ? launch_panel<R, NV, VW, 1, false, true>(p, a, s) : launch_panel<R, NV, VW, 1, false, false>(p, a, s);
+    return has_b1 ? launch_panel<R, NV, VW, 1, true, true>(p, a, s) : launch_panel<R, NV, VW, 1, true, false>(p, a, s);
 }
 
 // The row-panel kernels need one lane per column (pair): below ~24 columns most lanes of the
