@@ -63,6 +63,29 @@ def main():
             e2.print_stat()
             e2.free()
             dist.barrier()
+    # ---- mat_redist with device-resident blocks (dev_type 1: staged through pinned host memory;
+    #      2: device to device through the communicator's device all-to-all) against the fixture
+    #      produced by the reference's own engine
+    import json
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "mat_redist_P%d.json" % P)))
+    M, N = fx["M"], fx["N"]
+    G = np.arange(M, dtype=np.float64)[:, None] * 4096.0 + np.arange(N, dtype=np.float64)[None, :]
+    for si, sc in enumerate(fx["scenarios"]):
+        r = sc[me]
+        exp = fx["expected"][str(si)][str(me)]
+        for dev_type in (1, 2):
+            e = engine.MatRedist(*r, world, dt_size=8, dev_type=dev_type)
+            src = torch.zeros((max(r[2], 1), r[3] + 1), dtype=torch.float64, device=dev)
+            if r[2] and r[3]:
+                src[:r[2], :r[3]] = torch.from_numpy(G[r[0]:r[0] + r[2], r[1]:r[1] + r[3]].copy()).to(dev)
+            dst = torch.full((max(r[6], 1), r[7] + 2), -1.0, dtype=torch.float64, device=dev)
+            e.exec(src, dst)
+            torch.cuda.synchronize()
+            got = dst.cpu().numpy()
+            assert list(got[:r[6], :r[7]].reshape(-1)) == [float(x) for x in exp["dst"]], (si, me, dev_type)
+            assert (got[:r[6], r[7]:] == -1).all()
+            e.free()
+    dist.barrier()
     if me == 0:
         print("GPU_DIST_WORKER_OK world=%d" % P)
     dist.destroy_process_group()
