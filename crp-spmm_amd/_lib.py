@@ -75,6 +75,19 @@ class MatRedistView(C.Structure):
                [("dt_size", C.c_size_t), ("dev_type", C.c_int), ("hd_trans_ms", C.c_double)]
 
 
+class CrpspmmView(C.Structure):
+    """crp_crpspmm_view_t (include/crp_engine.h)."""
+    _fields_ = [(k, C.c_int) for k in ("np_glb", "rank_glb", "np_row", "np_col", "rank_row", "rank_col", "glb_m", "glb_n",
+                                       "glb_k", "loc_A_srow", "loc_A_erow", "loc_A_nrow", "loc_A_nnz", "loc_A_nnz_s",
+                                       "rd_B_srow", "rd_B_erow", "loc_B_scol", "loc_B_ecol", "loc_B_ncol", "loc_B_srow",
+                                       "loc_B_erow", "loc_B_nrow")] + \
+               [("loc_A_rowptr", c_int_p), ("loc_A_colidx", c_int_p), ("loc_A_val", c_dbl_p), ("red_B", c_dbl_p),
+                ("loc_C", c_dbl_p), ("n_exec", C.c_int)] + \
+               [(k, C.c_double) for k in ("t_init", "t_exec", "t_rd_A", "t_agv_A", "t_rd_B", "t_a2a_B", "t_spmm", "t_rd_C",
+                                          "t_exec_nr")] + \
+               [(k, C.c_size_t) for k in ("nelem_A_rd", "nelem_A_agv", "nelem_B_rd", "nelem_B_a2av", "nelem_B_a2av_min")]
+
+
 _V = C.c_void_p
 _I = C.c_int
 _LL = C.c_longlong
@@ -108,6 +121,7 @@ SIGNATURES = {
     "crp_event_elapsed_ms": (_I, [_V, _V, C.POINTER(C.c_float)]),
     "crp_csr_dev_create": (_I, [_I, _I, c_int_p, c_int_p, c_dbl_p, C.POINTER(_V)]),
     "crp_csr_dev_destroy": (_I, [C.POINTER(_V)]),
+    "crp_csr_dev_update_values": (_I, [_V, _V, _V]),
     "crp_csr_dev_nrow": (_I, [_V]),
     "crp_csr_dev_nnz": (_LL, [_V]),
     "crp_csr_dev_bytes": (_LL, [_V]),
@@ -136,6 +150,7 @@ SIGNATURES = {
     "crp_rp_spmm_set_timing": (None, [_V, _I]),
     "crp_rp_spmm_set_variant": (None, [_V, _I]),
     "crp_rp_spmm_alg_bytes": (_LL, [_V]),
+    "crp_rp_spmm_update_values": (None, [_V, c_dbl_p]),
     "crp_rp_spmm_nnz": (_LL, [_V]),
     "crp_rp_spmm_dev_colidx_host": (c_int_p, [_V]),
     "crp_para2d_spmm_init": (None, [C.POINTER(CrpComm), _I, _I, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p,
@@ -155,6 +170,15 @@ SIGNATURES = {
     "crp_mat_redist_exec": (None, [_V, _V, _I, _V, _I]),
     "crp_mat_redist_free": (None, [C.POINTER(_V)]),
     "crp_mat_redist_get_view": (None, [_V, C.POINTER(MatRedistView)]),
+    "crp_crpspmm_init": (None, [_I, _I, _I, _I, _I, c_int_p, c_int_p] + [_I] * 8 + [C.POINTER(CrpComm), C.POINTER(_V)]),
+    "crp_crpspmm_init_plan_only": (None, [_I, _I, _I, _I, _I, c_int_p, c_int_p] + [_I] * 8 +
+                                   [C.POINTER(CrpComm), C.POINTER(_V)]),
+    "crp_crpspmm_exec": (None, [_V, c_int_p, c_int_p, c_dbl_p, _V, _I, _V, _I]),
+    "crp_crpspmm_free": (None, [C.POINTER(_V)]),
+    "crp_crpspmm_print_stat": (None, [_V]),
+    "crp_crpspmm_clear_stat": (None, [_V]),
+    "crp_crpspmm_get_view": (None, [_V, C.POINTER(CrpspmmView)]),
+    "crp_crpspmm_plan_grid": (None, [_I, _I, _I, _I, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p]),
     # dev_type.h
     "is_dev_type_valid": (_I, [_I]),
     "dev_type_malloc": (_V, [C.c_size_t, _I]),

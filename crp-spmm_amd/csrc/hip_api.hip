@@ -17,7 +17,7 @@ struct PanelDev
     bool      built = false;
     int       R = 0, npanel = 0;
     int      *pptr = nullptr, *pcol = nullptr, *porder = nullptr;
-    uint32_t *pmask4 = nullptr;
+    uint32_t *pmask4 = nullptr, *pmap = nullptr;
     double   *pval = nullptr;
     double    fill = 0.0;
     long long entries = 0;
@@ -61,6 +61,9 @@ static int ensure_panel(crp_csr_dev *A, int idx)
     if (e == hipSuccess) e = hipMalloc((void **) &d.pcol, sizeof(int) * (h.pcol.size() + 64));
     if (e == hipSuccess) e = hipMalloc((void **) &d.pmask4, sizeof(uint32_t) * (h.pmask4.size() + 16));
     if (e == hipSuccess) e = hipMalloc((void **) &d.pval, sizeof(double) * (h.pval.size() + 512));
+    if (e == hipSuccess) e = hipMalloc((void **) &d.pmap, sizeof(uint32_t) * (h.pmap.size() + 1));
+    if (e == hipSuccess && !h.pmap.empty())
+        e = hipMemcpy(d.pmap, h.pmap.data(), sizeof(uint32_t) * h.pmap.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc((void **) &d.porder, sizeof(int) * (h.porder.size() + 1));
     if (e == hipSuccess && !h.porder.empty())
         e = hipMemcpy(d.porder, h.porder.data(), sizeof(int) * h.porder.size(), hipMemcpyHostToDevice);
@@ -307,6 +310,7 @@ int crp_csr_dev_destroy(crp_csr_dev_p *A_)
         if (A->pan[i].porder) (void) hipFree(A->pan[i].porder);
         if (A->pan[i].pcol) (void) hipFree(A->pan[i].pcol);
         if (A->pan[i].pmask4) (void) hipFree(A->pan[i].pmask4);
+        if (A->pan[i].pmap) (void) hipFree(A->pan[i].pmap);
         if (A->pan[i].pval) (void) hipFree(A->pan[i].pval);
     }
     if (A->rowptr) (void) hipFree(A->rowptr);
@@ -314,6 +318,21 @@ int crp_csr_dev_destroy(crp_csr_dev_p *A_)
     if (A->val) (void) hipFree(A->val);
     delete A;
     *A_ = NULL;
+    return 0;
+}
+
+int crp_csr_dev_update_values(crp_csr_dev_p A, const double *val, void *stream)
+{
+    if (A == NULL || (val == NULL && A->nnz > 0)) return -1;
+    if (A->nnz == 0) return 0;
+    int is_dev = 0;
+    crp_dev_ptr_is_device(val, &is_dev);
+    CRP_TRY(hipMemcpyAsync(A->val, val, sizeof(double) * (size_t) A->nnz, is_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                           (hipStream_t) stream));
+    if (!is_dev) memcpy(A->h_val.data(), val, sizeof(double) * (size_t) A->nnz);   // formats built later see the new values
+    for (int i = 0; i < 2; i++)
+        if (A->pan[i].built)
+            CRP_TRY(crp::scatter_vals_f64(A->nnz, A->pan[i].pmap, A->val, A->pan[i].pval, (hipStream_t) stream));
     return 0;
 }
 

@@ -45,6 +45,7 @@ hipError_t gather_rows_f64(int layout, int nidx, int n, const int *ridx, const d
                            double *dst, int64_t ldd, hipStream_t s);
 hipError_t scatter_rows_f64(int layout, int nidx, int n, const int *ridx, const double *src, int64_t lds,
                             double *dst, int64_t ldd, hipStream_t s);
+hipError_t scatter_vals_f64(int64_t n, const uint32_t *map, const double *src, double *dst, hipStream_t s);
 hipError_t transpose_f64(int nrow, int ncol, const double *src, int64_t lds, double *dst, int64_t ldd,
                          hipStream_t s);
 

@@ -18,6 +18,7 @@
 #include "crpspmm_hip.h"
 #include "mat_redist.h"
 #include "para2d_spmm.h"
+#include "crpspmm.h"
 #include "rowpara_spmm.h"
 #include "utils.h"
 
@@ -244,9 +245,98 @@ struct P2dGlue
     crp_comm_t       *comm = nullptr;
 };
 
+struct CeGlue
+{
+    crp_crpspmm_p eng = nullptr;
+    crp_comm_t   *comm = nullptr;
+};
+
+void ce_sync_public(crpspmm_engine_p s)
+{
+    CeGlue *g = (CeGlue *) s->impl;
+    crp_crpspmm_view_t v;
+    crp_crpspmm_get_view(g->eng, &v);
+    s->np_glb = v.np_glb; s->rank_glb = v.rank_glb; s->np_row = v.np_row; s->np_col = v.np_col;
+    s->rank_row = v.rank_row; s->rank_col = v.rank_col; s->glb_m = v.glb_m; s->glb_n = v.glb_n; s->glb_k = v.glb_k;
+    s->loc_A_srow = v.loc_A_srow; s->loc_A_erow = v.loc_A_erow; s->loc_A_nrow = v.loc_A_nrow;
+    s->loc_A_nnz = v.loc_A_nnz; s->loc_A_nnz_s = v.loc_A_nnz_s;
+    s->rd_B_srow = v.rd_B_srow; s->rd_B_erow = v.rd_B_erow;
+    s->loc_B_srow = v.loc_B_srow; s->loc_B_erow = v.loc_B_erow; s->loc_B_nrow = v.loc_B_nrow;
+    s->loc_B_scol = v.loc_B_scol; s->loc_B_ecol = v.loc_B_ecol; s->loc_B_ncol = v.loc_B_ncol;
+    s->loc_A_rowptr = (int *) v.loc_A_rowptr; s->loc_A_colidx = (int *) v.loc_A_colidx;
+    s->loc_A_val = (double *) v.loc_A_val; s->red_B = (double *) v.red_B; s->loc_C = (double *) v.loc_C;
+    s->n_exec = v.n_exec; s->t_init = v.t_init; s->t_exec = v.t_exec; s->t_rd_A = v.t_rd_A; s->t_agv_A = v.t_agv_A;
+    s->t_rd_B = v.t_rd_B; s->t_a2a_B = v.t_a2a_B; s->t_spmm = v.t_spmm; s->t_rd_C = v.t_rd_C; s->t_exec_nr = v.t_exec_nr;
+    s->nelem_A_rd = v.nelem_A_rd; s->nelem_A_agv = v.nelem_A_agv; s->nelem_B_rd = v.nelem_B_rd;
+    s->nelem_B_a2av = v.nelem_B_a2av; s->nelem_B_a2av_min = v.nelem_B_a2av_min;
+}
+
 }  // namespace
 
 extern "C" {
+
+void crpspmm_engine_init(const int m, const int n, const int k, const int src_A_srow, const int src_A_nrow,
+                         const int *src_A_rowptr, const int *src_A_colidx, const int src_B_srow, const int src_B_nrow,
+                         const int src_B_scol, const int src_B_ncol, const int dst_C_srow, const int dst_C_nrow,
+                         const int dst_C_scol, const int dst_C_ncol, MPI_Comm comm, int use_CUDA,
+                         crpspmm_engine_p *engine_, size_t *workbuf_bytes)
+{
+    select_device_once();
+    crpspmm_engine_p s = (crpspmm_engine_p) calloc(1, sizeof(crpspmm_engine_s));
+    CeGlue *g = new CeGlue;
+    g->comm = wrap(comm, false);
+    crp_crpspmm_init(m, n, k, src_A_srow, src_A_nrow, src_A_rowptr, src_A_colidx, src_B_srow, src_B_nrow, src_B_scol,
+                     src_B_ncol, dst_C_srow, dst_C_nrow, dst_C_scol, dst_C_ncol, g->comm, &g->eng);
+    s->impl = g;
+    s->comm_glb = comm;
+    s->comm_row = MPI_COMM_NULL;
+    s->comm_col = MPI_COMM_NULL;    // owned by the engine's communicator wrapper
+    s->use_CUDA = use_CUDA;
+    s->a2a_B_finegrain = 1;
+    s->alloc_workbuf = 1;
+    if (workbuf_bytes != NULL) *workbuf_bytes = 0;
+    ce_sync_public(s);
+    *engine_ = s;
+}
+
+void crpspmm_engine_attach_workbuf(crpspmm_engine_p engine, double *workbuf)
+{
+    (void) engine;
+    (void) workbuf;                 // the engine owns its buffers (see crpspmm.h)
+}
+
+void crpspmm_engine_exec(crpspmm_engine_p s, const int *src_A_rowptr, const int *src_A_colidx, const double *src_A_val,
+                         const double *src_B, const int ldB, double *dst_C, const int ldC)
+{
+    if (s == NULL) return;
+    crp_crpspmm_exec(((CeGlue *) s->impl)->eng, src_A_rowptr, src_A_colidx, src_A_val, src_B, ldB, dst_C, ldC);
+    ce_sync_public(s);
+}
+
+void crpspmm_engine_free(crpspmm_engine_p *engine_)
+{
+    if (engine_ == NULL || *engine_ == NULL) return;
+    crpspmm_engine_p s = *engine_;
+    CeGlue *g = (CeGlue *) s->impl;
+    crp_crpspmm_free(&g->eng);
+    if (g->comm) g->comm->free(g->comm);
+    delete g;
+    free(s);
+    *engine_ = NULL;
+}
+
+void crpspmm_engine_print_stat(crpspmm_engine_p s)
+{
+    if (s == NULL) return;
+    crp_crpspmm_print_stat(((CeGlue *) s->impl)->eng);
+}
+
+void crpspmm_engine_clear_stat(crpspmm_engine_p s)
+{
+    if (s == NULL) return;
+    crp_crpspmm_clear_stat(((CeGlue *) s->impl)->eng);
+    ce_sync_public(s);
+}
 
 void rp_spmm_init(const int A_srow, const int A_nrow, const int *A_rowptr, const int *A_colidx, const double *A_val,
                   const int *B_row_displs, const int glb_n, MPI_Comm comm, rp_spmm_p *rp_spmm)

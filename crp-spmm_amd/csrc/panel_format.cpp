@@ -123,6 +123,7 @@ void build_panels(int nrow, const int *rowptr, const int *colidx, const double *
     out->pcol.assign(total, 0);
     out->pmask4.assign(total / 4 + 2, 0u);
     out->pval.assign(total * (size_t) R, 0.0);
+    out->pmap.assign((size_t) rowptr[nrow], 0u);
     // pass 2: fill
     parallel_chunks(npanel, 512, [&](long long b, long long e, int) {
         std::vector<Trip> tmp;
@@ -136,7 +137,11 @@ void build_panels(int nrow, const int *rowptr, const int *colidx, const double *
                 // pmask4 words are private to a panel: panel starts are multiples of 4
                 out->pmask4[q >> 2] |= (mask & 0xFFu) << (8 * (q & 3));
                 for (int r = 0; r < R; r++)
-                    if (pos[r] >= 0) out->pval[q * (size_t) R + r] = val[pos[r]];
+                    if (pos[r] >= 0)
+                    {
+                        out->pval[q * (size_t) R + r] = val[pos[r]];
+                        out->pmap[(size_t) pos[r]] = (uint32_t) (q * (size_t) R + r);
+                    }
                 last_col = col;
                 q++;
             });

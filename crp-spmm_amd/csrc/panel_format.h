@@ -28,6 +28,7 @@ struct PanelHost
     std::vector<int>      pcol;    // entries: two-source column index
     std::vector<uint32_t> pmask4;  // entries / 4 words: byte u of word g = mask of entry 4g + u
     std::vector<double>   pval;    // entries * R, value of row r of entry q at q*R + r
+    std::vector<uint32_t> pmap;    // nnz: slot (q*R + r) in pval of CSR nonzero p (for value updates)
     std::vector<int>      porder;  // npanel: processing order of the panels (locality_order())
     long long real_entries = 0;    // entries before padding
     double fill() const;           // nnz / (real_entries * R)

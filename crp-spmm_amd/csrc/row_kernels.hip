@@ -139,4 +139,18 @@ hipError_t transpose_f64(int nrow, int ncol, const double *src, int64_t lds, dou
     return hipGetLastError();
 }
 
+// dst[map[i]] = src[i]: refresh the values of a derived sparse format from new CSR values
+__global__ __launch_bounds__(256) void scatter_vals_kernel(const int64_t n, const uint32_t *__restrict__ map,
+                                                           const double *__restrict__ src, double *__restrict__ dst)
+{
+    for (int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t) gridDim.x * 256) dst[map[i]] = src[i];
+}
+
+hipError_t scatter_vals_f64(int64_t n, const uint32_t *map, const double *src, double *dst, hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(scatter_vals_kernel, dim3(grid_for(n)), dim3(256), 0, s, n, map, src, dst);
+    return hipGetLastError();
+}
+
 }  // namespace crp

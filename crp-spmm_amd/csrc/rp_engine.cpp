@@ -467,6 +467,20 @@ void crp_rp_spmm_get_plan(crp_rp_spmm_p e, crp_rp_plan_view_t *v)
     v->t_spmm = e->t_spmm; v->t_exec = e->t_exec;
 }
 
+void crp_rp_spmm_update_values(crp_rp_spmm_p e, const double *A_val)
+{
+    if (e == NULL) return;
+    const size_t nnz = e->A_val.size();
+    if (nnz == 0) return;
+    ASSERT_PRINTF(A_val != NULL, "rp_spmm_update_values: NULL values\n");
+    memcpy(e->A_val.data(), A_val, sizeof(double) * nnz);
+    if (!e->plan_only)
+    {
+        HIP_OK(crp_csr_dev_update_values(e->A_dev, A_val, e->stream));
+        HIP_OK(crp_stream_sync(e->stream));
+    }
+}
+
 void crp_rp_spmm_set_timing(crp_rp_spmm_p e, int timing) { if (e) e->timing = timing ? 1 : 0; }
 void crp_rp_spmm_set_variant(crp_rp_spmm_p e, int variant) { if (e) e->variant = variant; }
 

@@ -109,6 +109,10 @@ class RpSpmm:
     def set_variant(self, variant):
         self._lib.crp_rp_spmm_set_variant(self.handle, int(variant))
 
+    def update_values(self, A_val):
+        va = _f64(A_val)
+        self._lib.crp_rp_spmm_update_values(self.handle, _dp(va))
+
     def alg_bytes(self):
         return int(self._lib.crp_rp_spmm_alg_bytes(self.handle))
 
@@ -248,6 +252,66 @@ class MatRedist:
     def free(self):
         if getattr(self, "handle", None) is not None and self.handle:
             self._lib.crp_mat_redist_free(C.byref(self.handle))
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class CrpspmmEngine:
+    """The older all-in-one engine, arguments as crpspmm_engine_init / _exec
+    (/root/reference/deprecated/src/crpspmm.h:89-122) with the communicator in place of MPI_Comm:
+    A in any 1D row distribution (src_A_rowptr holds GLOBAL nonzero offsets), B and C in arbitrary
+    2D blocks, all host (numpy) arrays, A's values passed on every exec."""
+
+    def __init__(self, m, n, k, src_A_srow, src_A_nrow, src_A_rowptr, src_A_colidx, src_B_srow, src_B_nrow, src_B_scol,
+                 src_B_ncol, dst_C_srow, dst_C_nrow, dst_C_scol, dst_C_ncol, comm, plan_only=False):
+        lib = L.load()
+        self._lib, self.comm = lib, comm
+        self.handle = C.c_void_p()
+        self._rowptr, self._colidx = _i32(src_A_rowptr), _i32(src_A_colidx)
+        if self._colidx.size == 0:
+            self._colidx = np.zeros(1, np.int32)
+        fn = lib.crp_crpspmm_init_plan_only if plan_only else lib.crp_crpspmm_init
+        fn(m, n, k, src_A_srow, src_A_nrow, _ip(self._rowptr), _ip(self._colidx), src_B_srow, src_B_nrow, src_B_scol,
+           src_B_ncol, dst_C_srow, dst_C_nrow, dst_C_scol, dst_C_ncol, comm.ptr, C.byref(self.handle))
+        self.dst_shape = (dst_C_nrow, dst_C_ncol)
+
+    def exec(self, src_A_val, src_B, dst_C):
+        """src_B / dst_C: 2-D row-major float64 numpy arrays (the caller's blocks)."""
+        val = _f64(src_A_val)
+        if val.size == 0:
+            val = np.zeros(1, np.float64)
+        bp, ldb, _a = _ptr_ld_any(src_B)
+        cp, ldc, _b = _ptr_ld_any(dst_C)
+        self._lib.crp_crpspmm_exec(self.handle, _ip(self._rowptr), _ip(self._colidx), _dp(val), bp, ldb, cp, ldc)
+
+    def view(self):
+        v = L.CrpspmmView()
+        self._lib.crp_crpspmm_get_view(self.handle, C.byref(v))
+        d = {k: getattr(v, k) for k, _t in L.CrpspmmView._fields_ if not k.startswith(("loc_A_rowptr", "loc_A_colidx",
+                                                                                     "loc_A_val", "red_B", "loc_C"))}
+
+        def arr(p, n):
+            return np.ctypeslib.as_array(p, (n,)).copy() if n > 0 else np.zeros(0)
+        d["loc_A_rowptr"] = arr(v.loc_A_rowptr, v.loc_A_nrow + 1)
+        d["loc_A_colidx"] = arr(v.loc_A_colidx, v.loc_A_nnz)
+        d["loc_A_val"] = arr(v.loc_A_val, v.loc_A_nnz)
+        d["red_B"] = arr(v.red_B, (v.rd_B_erow - v.rd_B_srow) * v.loc_B_ncol).reshape(v.rd_B_erow - v.rd_B_srow, v.loc_B_ncol)
+        return d
+
+    def print_stat(self):
+        self._lib.crp_crpspmm_print_stat(self.handle)
+
+    def clear_stat(self):
+        self._lib.crp_crpspmm_clear_stat(self.handle)
+
+    def free(self):
+        if getattr(self, "handle", None) is not None and self.handle:
+            self._lib.crp_crpspmm_free(C.byref(self.handle))
         self.handle = None
 
     def __del__(self):

@@ -65,3 +65,18 @@ def calc_spmm_part2d_from_1d(nproc, m, n, k, rb_displs0, rowptr, colidx, rA=1, d
     return dict(pm=pm.value, pn=pn.value, comm_cost=int(cost.value), A0_rowptr=_take(a0, nproc + 1),
                 B_rowptr=_take(br, pm.value + 1), AC_rowptr=_take(ac, pm.value + 1),
                 BC_colptr=_take(bc, pn.value + 1))
+
+
+def crpspmm_plan_grid(nproc, m, n, k, rowptr, colidx):
+    """Grid rule of the older all-in-one engine (/root/reference/deprecated/src/crpspmm.c:136-195):
+    returns (np_row, np_col, m_split_idx).  rowptr / colidx: the global CSR pattern."""
+    lib = L.load()
+    rowptr, colidx = _i32(rowptr), _i32(colidx)
+    cse = np.zeros(2 * max(m, 1), np.int32)
+    for i in range(m):
+        s, e = rowptr[i], rowptr[i + 1]
+        cse[2 * i], cse[2 * i + 1] = (colidx[s:e].min(), colidx[s:e].max()) if e > s else (1, 0)
+    pr, pc = C.c_int(), C.c_int()
+    idx = np.zeros(nproc + 1, np.int32)
+    lib.crp_crpspmm_plan_grid(nproc, m, n, k, _ip(rowptr), _ip(cse), C.byref(pr), C.byref(pc), _ip(idx))
+    return pr.value, pc.value, idx[:pr.value + 1].copy()

@@ -94,6 +94,9 @@ void crp_rp_spmm_set_variant(crp_rp_spmm_p rp_spmm, int variant);
  * this rank): 12*nnz + 4*(A_nrow+1) + 8*n*(distinct B rows) + 8*n*A_nrow. */
 long long crp_rp_spmm_alg_bytes(crp_rp_spmm_p rp_spmm);
 long long crp_rp_spmm_nnz(crp_rp_spmm_p rp_spmm);
+/* New values for the same sparsity pattern, in the order of the A_val given to init (the
+ * deprecated crpspmm_engine passes A's values on every exec: deprecated/src/crpspmm.h:108-117). */
+void crp_rp_spmm_update_values(crp_rp_spmm_p rp_spmm, const double *A_val);
 
 /* See para2d_spmm_init (src/para2d_spmm.h:22-47). Rank r sits at grid position
  * (r / pn, r % pn); A_rowptr/A_colidx/A_val is the rank's A0 slice. */
@@ -141,6 +144,51 @@ void crp_mat_redist_attach_workbuf(crp_mat_redist_p engine, void *workbuf_h, voi
 void crp_mat_redist_exec(crp_mat_redist_p engine, const void *src_blk, int src_ld, void *dst_blk, int dst_ld);
 void crp_mat_redist_free(crp_mat_redist_p *engine);
 void crp_mat_redist_get_view(crp_mat_redist_p engine, crp_mat_redist_view_t *view);
+
+/* ---- compatibility engine: the older all-in-one API (deprecated/src/crpspmm.h:89-130) ----------
+ * A arrives in any 1D row distribution, B and C in arbitrary 2D blocks, all on the HOST, and A's
+ * values are passed on every exec.  init plans the np_row x np_col grid with the deprecated
+ * engine's own rule (per prime factor of P, largest first, split M or N by comparing
+ * 1.5*nnz*n_split(*p) + k*n-style upper bounds built from per-row column RANGES,
+ * deprecated/src/crpspmm.c:136-195), redistributes A's pattern to row panels, B to an even
+ * (k / np_row) x (n / np_col) layout and C back to the caller's layout with crp_mat_redist, and
+ * runs the 1D row-parallel device engine inside every grid column.  Same statistics lines as
+ * crpspmm_engine_print_stat (deprecated/src/crpspmm.c:715-772). */
+typedef struct crp_crpspmm *crp_crpspmm_p;
+typedef struct crp_crpspmm_view
+{
+    int np_glb, rank_glb, np_row, np_col, rank_row, rank_col, glb_m, glb_n, glb_k;
+    int loc_A_srow, loc_A_erow, loc_A_nrow, loc_A_nnz, loc_A_nnz_s;
+    int rd_B_srow, rd_B_erow, loc_B_scol, loc_B_ecol, loc_B_ncol;
+    int loc_B_srow, loc_B_erow, loc_B_nrow;   /* hull and count of the B rows the panel touches */
+    const int *loc_A_rowptr, *loc_A_colidx;   /* panel CSR on the host (rowptr rebased to 0) */
+    const double *loc_A_val, *red_B, *loc_C;
+    int n_exec;
+    double t_init, t_exec, t_rd_A, t_agv_A, t_rd_B, t_a2a_B, t_spmm, t_rd_C, t_exec_nr;
+    size_t nelem_A_rd, nelem_A_agv, nelem_B_rd, nelem_B_a2av, nelem_B_a2av_min;
+} crp_crpspmm_view_t;
+void crp_crpspmm_init(int m, int n, int k, int src_A_srow, int src_A_nrow, const int *src_A_rowptr,
+                      const int *src_A_colidx, int src_B_srow, int src_B_nrow, int src_B_scol, int src_B_ncol,
+                      int dst_C_srow, int dst_C_nrow, int dst_C_scol, int dst_C_ncol, crp_comm_t *comm,
+                      crp_crpspmm_p *engine);
+/* host planning and redistribution only (no device state): exec stops after A's values and B
+ * have reached the internal layout (inspect them through the view); used by the CPU tests */
+void crp_crpspmm_init_plan_only(int m, int n, int k, int src_A_srow, int src_A_nrow, const int *src_A_rowptr,
+                                const int *src_A_colidx, int src_B_srow, int src_B_nrow, int src_B_scol,
+                                int src_B_ncol, int dst_C_srow, int dst_C_nrow, int dst_C_scol, int dst_C_ncol,
+                                crp_comm_t *comm, crp_crpspmm_p *engine);
+void crp_crpspmm_exec(crp_crpspmm_p engine, const int *src_A_rowptr, const int *src_A_colidx,
+                      const double *src_A_val, const double *src_B, int ldB, double *dst_C, int ldC);
+void crp_crpspmm_free(crp_crpspmm_p *engine);
+void crp_crpspmm_print_stat(crp_crpspmm_p engine);
+void crp_crpspmm_clear_stat(crp_crpspmm_p engine);
+void crp_crpspmm_get_view(crp_crpspmm_p engine, crp_crpspmm_view_t *view);
+/* the deprecated engine's grid rule alone (host, no communication): A_rowptr_glb has m + 1
+ * entries, cidx_se holds (first, last) column of every row (2*m ints; an empty row holds any
+ * pair with first > last and is ignored).  m_split_idx receives np_row + 1 row offsets
+ * (room for P + 1). */
+void crp_crpspmm_plan_grid(int P, int m, int n, int k, const int *A_rowptr_glb, const int *cidx_se,
+                           int *np_row, int *np_col, int *m_split_idx);
 
 /* ---- host-only pieces exposed for tests (no GPU needed) -------------------
  * Build only the exchange plan (everything rp_spmm_init computes on the host,

@@ -80,6 +80,9 @@ int crp_event_elapsed_ms(void *start, void *stop, float *ms);
 int crp_csr_dev_create(int nrow, int ncol, const int *rowptr, const int *colidx,
                        const double *val, crp_csr_dev_p *out);
 int crp_csr_dev_destroy(crp_csr_dev_p *A);
+/* New values for the same sparsity pattern (val in the order given at create; host or device
+ * pointer): refreshes the CSR copy and every derived format on `stream`. */
+int crp_csr_dev_update_values(crp_csr_dev_p A, const double *val, void *stream);
 int crp_csr_dev_nrow(crp_csr_dev_p A);
 long long crp_csr_dev_nnz(crp_csr_dev_p A);
 /* bytes of HBM the kernel must touch for A itself: 12*nnz + 4*(nrow+1). */

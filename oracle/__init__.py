@@ -408,3 +408,47 @@ def rp_exec_all(plans, B_parts, n):
             rB[dst] = np.asarray(B_parts[me], dtype=np.float64)[src, :n]
         out.append(spmm_csr(d["A_rowptr"], d["A_colidx"], d["A_val"], rB, n=n))
     return out
+
+
+def crpspmm_plan_grid(P, m, n, k, rowptr, colidx):
+    """The deprecated all-in-one engine's grid rule, restated in plain Python
+    (/root/reference/deprecated/src/crpspmm.c:104-195): per row the (first, last) column, then per
+    prime factor of P (largest first) split M or N by comparing
+        split N: floor(nnz * n_split * 1.5) * p + current B volume   (SIZE_MAX when n_split*p > n)
+        split M: floor(nnz * n_split * 1.5) + sum over candidate panels of (hull width) * n
+    Returns (np_row, np_col, m_split_idx[:np_row + 1]).  Parity unpinned by reference OUTPUT (the
+    deprecated engine needs mkl.h / MPI to build); the restatement follows the source line by line
+    and assumes what that code assumes: sorted column indices, no empty rows, panels that
+    start before row m."""
+    rowptr = np.asarray(rowptr, np.int64)
+    colidx = np.asarray(colidx, np.int64)
+    first = colidx[rowptr[:-1]]              # crpspmm.c:110-115
+    last = colidx[rowptr[1:] - 1]
+    SIZE_MAX = 2 ** 64 - 1
+    m_split, n_split = 1, 1
+    idx = [0, m]
+    copy_B = k * n
+    nnz = int(rowptr[m])
+    for p in reversed(prime_factorization(P)):
+        a1 = int(float(nnz) * float(n_split) * 1.5)
+        cost_n = a1 * p + copy_B
+        if n_split * p > n:
+            cost_n = SIZE_MAX
+        ms = m_split * p
+        idx2, srow, copy_B2 = [0], 0, 0
+        for j in range(ms):
+            target = nnz if j == ms - 1 else nnz // ms * (j + 1)
+            erow = srow + 1
+            lo, hi = int(first[srow]), int(last[srow])
+            while rowptr[erow] < target:
+                lo, hi = min(lo, int(first[erow])), max(hi, int(last[erow]))
+                erow += 1
+            copy_B2 += (hi - lo + 1) * n
+            idx2.append(erow)
+            srow = erow
+        cost_m = a1 + copy_B2
+        if cost_m < cost_n:
+            m_split, copy_B, idx = ms, copy_B2, idx2
+        else:
+            n_split *= p
+    return m_split, n_split, np.asarray(idx[:m_split + 1], np.int32)

@@ -78,6 +78,56 @@ def check_mat_redist(world, orc):
         pass
 
 
+def check_crpspmm_engine(world, orc):
+    """crp_crpspmm_* (plan-only: no device) over gloo: grid against the oracle's restatement of the
+    deprecated rule, A's pattern / values and B after the redistribution against direct slices of
+    the global operands (protocol of deprecated/examples/test_crpspmm.c:45-124)."""
+    from crp_spmm_amd import engine, gen, planner
+    P, me = world.nproc, world.rank
+    for (m, n, offs) in ((900, 24, (1, 2, 3, 30)), (700, 4, (1, 5, 300)), (400, 512, (1, 2)), (400, 512, (1, 199))):
+        k = m
+        rp, ci, va = gen.banded_fem(m, offsets=offs, seed=3)
+        B = orc.fill_B(0, k, 0, n)
+        rb = planner.csr_mat_row_partition(rp, P)
+        a_rp, a_ci, a_va = slices(rp, ci, va, rb, me)
+        a_rp_glb = np.ascontiguousarray(a_rp, dtype=np.int32)    # global nonzero offsets, as the old API wants
+        # B and C blocks of the caller: a balanced 2D grid like MPI_Dims_create would pick
+        gr = max(d for d in range(1, int(P ** 0.5) + 1) if P % d == 0)
+        gr, gc = P // gr, gr
+        rr, rc = me // gc, me % gc
+        bs, bn = planner.calc_block_spos_size(k, gr, rr)
+        cs, cn = planner.calc_block_spos_size(n, gc, rc)
+        ms, mn = planner.calc_block_spos_size(m, gr, rr)
+        e = engine.CrpspmmEngine(m, n, k, int(rb[me]), int(rb[me + 1] - rb[me]), a_rp_glb, a_ci, bs, bn, cs, cn,
+                                 ms, mn, cs, cn, world, plan_only=True)
+        v = e.view()
+        o_pr, o_pc, o_idx = orc.crpspmm_plan_grid(P, m, n, k, rp, ci)
+        o_idx = o_idx.copy()
+        o_idx[-1] = m
+        assert (v["np_row"], v["np_col"]) == (o_pr, o_pc), (me, v["np_row"], v["np_col"], o_pr, o_pc)
+        pr_i, pc_i = me // o_pc, me % o_pc
+        assert (v["rank_row"], v["rank_col"]) == (pr_i, pc_i)
+        s_row, e_row = int(o_idx[pr_i]), int(o_idx[pr_i + 1])
+        assert (v["loc_A_srow"], v["loc_A_erow"]) == (s_row, e_row)
+        assert np.array_equal(v["loc_A_rowptr"], rp[s_row:e_row + 1] - rp[s_row])
+        assert np.array_equal(v["loc_A_colidx"], ci[rp[s_row]:rp[e_row]])
+        Bsrc = np.ascontiguousarray(B[bs:bs + bn, cs:cs + cn])
+        if Bsrc.size == 0:
+            Bsrc = np.zeros((max(bn, 1), max(cn, 1)))
+        Cdst = np.zeros((max(mn, 1), max(cn, 1)))
+        e.exec(a_va, Bsrc, Cdst)
+        v = e.view()
+        assert np.array_equal(v["loc_A_val"], va[rp[s_row]:rp[e_row]])
+        ks, kn = planner.calc_block_spos_size(k, o_pr, pr_i)
+        ns, nn = planner.calc_block_spos_size(n, o_pc, pc_i)
+        assert (v["rd_B_srow"], v["rd_B_erow"], v["loc_B_scol"], v["loc_B_ncol"]) == (ks, ks + kn, ns, nn)
+        assert np.array_equal(v["red_B"], B[ks:ks + kn, ns:ns + nn])
+        hull = ci[rp[s_row]:rp[e_row]]
+        assert v["loc_B_nrow"] == np.unique(hull).size and v["loc_B_srow"] == hull.min() and v["loc_B_erow"] == hull.max() + 1
+        e.print_stat()
+        e.free()
+
+
 def main():
     import torch.distributed as dist
     import oracle as orc
@@ -144,6 +194,8 @@ def main():
         dist.barrier()
     dist.barrier()
     check_mat_redist(world, orc)
+    dist.barrier()
+    check_crpspmm_engine(world, orc)
     dist.barrier()
     if me == 0:
         print("DIST_WORKER_OK world=%d" % P)

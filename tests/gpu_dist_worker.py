@@ -86,6 +86,28 @@ def main():
             assert (got[:r[6], r[7]:] == -1).all()
             e.free()
     dist.barrier()
+    # ---- the older all-in-one engine: A in nnz-balanced row blocks, B / C on a P x 1 or 1 x P grid
+    #      of the CALLER's choosing, C gathered whole on rank 0 in the second pass
+    for (mm, nn, offs) in ((3000, 24, (1, 2, 3, 30)), (1200, 512, (1, 599))):
+        rp2, ci2, va2 = gen.banded_fem(mm, offsets=offs, seed=2)
+        B2 = orc.fill_B(0, mm, 0, nn)
+        C2 = orc.spmm_csr(rp2, ci2, va2, B2)
+        rb2 = planner.csr_mat_row_partition(rp2, P)
+        s, e = int(rb2[me]), int(rb2[me + 1])
+        for gather in (False, True):
+            bs, bn = planner.calc_block_spos_size(mm, P, me)            # B: row blocks
+            cs, cn = planner.calc_block_spos_size(nn, P, me)            # C: column blocks
+            dst = (0, mm if me == 0 else 0, 0, nn if me == 0 else 0) if gather else (0, mm, cs, cn)
+            ce = engine.CrpspmmEngine(mm, nn, mm, s, e - s, rp2[s:e + 1], ci2[rp2[s]:rp2[e]], bs, bn, 0, nn, *dst, world)
+            Cout = np.full((max(dst[1], 1), max(dst[3], 1)), np.nan)
+            for trial in range(2):
+                ce.exec(va2[rp2[s]:rp2[e]] * (trial + 1), np.ascontiguousarray(B2[bs:bs + bn]), Cout)
+                want = C2[dst[0]:dst[0] + dst[1], dst[2]:dst[2] + dst[3]] * (trial + 1)
+                if want.size:
+                    assert orc.rel_fro_err(want, Cout[:dst[1], :dst[3]]) <= 1e-12, (me, mm, nn, gather, trial)
+            ce.print_stat()
+            ce.free()
+            dist.barrier()
     if me == 0:
         print("GPU_DIST_WORKER_OK world=%d" % P)
     dist.destroy_process_group()

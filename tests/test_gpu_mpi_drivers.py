@@ -16,14 +16,14 @@ pytestmark = pytest.mark.gpu
 MPIEXEC = shutil.which("mpiexec") or "/opt/conda/bin/mpiexec"
 
 
-def _run(exe, np_, mtx, n, extra_env=None):
+def _run(exe, np_, mtx, n, extra_env=None, tail=("2", "0", "1")):
     path = os.path.join(ROOT, "examples", exe)
     if not os.path.exists(path) or not os.path.exists(MPIEXEC):
         pytest.skip("no MPI launcher / example drivers not built on this machine")
     env = dict(os.environ, OMP_NUM_THREADS="1")
     env["PATH"] = os.path.dirname(MPIEXEC) + ":" + env["PATH"]
     env.update(extra_env or {})
-    r = subprocess.run([MPIEXEC, "-np", str(np_), path, os.path.join(GOLDEN, mtx), str(n), "2", "0", "1"],
+    r = subprocess.run([MPIEXEC, "-np", str(np_), path, os.path.join(GOLDEN, mtx), str(n), *tail],
                        capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     m = re.search(r"\|\|C_ref - C\|\|_f / \|\|C_ref\|\|_f = ([0-9.eE+-]+)", r.stdout)
@@ -50,3 +50,13 @@ def test_para2d_spmm_driver(np_):
 def test_rp_spmm_driver_env_knobs():
     out = _run("test_rp_spmm.exe", 2, "g_symm.mtx", 16, {"RP_SPMM_P2P": "0", "RP_SPMM_REIDX": "0"})
     assert "Overriding parameter rB_reidx: 1 (default) --> 0 (runtime)" in out
+
+
+@pytest.mark.parametrize("np_", [1, 2, 4])
+def test_crpspmm_engine_driver(np_):
+    """the older all-in-one API (deprecated/examples/test_crpspmm.c): <ntest> <check> <use-CUDA>"""
+    out = _run("test_crpspmm.exe", np_, "g_symm.mtx", 48, tail=("2", "1", "1"))
+    assert "CRP-SpMM 2D partition:" in out and "Redist C to user's 2D layout" in out
+    assert "Alltoallv B necessary" in out
+    out = _run("test_crpspmm.exe", np_, "g_gen.mtx", 5, tail=("1", "1"))      # non-square A, narrow B
+    assert "SpMM total (avg of   1 runs)" in out

@@ -211,6 +211,53 @@ def test_rp_engine_single_rank(crp, orc, gpu, layout, where):
     sc.free()
 
 
+def test_engine_update_values(crp, orc, gpu):
+    """New values on the same pattern (the deprecated engine's calling convention) refresh the CSR
+    and the derived row-panel format."""
+    import torch
+    from crp_spmm_amd import comm, engine, gen
+    m = k = 2000
+    rp, ci, va = gen.banded_fem(m, offsets=(1, 2, 3, 40), seed=6)
+    n = 128
+    B = orc.fill_B(0, k, 0, n)
+    sc = comm.SelfComm()
+    e = engine.RpSpmm(0, m, rp, ci, np.zeros_like(va), [0, k], n, sc)
+    Bd, Cd = _t(B, gpu), torch.empty((m, n), dtype=torch.float64, device=gpu)
+    for trial in range(2):
+        v2 = va * (trial + 1) + trial
+        e.update_values(v2)
+        for variant in (1, 2, 3):
+            e.set_variant(variant)
+            e.exec(0, Bd, Cd)
+            torch.cuda.synchronize()
+            assert orc.rel_fro_err(orc.spmm_csr(rp, ci, v2, B), Cd.cpu().numpy()) <= FP64_TOL, (trial, variant)
+    e.free()
+    sc.free()
+
+
+def test_crpspmm_engine_single_rank(crp, orc, gpu):
+    """The older all-in-one API at one rank: host operands in, host C out, values passed per exec
+    (deprecated/src/crpspmm.h:89-122); C through a padded leading dimension."""
+    from crp_spmm_amd import comm, engine, gen
+    m, k, n = 1300, 1700, 40
+    rp, ci, va = gen.random_csr(m, k, 18, seed=12)
+    B = orc.fill_B(0, k, 0, n)
+    sc = comm.SelfComm()
+    e = engine.CrpspmmEngine(m, n, k, 0, m, rp, ci, 0, k, 0, n, 0, m, 0, n, sc)
+    v = e.view()
+    assert (v["np_row"], v["np_col"], v["loc_A_nrow"], v["loc_B_ncol"]) == (1, 1, m, n)
+    Cpad = np.full((m, n + 3), -7.0)
+    for trial in range(2):
+        v2 = va * (1.0 + trial)
+        e.exec(v2, B, Cpad[:, :n])
+        assert orc.rel_fro_err(orc.spmm_csr(rp, ci, v2, B), Cpad[:, :n]) <= FP64_TOL, trial
+        assert (Cpad[:, n:] == -7.0).all()
+    assert e.view()["n_exec"] == 2
+    e.print_stat()
+    e.free()
+    sc.free()
+
+
 def test_para2d_engine_single_rank_no_deadlock(crp, orc, gpu):
     """para2d at one rank (the reference self-sends and hangs: src/para2d_spmm.c:102-109)."""
     import torch

@@ -43,7 +43,8 @@ def test_library_exports_every_declared_symbol(crp):
 
 def test_mpi_facade_exports_reference_api(crp):
     """libcrpspmm.so (built when mpi.h is present) exports the reference's exact entry points
-    (src/rowpara_spmm.h:60-87, src/para2d_spmm.h:42-75, src/mat_redist.h:69-100)."""
+    (src/rowpara_spmm.h:60-87, src/para2d_spmm.h:42-75, src/mat_redist.h:69-100,
+    deprecated/src/crpspmm.h:89-130)."""
     from crp_spmm_amd import _lib
     path = os.path.join(os.path.dirname(_lib.LIB_PATH), "libcrpspmm.so")
     if not os.path.exists(path):
@@ -53,7 +54,10 @@ def test_mpi_facade_exports_reference_api(crp):
     for fn in ("rp_spmm_init", "rp_spmm_free", "rp_spmm_exec", "rp_spmm_print_stat", "rp_spmm_clear_stat",
                "para2d_spmm_init", "para2d_spmm_free", "para2d_spmm_exec", "para2d_spmm_print_stat",
                "para2d_spmm_clear_stat", "mat_redist_engine_init", "mat_redist_engine_attach_workbuf",
-               "mat_redist_engine_exec", "mat_redist_engine_free"):
+               "mat_redist_engine_exec", "mat_redist_engine_free",
+               # deprecated/src/crpspmm.h:89-130
+               "crpspmm_engine_init", "crpspmm_engine_attach_workbuf", "crpspmm_engine_exec", "crpspmm_engine_free",
+               "crpspmm_engine_print_stat", "crpspmm_engine_clear_stat"):
         assert fn in exported, fn
 
 
@@ -302,3 +306,35 @@ def test_panel_locality_order(crp, monkeypatch):
     assert d_ord < 0.75 * d_nat, (d_ord, d_nat)    # (small mesh: BFS levels are wide; pwtk-size meshes gain far more)
     monkeypatch.setenv("CRPSPMM_PANEL_ORDER", "0")
     assert np.array_equal(hip.panel_format_host(rp, ci, va, 4)["porder"], np.arange(f["npanel"]))
+
+
+def test_crpspmm_grid_rule_matches_oracle(crp, orc):
+    """Grid rule of the older all-in-one engine (deprecated/src/crpspmm.c:136-195): library vs the
+    oracle's line-by-line restatement, on matrices that meet the reference's assumptions (sorted
+    indices, no empty rows); both M-, N- and mixed splits must occur."""
+    import scipy.sparse as sp
+    from crp_spmm_amd import planner
+    rng = np.random.default_rng(0)
+    kinds = set()
+    for trial in range(120):
+        m, k = int(rng.integers(20, 400)), int(rng.integers(20, 400))
+        if trial % 3 == 0:
+            A = sp.diags([1.0] * 5, [-2, -1, 0, 1, 2], shape=(m, m), format="csr")
+            k = m
+        else:
+            A = sp.random(m, k, rng.uniform(0.01, 0.2), format="csr", random_state=int(rng.integers(1 << 30)))
+            A = sp.csr_matrix(A + sp.csr_matrix((np.ones(m), (np.arange(m), np.arange(m) % k)), shape=(m, k)))
+        A.sort_indices()
+        P = int(rng.choice([1, 2, 3, 4, 6, 8, 12, 16, 7, 9, 30]))
+        n = int(rng.choice([1, 2, 8, 32, 256]))
+        try:
+            a = orc.crpspmm_plan_grid(P, m, n, k, A.indptr, A.indices)
+        except IndexError:
+            continue                      # a candidate panel starts at row m: the reference reads past its arrays
+        b = planner.crpspmm_plan_grid(P, m, n, k, A.indptr, A.indices)
+        assert (a[0], a[1]) == (b[0], b[1]), (trial, P, n, a, b)
+        ai = a[2].copy()
+        ai[-1] = m                        # the library closes the last panel at m (trailing empty rows)
+        assert np.array_equal(ai, b[2]), (trial, a, b)
+        kinds.add((a[0] > 1, a[1] > 1))
+    assert kinds == {(False, False), (True, False), (False, True), (True, True)}
