@@ -21,3 +21,15 @@ def test_engines_multi_rank_one_gpu(world):
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "GPU_DIST_WORKER_OK world=%d" % world in r.stdout
+
+
+def test_rccl_backend_single_rank():
+    """The real device transport (torch.distributed "nccl" == RCCL) at the one rank a 1-GPU box allows."""
+    env = dict(os.environ)
+    env.update(OMP_NUM_THREADS="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", LOCAL_WORLD_SIZE="1",
+               MASTER_ADDR="127.0.0.1", MASTER_PORT="29711", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("CRPSPMM_EXCHANGE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "gpu_nccl_worker.py")], capture_output=True, text=True,
+                       env=env, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "GPU_NCCL_WORKER_OK" in r.stdout
