@@ -9,7 +9,10 @@ One "step" = one C := A * B of the hot path (rp_spmm_exec / para2d_spmm_exec,
 N = 1 : BASELINE configs[1] -- pwtk (seeded stand-in, gen.banded_fem(217918): no
         SuiteSparse files and no network in the containers) x n = 256, fp64,
         1 MI355X, rp_spmm HIP kernel.
-N > 1 : the same matrix and n, 2D grid chosen by calc_spmm_part2d_from_1d, one
+N > 1 : the same matrix and n, 2D grid chosen by the planner for an A that is
+        multiplied (steps + warmup) times -- crp_spmm_part2d_amortized, the
+        reference's cost terms with its "rA = times A is reused" applied
+        consistently (--grid reference: the reference rule with rA = 1) --, one
         rank per GPU over torch.distributed (control plane gloo, B exchange
         nccl == RCCL); strong scaling (total work fixed).
 Prints ONE JSON line on rank 0.
@@ -87,6 +90,8 @@ def main():
     ap.add_argument("--n", type=int, default=256)
     ap.add_argument("--matrix", default="pwtk")
     ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--grid", default="amortized", choices=("amortized", "reference"),
+                    help="N > 1: planner rule for the process grid (see module docstring)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", type=int, default=1)
     ap.add_argument("--sweep-variants", action="store_true", help="also time kernel variants 1..3 (stderr)")
@@ -122,7 +127,10 @@ def main():
     # ---- partition (planner runs on every rank: deterministic, same answer everywhere)
     rb = planner.csr_mat_row_partition(rp, world)
     if distributed:
-        pl = planner.calc_spmm_part2d_from_1d(world, m, n, k, rb, rp, ci, rA=1)
+        if args.grid == "reference":
+            pl = planner.calc_spmm_part2d_from_1d(world, m, n, k, rb, rp, ci, rA=1)
+        else:
+            pl = planner.spmm_part2d_amortized(world, m, n, k, rb, rp, ci, max(1, args.steps + args.warmup))
         pm, pn = pl["pm"], pl["pn"]
         a0, br, ac, bc = pl["A0_rowptr"], pl["B_rowptr"], pl["AC_rowptr"], pl["BC_colptr"]
         s, e_ = int(a0[rank]), int(a0[rank + 1])

@@ -178,6 +178,9 @@ SIGNATURES = {
     "crp_crpspmm_print_stat": (None, [_V]),
     "crp_crpspmm_clear_stat": (None, [_V]),
     "crp_crpspmm_get_view": (None, [_V, C.POINTER(CrpspmmView)]),
+    "crp_spmm_part2d_amortized": (None, [_I, _I, _I, _I, c_int_p, c_int_p, c_int_p, _I, c_int_p, c_int_p, c_sz_p,
+                                         C.POINTER(c_int_p), C.POINTER(c_int_p), C.POINTER(c_int_p),
+                                         C.POINTER(c_int_p)]),
     "crp_crpspmm_plan_grid": (None, [_I, _I, _I, _I, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p]),
     # dev_type.h
     "is_dev_type_valid": (_I, [_I]),

@@ -67,6 +67,20 @@ def calc_spmm_part2d_from_1d(nproc, m, n, k, rb_displs0, rowptr, colidx, rA=1, d
                 BC_colptr=_take(bc, pn.value + 1))
 
 
+def spmm_part2d_amortized(nproc, m, n, k, rb_displs0, rowptr, colidx, rA):
+    """Grid for an A that is multiplied rA times (crp_spmm_part2d_amortized, include/crp_engine.h):
+    every pm x pn priced with the reference's own cost terms, rA applied consistently.
+    -> the same dict as calc_spmm_part2d_from_1d."""
+    rb, rowptr, colidx = _i32(rb_displs0), _i32(rowptr), _i32(colidx)
+    pm, pn, cost = C.c_int(), C.c_int(), C.c_size_t()
+    a0, br, ac, bc = L.c_int_p(), L.c_int_p(), L.c_int_p(), L.c_int_p()
+    L.load().crp_spmm_part2d_amortized(nproc, m, n, k, _ip(rb), _ip(rowptr), _ip(colidx), rA, C.byref(pm),
+                                       C.byref(pn), C.byref(cost), C.byref(a0), C.byref(br), C.byref(ac), C.byref(bc))
+    return dict(pm=pm.value, pn=pn.value, comm_cost=int(cost.value), A0_rowptr=_take(a0, nproc + 1),
+                B_rowptr=_take(br, pm.value + 1), AC_rowptr=_take(ac, pm.value + 1),
+                BC_colptr=_take(bc, pn.value + 1))
+
+
 def crpspmm_plan_grid(nproc, m, n, k, rowptr, colidx):
     """Grid rule of the older all-in-one engine (/root/reference/deprecated/src/crpspmm.c:136-195):
     returns (np_row, np_col, m_split_idx).  rowptr / colidx: the global CSR pattern."""

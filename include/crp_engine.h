@@ -190,6 +190,15 @@ void crp_crpspmm_get_view(crp_crpspmm_p engine, crp_crpspmm_view_t *view);
 void crp_crpspmm_plan_grid(int P, int m, int n, int k, const int *A_rowptr_glb, const int *cidx_se,
                            int *np_row, int *np_col, int *m_split_idx);
 
+/* ---- planner extension: grid for an A that is reused rA times ------------------------------------
+ * Same arguments and output arrays as calc_spmm_part2d_from_1d (spmat_part.h; src/spmat_part.h:55-76)
+ * without dbg_print.  Prices EVERY pm x pn with pn | nproc as floor(1.5 nnz (pn-1)) [replicate A once]
+ * + rA * n * (B rows exchanged per multiply) and returns the cheapest; the reference rule leaves rA
+ * out of its 1D starting cost and searches greedily, so there rA > 1 favours 1D.  Host only. */
+void crp_spmm_part2d_amortized(int nproc, int m, int n, int k, const int *rb_displs0, const int *rowptr,
+                               const int *colidx, int rA, int *pm, int *pn, size_t *comm_cost, int **A0_rowptr,
+                               int **B_rowptr, int **AC_rowptr, int **BC_colptr);
+
 /* ---- host-only pieces exposed for tests (no GPU needed) -------------------
  * Build only the exchange plan (everything rp_spmm_init computes on the host,
  * including the alltoall of needed row ids) without touching the device.

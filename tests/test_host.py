@@ -338,3 +338,33 @@ def test_crpspmm_grid_rule_matches_oracle(crp, orc):
         assert np.array_equal(ai, b[2]), (trial, a, b)
         kinds.add((a[0] > 1, a[1] > 1))
     assert kinds == {(False, False), (True, False), (False, True), (True, True)}
+
+
+def test_amortized_planner_is_exhaustive_minimum(crp, orc):
+    """crp_spmm_part2d_amortized: cheapest of ALL pm x pn under the reference's cost terms
+    (src/spmat_part.c:143-145) with rA applied to every candidate; arrays laid out like the
+    reference planner's for the same grid."""
+    from crp_spmm_amd import gen, planner
+    m, n = 6000, 48
+    rp, ci, _ = gen.banded_fem(m, offsets=(1, 2, 3, 40, 41, 900), seed=2)
+    for P in (1, 2, 4, 6, 8, 12):
+        rb = planner.csr_mat_row_partition(rp, P)
+        for rA in (1, 7, 500):
+            got = planner.spmm_part2d_amortized(P, m, n, m, rb, rp, ci, rA)
+            costs = {}
+            for pn in [d for d in range(1, P + 1) if P % d == 0 and (d == 1 or d <= n)]:
+                pm = P // pn
+                rows = np.array([rb[i * pn] for i in range(pm + 1)], dtype=np.int32)
+                _sz, vol = orc.csr_row_part_comm_size(m, rp, ci, rows, rows)
+                costs[pn] = int(float(rp[-1]) * (pn - 1) * 1.5) + rA * vol * n
+            best_pn = min(costs, key=lambda d: (costs[d], d))
+            assert (got["pm"], got["pn"], got["comm_cost"]) == (P // best_pn, best_pn, costs[best_pn]), (P, rA, costs, got)
+            ref = planner.calc_spmm_part2d_from_1d(P, m, n, m, rb, rp, ci, rA=1)
+            if rA == 1:
+                assert got["comm_cost"] <= ref["comm_cost"]
+            if (got["pm"], got["pn"]) == (ref["pm"], ref["pn"]):
+                for key in ("A0_rowptr", "B_rowptr", "AC_rowptr", "BC_colptr"):
+                    assert np.array_equal(got[key], ref[key]), (P, rA, key)
+    # many reuses of a matrix with a far band: replicate A, exchange nothing
+    got = planner.spmm_part2d_amortized(8, m, n, m, planner.csr_mat_row_partition(rp, 8), rp, ci, 1000)
+    assert (got["pm"], got["pn"]) == (1, 8)
