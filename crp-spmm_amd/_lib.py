@@ -122,6 +122,7 @@ SIGNATURES = {
     "crp_csr_dev_create": (_I, [_I, _I, c_int_p, c_int_p, c_dbl_p, C.POINTER(_V)]),
     "crp_csr_dev_destroy": (_I, [C.POINTER(_V)]),
     "crp_csr_dev_update_values": (_I, [_V, _V, _V]),
+    "crp_csr_dev_set_rowmap": (_I, [_V, c_int_p, _I]),
     "crp_csr_dev_nrow": (_I, [_V]),
     "crp_csr_dev_nnz": (_LL, [_V]),
     "crp_csr_dev_bytes": (_LL, [_V]),
@@ -147,6 +148,7 @@ SIGNATURES = {
     "crp_rp_spmm_print_stat": (None, [_V]),
     "crp_rp_spmm_clear_stat": (None, [_V]),
     "crp_rp_spmm_get_plan": (None, [_V, C.POINTER(RpPlanView)]),
+    "crp_rp_spmm_overlap_rows": (None, [_V, c_int_p, c_int_p]),
     "crp_rp_spmm_set_timing": (None, [_V, _I]),
     "crp_rp_spmm_set_variant": (None, [_V, _I]),
     "crp_rp_spmm_alg_bytes": (_LL, [_V]),

@@ -37,6 +37,8 @@ struct crp_csr_dev
     PanelDev pan[2];          // [0]: R = 4, [1]: R = 8
     int      auto_variant = 1; // what variant 0 resolves to (1 rowgroup, 2 panel R4, 3 panel R8)
     long long b0_rows = 0, b1_rows = 0;   // 1 + largest local / receive-buffer row a column index addresses
+    int      *rowmap = nullptr;           // row-subset matrices: C row of every row (device), else nullptr
+    int       c_nrow = 0;                 // rows of C the product writes into (nrow without a rowmap)
 };
 
 #define CRP_TRY(expr)                                 \
@@ -316,6 +318,7 @@ int crp_csr_dev_destroy(crp_csr_dev_p *A_)
     if (A->rowptr) (void) hipFree(A->rowptr);
     if (A->colidx) (void) hipFree(A->colidx);
     if (A->val) (void) hipFree(A->val);
+    if (A->rowmap) (void) hipFree(A->rowmap);
     delete A;
     *A_ = NULL;
     return 0;
@@ -333,6 +336,20 @@ int crp_csr_dev_update_values(crp_csr_dev_p A, const double *val, void *stream)
     for (int i = 0; i < 2; i++)
         if (A->pan[i].built)
             CRP_TRY(crp::scatter_vals_f64(A->nnz, A->pan[i].pmap, A->val, A->pan[i].pval, (hipStream_t) stream));
+    return 0;
+}
+
+int crp_csr_dev_set_rowmap(crp_csr_dev_p A, const int *rowmap, int c_nrow)
+{
+    if (A == NULL || (rowmap != NULL && c_nrow < 0)) return -1;
+    if (A->rowmap) { CRP_TRY(hipFree(A->rowmap)); A->rowmap = nullptr; }
+    A->c_nrow = A->nrow;
+    if (rowmap == NULL || A->nrow == 0) return 0;
+    for (int i = 0; i < A->nrow; i++)
+        if (rowmap[i] < 0 || rowmap[i] >= c_nrow) return -2;
+    CRP_TRY(hipMalloc((void **) &A->rowmap, sizeof(int) * (size_t) A->nrow));
+    CRP_TRY(hipMemcpy(A->rowmap, rowmap, sizeof(int) * (size_t) A->nrow, hipMemcpyHostToDevice));
+    A->c_nrow = c_nrow;
     return 0;
 }
 
@@ -357,11 +374,12 @@ int crp_spmm_csr_f64(crp_csr_dev_p A, int layout, int n, const double *B0, long 
     if (A->nrow == 0 || n == 0) return 0;
     if (C == NULL || (B0 == NULL && B1 == NULL && A->nnz > 0)) return -1;
     if (layout == CRP_LAYOUT_ROW_MAJOR && (ldC < n || (B0 && ldB0 < n) || (B1 && ldB1 < n))) return -4;
-    if (layout == CRP_LAYOUT_COL_MAJOR && ldC < A->nrow) return -4;
+    if (layout == CRP_LAYOUT_COL_MAJOR && ldC < (A->rowmap ? A->c_nrow : A->nrow)) return -4;
     crp::SpmmArgs a;
     a.nrow = A->nrow; a.n = n;
     a.rowptr = A->rowptr; a.colidx = A->colidx; a.val = A->val;
     a.B0 = B0; a.ldB0 = ldB0; a.B1 = B1; a.ldB1 = ldB1; a.C = C; a.ldC = ldC;
+    a.rowmap = A->rowmap;
     hipError_t e;
     if (layout == CRP_LAYOUT_COL_MAJOR) return (int) crp::spmm_cm_f64(a, (hipStream_t) stream);
     int v = (variant == 0) ? A->auto_variant : variant;

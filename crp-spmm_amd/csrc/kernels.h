@@ -19,6 +19,7 @@ struct SpmmArgs
     int64_t       ldB1;
     double       *C;
     int64_t       ldC;
+    const int    *rowmap;   // nullptr, or the C row of every row (row-subset matrices)
 };
 
 struct PanelArgs

@@ -41,6 +41,12 @@ struct crp_rp_spmm
     long long n_send_rows = 0, n_recv_rows = 0, n_needed_rows = 0;
     std::vector<int> dev_colidx_host;
     crp_csr_dev_p A_dev = nullptr;
+    // exchange / compute overlap (nproc > 1): rows with no remote column ("interior") run while the
+    // B rows travel, the rest ("boundary") after they have landed; A_dev then stays unset
+    crp_csr_dev_p A_int = nullptr, A_bnd = nullptr;
+    std::vector<long long> int_src, bnd_src;     // position in A_val of every nonzero of the two parts
+    std::vector<double>    split_vals;
+    void *xstream = nullptr, *ev_packed = nullptr, *ev_landed = nullptr;
     int    *sridxs_dev = nullptr;
     double *sendbuf_dev = nullptr, *recvbuf_dev = nullptr;
     void   *stream = nullptr;
@@ -196,6 +202,55 @@ static void build_plan(crp_rp_spmm *e, int A_nrow, const int *A_rowptr, const in
     }
 }
 
+// Upload A: whole, or split by rows into interior / boundary parts when an exchange exists and
+// both parts are worth a launch (CRPSPMM_OVERLAP=0 keeps the single product).
+static void build_device_matrices(crp_rp_spmm *e)
+{
+    const int m = e->A_nrow;
+    int overlap = 1;
+    GET_ENV_INT_VAR(overlap, "CRPSPMM_OVERLAP", "overlap", 1, 0, 1, e->my_rank == 0);
+    std::vector<int> rows_int, rows_bnd;
+    if (overlap && e->nproc > 1 && e->n_recv_rows > 0)
+    {
+        for (int i = 0; i < m; i++)
+        {
+            bool remote = false;
+            for (int p = e->A_rowptr[i]; p < e->A_rowptr[i + 1] && !remote; p++) remote = e->dev_colidx_host[p] < 0;
+            (remote ? rows_bnd : rows_int).push_back(i);
+        }
+    }
+    // a part smaller than 1/16 of the rows does not pay for a second launch
+    if (rows_int.size() < (size_t) m / 16 || rows_bnd.empty())
+    {
+        HIP_OK(crp_csr_dev_create(m, e->loc_B_nrow, e->A_rowptr.data(), e->dev_colidx_host.data(), e->A_val.data(), &e->A_dev));
+        return;
+    }
+    auto make = [&](const std::vector<int> &rows, std::vector<long long> &src, crp_csr_dev_p *out) {
+        std::vector<int> rp(rows.size() + 1, 0), ci;
+        std::vector<double> va;
+        src.clear();
+        for (size_t t = 0; t < rows.size(); t++)
+        {
+            const int i = rows[t];
+            for (int p = e->A_rowptr[i]; p < e->A_rowptr[i + 1]; p++)
+            {
+                ci.push_back(e->dev_colidx_host[p]);
+                va.push_back(e->A_val[p]);
+                src.push_back(p);
+            }
+            rp[t + 1] = (int) ci.size();
+        }
+        if (ci.empty()) { ci.push_back(0); va.push_back(0.0); }
+        HIP_OK(crp_csr_dev_create((int) rows.size(), e->loc_B_nrow, rp.data(), ci.data(), va.data(), out));
+        HIP_OK(crp_csr_dev_set_rowmap(*out, rows.data(), m));
+    };
+    make(rows_int, e->int_src, &e->A_int);
+    make(rows_bnd, e->bnd_src, &e->A_bnd);
+    HIP_OK(crp_stream_create(&e->xstream));
+    HIP_OK(crp_event_create(&e->ev_packed));
+    HIP_OK(crp_event_create(&e->ev_landed));
+}
+
 static void rp_init_common(int A_nrow, const int *A_rowptr, const int *A_colidx, const double *A_val,
                            const int *B_row_displs, int glb_n, crp_comm_t *comm, crp_rp_spmm_p *out,
                            bool plan_only)
@@ -208,8 +263,7 @@ static void rp_init_common(int A_nrow, const int *A_rowptr, const int *A_colidx,
     build_plan(e, A_nrow, A_rowptr, A_colidx, A_val, B_row_displs, glb_n, comm);
     if (!plan_only)
     {
-        HIP_OK(crp_csr_dev_create(A_nrow, e->loc_B_nrow, e->A_rowptr.data(), e->dev_colidx_host.data(),
-                                  e->A_val.data(), &e->A_dev));
+        build_device_matrices(e);
         HIP_OK(crp_stream_create(&e->stream));
         void *p = NULL;
         if (e->n_send_rows > 0)
@@ -255,6 +309,11 @@ void crp_rp_spmm_free(crp_rp_spmm_p *rp_spmm)
     if (!e->plan_only)
     {
         crp_csr_dev_destroy(&e->A_dev);
+        crp_csr_dev_destroy(&e->A_int);
+        crp_csr_dev_destroy(&e->A_bnd);
+        if (e->xstream) crp_stream_destroy(e->xstream);
+        if (e->ev_packed) crp_event_destroy(e->ev_packed);
+        if (e->ev_landed) crp_event_destroy(e->ev_landed);
         crp_dev_free(e->sridxs_dev);
         crp_dev_free(e->sendbuf_dev);
         crp_dev_free(e->recvbuf_dev);
@@ -345,19 +404,40 @@ void crp_rp_spmm_exec_ex(crp_rp_spmm_p e, int BC_layout, const double *B, long l
     }
 
     // ---- 2. exchange (reference :275-309); received rows land in final order
-    if (e->nproc > 1)
-        e->comm->alltoallv_dev_f64(e->comm->ctx, e->sendbuf_dev, e->rB_scnts.data(), e->rB_sdispls.data(),
-                                   e->recvbuf_dev, e->rB_rcnts.data(), e->rB_rdispls.data(), s);
-    if (timing)
+    const bool split = (e->A_int != nullptr);
+    if (split && !timing)
     {
-        HIP_OK(crp_stream_sync(s));
-        t1 = get_wtime_sec();
-        e->t_a2a += t1 - t0;
-        t0 = t1;
+        // the exchange runs on its own stream beside the interior rows' product
+        HIP_OK(crp_event_record(e->ev_packed, s));
+        HIP_OK(crp_stream_wait_event(e->xstream, e->ev_packed));
+        e->comm->alltoallv_dev_f64(e->comm->ctx, e->sendbuf_dev, e->rB_scnts.data(), e->rB_sdispls.data(),
+                                   e->recvbuf_dev, e->rB_rcnts.data(), e->rB_rdispls.data(), e->xstream);
+        HIP_OK(crp_event_record(e->ev_landed, e->xstream));
+        HIP_OK(crp_spmm_csr_f64(e->A_int, 0, n, Bd, ldBd, e->recvbuf_dev, n, Cd, ldCd, e->variant, s));
+        HIP_OK(crp_stream_wait_event(s, e->ev_landed));
+        HIP_OK(crp_spmm_csr_f64(e->A_bnd, 0, n, Bd, ldBd, e->recvbuf_dev, n, Cd, ldCd, e->variant, s));
     }
+    else
+    {
+        if (e->nproc > 1)
+            e->comm->alltoallv_dev_f64(e->comm->ctx, e->sendbuf_dev, e->rB_scnts.data(), e->rB_sdispls.data(),
+                                       e->recvbuf_dev, e->rB_rcnts.data(), e->rB_rdispls.data(), s);
+        if (timing)
+        {
+            HIP_OK(crp_stream_sync(s));
+            t1 = get_wtime_sec();
+            e->t_a2a += t1 - t0;
+            t0 = t1;
+        }
 
-    // ---- 3. local SpMM (reference :388-408)
-    HIP_OK(crp_spmm_csr_f64(e->A_dev, 0, n, Bd, ldBd, e->recvbuf_dev, n, Cd, ldCd, e->variant, s));
+        // ---- 3. local SpMM (reference :388-408)
+        if (split)
+        {
+            HIP_OK(crp_spmm_csr_f64(e->A_int, 0, n, Bd, ldBd, e->recvbuf_dev, n, Cd, ldCd, e->variant, s));
+            HIP_OK(crp_spmm_csr_f64(e->A_bnd, 0, n, Bd, ldBd, e->recvbuf_dev, n, Cd, ldCd, e->variant, s));
+        }
+        else HIP_OK(crp_spmm_csr_f64(e->A_dev, 0, n, Bd, ldBd, e->recvbuf_dev, n, Cd, ldCd, e->variant, s));
+    }
     if (BC_layout == 1 && m > 0 && n > 0)
     {
         double *Ccm = C;
@@ -476,9 +556,27 @@ void crp_rp_spmm_update_values(crp_rp_spmm_p e, const double *A_val)
     memcpy(e->A_val.data(), A_val, sizeof(double) * nnz);
     if (!e->plan_only)
     {
-        HIP_OK(crp_csr_dev_update_values(e->A_dev, A_val, e->stream));
+        if (e->A_int != nullptr)
+        {
+            for (int part = 0; part < 2; part++)
+            {
+                const std::vector<long long> &src = part == 0 ? e->int_src : e->bnd_src;
+                if (src.empty()) continue;
+                e->split_vals.resize(src.size());
+                for (size_t t = 0; t < src.size(); t++) e->split_vals[t] = A_val[src[t]];
+                HIP_OK(crp_csr_dev_update_values(part == 0 ? e->A_int : e->A_bnd, e->split_vals.data(), e->stream));
+                HIP_OK(crp_stream_sync(e->stream));     // split_vals is reused by the next part
+            }
+        }
+        else HIP_OK(crp_csr_dev_update_values(e->A_dev, A_val, e->stream));
         HIP_OK(crp_stream_sync(e->stream));
     }
+}
+
+void crp_rp_spmm_overlap_rows(crp_rp_spmm_p e, int *n_interior, int *n_boundary)
+{
+    if (n_interior) *n_interior = (e && e->A_int) ? crp_csr_dev_nrow(e->A_int) : 0;
+    if (n_boundary) *n_boundary = (e && e->A_bnd) ? crp_csr_dev_nrow(e->A_bnd) : 0;
 }
 
 void crp_rp_spmm_set_timing(crp_rp_spmm_p e, int timing) { if (e) e->timing = timing ? 1 : 0; }

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void spmm_rm_f64_kernel(
     const int *__restrict__ rowptr, const int *__restrict__ colidx, const double *__restrict__ val,
     const double *__restrict__ B0, const int64_t ldB0,
     const double *__restrict__ B1, const int64_t ldB1,
-    double *__restrict__ C, const int64_t ldC)
+    double *__restrict__ C, const int64_t ldC, const int *__restrict__ rowmap)
 {
     constexpr int RPB = 256 / LPR;
     constexpr int TW  = LPR * VW * NV;
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void spmm_rm_f64_kernel(
         }
     }
 
-    double *crow = C + (int64_t) row * ldC;
+    double *crow = C + (int64_t) (rowmap ? rowmap[row] : row) * ldC;     // rowmap: C row of every row of a row-subset matrix
 #pragma unroll
     for (int v = 0; v < NV; v++)
     {
@@ -165,7 +165,7 @@ static hipError_t launch_rm(const SpmmArgs &a, hipStream_t s)
     constexpr int TW  = LPR * VW * NV;
     dim3 grid((a.nrow + RPB - 1) / RPB, (a.n + TW - 1) / TW);
     hipLaunchKernelGGL((spmm_rm_f64_kernel<LPR, VW, NV>), grid, dim3(256), 0, s,
-                       a.nrow, a.n, a.rowptr, a.colidx, a.val, a.B0, a.ldB0, a.B1, a.ldB1, a.C, a.ldC);
+                       a.nrow, a.n, a.rowptr, a.colidx, a.val, a.B0, a.ldB0, a.B1, a.ldB1, a.C, a.ldC, a.rowmap);
     return hipGetLastError();
 }
 
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(256) void spmm_panel_f64_kernel(
     const int *__restrict__ pptr, const int *__restrict__ pcol, const uint32_t *__restrict__ pmask4,
     const double *__restrict__ pval,
     const double *__restrict__ B0, const int64_t ldB0, const double *__restrict__ B1, const int64_t ldB1,
-    double *__restrict__ C, const int64_t ldC)
+    double *__restrict__ C, const int64_t ldC, const int *__restrict__ rowmap)
 {
     constexpr int TW = 64 * VW * NV;
     constexpr int RING = PANEL_RING;             // entries per round = slots per ring set
@@ -570,7 +570,7 @@ __global__ __launch_bounds__(256) void spmm_panel_f64_kernel(
         const int row = panel * R + r;
         if (row < nrow)
         {
-            double *crow = C + (int64_t) row * ldC;
+            double *crow = C + (int64_t) (rowmap ? rowmap[row] : row) * ldC;
 #pragma unroll
             for (int v = 0; v < NV; v++)
                 if (ok[v])
@@ -595,7 +595,7 @@ static hipError_t launch_panel(const PanelArgs &p, const SpmmArgs &a, hipStream_
     const int nwg = (p.npanel + 3) / 4;
     dim3 grid((nwg + 7) / 8 * 8, (a.n + TW - 1) / TW);      // multiple of 8 for the XCD remap
     hipLaunchKernelGGL((spmm_panel_f64_kernel<R, NV, VW, DEPTH, ADDR64, HAS_B1>), grid, dim3(256), 0, s, p.npanel, a.nrow, a.n,
-                       p.porder, p.pptr, p.pcol, p.pmask4, p.pval, a.B0, a.ldB0, a.B1, a.ldB1, a.C, a.ldC);
+                       p.porder, p.pptr, p.pcol, p.pmask4, p.pval, a.B0, a.ldB0, a.B1, a.ldB1, a.C, a.ldC, a.rowmap);
     return hipGetLastError();
 }
 
@@ -656,7 +656,7 @@ __global__ __launch_bounds__(256) void spmm_cm_f64_kernel(
     const int *__restrict__ rowptr, const int *__restrict__ colidx, const double *__restrict__ val,
     const double *__restrict__ B0, const int64_t ldB0,
     const double *__restrict__ B1, const int64_t ldB1,
-    double *__restrict__ C, const int64_t ldC)
+    double *__restrict__ C, const int64_t ldC, const int *__restrict__ rowmap)
 {
     const int row = blockIdx.x * 256 + threadIdx.x;
     const int j   = blockIdx.y;
@@ -671,14 +671,14 @@ __global__ __launch_bounds__(256) void spmm_cm_f64_kernel(
         const double b = (c >= 0) ? b0[c] : b1[~c];
         acc = fma(val[p], b, acc);
     }
-    C[(int64_t) j * ldC + row] = acc;
+    C[(int64_t) j * ldC + (rowmap ? rowmap[row] : row)] = acc;
 }
 
 hipError_t spmm_cm_f64(const SpmmArgs &a, hipStream_t s)
 {
     dim3 grid((a.nrow + 255) / 256, a.n);
     hipLaunchKernelGGL(spmm_cm_f64_kernel, grid, dim3(256), 0, s,
-                       a.nrow, a.n, a.rowptr, a.colidx, a.val, a.B0, a.ldB0, a.B1, a.ldB1, a.C, a.ldC);
+                       a.nrow, a.n, a.rowptr, a.colidx, a.val, a.B0, a.ldB0, a.B1, a.ldB1, a.C, a.ldC, a.rowmap);
     return hipGetLastError();
 }
 

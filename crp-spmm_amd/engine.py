@@ -109,6 +109,12 @@ class RpSpmm:
     def set_variant(self, variant):
         self._lib.crp_rp_spmm_set_variant(self.handle, int(variant))
 
+    def overlap_rows(self):
+        """(interior rows, boundary rows) of the exchange / compute overlap split; (0, 0) when off."""
+        a, b = C.c_int(), C.c_int()
+        self._lib.crp_rp_spmm_overlap_rows(self.handle, C.byref(a), C.byref(b))
+        return a.value, b.value
+
     def update_values(self, A_val):
         va = _f64(A_val)
         self._lib.crp_rp_spmm_update_values(self.handle, _dp(va))

@@ -87,6 +87,13 @@ void crp_rp_spmm_get_plan(crp_rp_spmm_p rp_spmm, crp_rp_plan_view_t *view);
 /* timing = 1 (default): every phase is bracketed by stream synchronisation and
  * billed to t_pack / t_a2a / t_unpack / t_spmm like the reference; 0: fully
  * asynchronous exec, only t_exec (host enqueue time) is accumulated. */
+/* Exchange / compute overlap: with more than one rank the rows of A are split at init into
+ * "interior" rows (no column owned by a peer) and "boundary" rows; with timing off, exec runs the
+ * B exchange on a second stream beside the interior rows' product and the boundary rows' product
+ * after the rows have landed (per-row summation order unchanged).  Both counts are 0 when the
+ * engine runs one product (one rank, nothing to receive, a part too small to pay for a launch,
+ * or CRPSPMM_OVERLAP=0). */
+void crp_rp_spmm_overlap_rows(crp_rp_spmm_p rp_spmm, int *n_interior, int *n_boundary);
 void crp_rp_spmm_set_timing(crp_rp_spmm_p rp_spmm, int timing);
 /* kernel variant for the local SpMM (crpspmm_hip.h: crp_spmm_variant_name). */
 void crp_rp_spmm_set_variant(crp_rp_spmm_p rp_spmm, int variant);

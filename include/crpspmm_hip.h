@@ -83,6 +83,11 @@ int crp_csr_dev_destroy(crp_csr_dev_p *A);
 /* New values for the same sparsity pattern (val in the order given at create; host or device
  * pointer): refreshes the CSR copy and every derived format on `stream`. */
 int crp_csr_dev_update_values(crp_csr_dev_p A, const double *val, void *stream);
+/* Row-subset matrices: row i of A writes row rowmap[i] of C (0 <= rowmap[i] < c_nrow; host array of
+ * nrow entries, copied).  Lets a product be split into row subsets that run at different times
+ * (rows with no remote column while the B exchange is in flight, the rest after it) without
+ * touching the per-row summation order.  rowmap = NULL restores the identity.  Blocking. */
+int crp_csr_dev_set_rowmap(crp_csr_dev_p A, const int *rowmap, int c_nrow);
 int crp_csr_dev_nrow(crp_csr_dev_p A);
 long long crp_csr_dev_nnz(crp_csr_dev_p A);
 /* bytes of HBM the kernel must touch for A itself: 12*nnz + 4*(nrow+1). */

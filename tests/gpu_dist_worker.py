@@ -37,6 +37,22 @@ def main():
         eng.exec(0, Bd, Cd)
         torch.cuda.synchronize()
         assert orc.rel_fro_err(C_ref[s:e], Cd.cpu().numpy()) <= 1e-12, (me, n, "1D rm")
+        # exchange / compute overlap: the rows were split (this matrix has interior rows on every rank)
+        n_int, n_bnd = eng.overlap_rows()
+        assert n_int > 0 and n_bnd > 0 and n_int + n_bnd == e - s, (me, n_int, n_bnd)
+        C_seq = Cd.cpu().numpy().copy()             # timing on: exchange, then the two products, in sequence
+        eng.set_timing(False)                       # asynchronous path: exchange beside the interior rows
+        Cd.fill_(float("nan"))
+        for _ in range(3):
+            eng.exec(0, Bd, Cd)
+        torch.cuda.synchronize()
+        assert np.array_equal(Cd.cpu().numpy(), C_seq), (me, n, "overlapped exec differs from the sequential one")
+        eng.update_values(va[rp[s]:rp[e]] * 2.0)
+        eng.exec(0, Bd, Cd)
+        torch.cuda.synchronize()
+        assert orc.rel_fro_err(2.0 * C_ref[s:e], Cd.cpu().numpy()) <= 1e-12, (me, n, "overlap + update_values")
+        eng.update_values(va[rp[s]:rp[e]])
+        eng.set_timing(True)
         Ch = np.full((n, e - s), np.nan)
         eng.exec(1, np.ascontiguousarray(B[s:e].T), Ch)            # host pointers, column-major
         assert orc.rel_fro_err(C_ref[s:e], Ch.T) <= 1e-12, (me, n, "1D cm host")

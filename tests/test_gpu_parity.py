@@ -235,6 +235,47 @@ def test_engine_update_values(crp, orc, gpu):
     sc.free()
 
 
+def test_row_subset_matrices(crp, orc, gpu):
+    """crp_csr_dev_set_rowmap: two row subsets of A write disjoint rows of one C; every kernel
+    variant; the untouched rows keep their content."""
+    import ctypes as C
+    import torch
+    from crp_spmm_amd import gen
+    lib = crp.load()
+    _IP, _DP = C.POINTER(C.c_int), C.POINTER(C.c_double)
+    m = k = 3001
+    rp, ci, va = gen.banded_fem(m, offsets=(1, 2, 3, 60), seed=13)
+    n = 96
+    B = orc.fill_B(0, k, 0, n)
+    C_ref = orc.spmm_csr(rp, ci, va, B)
+    sel = np.zeros(m, dtype=bool)
+    sel[100:1500] = True
+    sel[2000::3] = True
+    parts = [np.nonzero(sel)[0].astype(np.int32), np.nonzero(~sel)[0].astype(np.int32)]
+    Bd = _t(B, gpu)
+    for variant in (1, 2, 3):
+        Cd = torch.full((m, n), -3.0, dtype=torch.float64, device=gpu)
+        for pi, rows in enumerate(parts):
+            cnt = (rp[rows + 1] - rp[rows]).astype(np.int64)
+            sub_rp = np.zeros(rows.size + 1, dtype=np.int32)
+            sub_rp[1:] = np.cumsum(cnt)
+            idx = np.concatenate([np.arange(rp[r], rp[r + 1]) for r in rows])
+            sub_ci, sub_va = np.ascontiguousarray(ci[idx]), np.ascontiguousarray(va[idx])
+            h = C.c_void_p()
+            assert lib.crp_csr_dev_create(rows.size, k, sub_rp.ctypes.data_as(_IP), sub_ci.ctypes.data_as(_IP),
+                                          sub_va.ctypes.data_as(_DP), C.byref(h)) == 0
+            assert lib.crp_csr_dev_set_rowmap(h, rows.ctypes.data_as(_IP), m - 1) == -2      # a row outside C
+            assert lib.crp_csr_dev_set_rowmap(h, rows.ctypes.data_as(_IP), m) == 0
+            assert lib.crp_spmm_csr_f64(h, 0, n, Bd.data_ptr(), n, None, 0, Cd.data_ptr(), n, variant, None) == 0
+            torch.cuda.synchronize()
+            got = Cd.cpu().numpy()
+            assert orc.rel_fro_err(C_ref[rows], got[rows]) <= FP64_TOL, (variant, pi)
+            if pi == 0:
+                assert (got[parts[1]] == -3.0).all()
+            lib.crp_csr_dev_destroy(C.byref(h))
+        assert orc.rel_fro_err(C_ref, Cd.cpu().numpy()) <= FP64_TOL, variant
+
+
 def test_crpspmm_engine_single_rank(crp, orc, gpu):
     """The older all-in-one API at one rank: host operands in, host C out, values passed per exec
     (deprecated/src/crpspmm.h:89-122); C through a padded leading dimension."""
