@@ -264,7 +264,7 @@ def test_row_subset_matrices(crp, orc, gpu):
             h = C.c_void_p()
             assert lib.crp_csr_dev_create(rows.size, k, sub_rp.ctypes.data_as(_IP), sub_ci.ctypes.data_as(_IP),
                                           sub_va.ctypes.data_as(_DP), C.byref(h)) == 0
-            assert lib.crp_csr_dev_set_rowmap(h, rows.ctypes.data_as(_IP), m - 1) == -2      # a row outside C
+            assert lib.crp_csr_dev_set_rowmap(h, rows.ctypes.data_as(_IP), int(rows.max())) == -2      # a row outside C
             assert lib.crp_csr_dev_set_rowmap(h, rows.ctypes.data_as(_IP), m) == 0
             assert lib.crp_spmm_csr_f64(h, 0, n, Bd.data_ptr(), n, None, 0, Cd.data_ptr(), n, variant, None) == 0
             torch.cuda.synchronize()
