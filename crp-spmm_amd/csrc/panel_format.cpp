@@ -1,5 +1,7 @@
 // panel_format.cpp -- host construction of the row-panel format (panel_format.h).
 #include <algorithm>
+#include <cmath>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include "panel_format.h"
@@ -148,15 +150,125 @@ void build_panels(int nrow, const int *rowptr, const int *colidx, const double *
             for (; q < qend; q++) out->pcol[q] = last_col;   // padding: valid address, mask 0
         }
     });
-    // processing order (CRPSPMM_PANEL_ORDER=0 keeps the natural order; CRPSPMM_PANEL_GROUP = panels per group)
+    // processing order.  CRPSPMM_PANEL_ORDER: 0 natural, 1 breadth-first groups, 2 stride lattice when the
+    // matrix has one (else natural); unset = stride lattice when detected, else breadth-first groups.
+    // CRPSPMM_PANEL_GROUP = panels per breadth-first group.
     const char *eo = getenv("CRPSPMM_PANEL_ORDER"), *eg = getenv("CRPSPMM_PANEL_GROUP");
     const int group = (eg && atoi(eg) > 0) ? atoi(eg) : 16;
-    if (eo && atoi(eo) == 0)
+    const int mode = eo ? atoi(eo) : -1;
+    const int chunk = ((((npanel + 3) / 4) + 7) / 8) * 4;      // order positions per XCD (the kernels' block -> XCD map)
+    bool done = false;
+    if (mode == 2 || mode == -1) done = stride_lattice_order(nrow, rowptr, colidx, R, npanel, chunk, &out->porder);
+    if (!done && (mode == 0 || mode == 2))
     {
         out->porder.resize((size_t) npanel);
         for (int i = 0; i < npanel; i++) out->porder[(size_t) i] = i;
+        done = true;
     }
-    else locality_order(*out, group, &out->porder);
+    if (!done) locality_order(*out, group, &out->porder);
+    // experiment hook: a processing order read from a file of npanel int32 (must be a permutation)
+    if (const char *ef = getenv("CRPSPMM_PANEL_ORDER_FILE"))
+    {
+        std::vector<int> perm((size_t) npanel);
+        FILE *f = fopen(ef, "rb");
+        if (f != NULL && npanel > 0 && fread(perm.data(), sizeof(int), (size_t) npanel, f) == (size_t) npanel)
+        {
+            std::vector<char> seen((size_t) npanel, 0);
+            bool ok = true;
+            for (int v : perm)
+            {
+                if (v < 0 || v >= npanel || seen[(size_t) v]) { ok = false; break; }
+                seen[(size_t) v] = 1;
+            }
+            if (ok) out->porder = perm;
+        }
+        if (f != NULL) fclose(f);
+    }
+}
+
+bool stride_lattice_order(int nrow, const int *rowptr, const int *colidx, int R, int npanel, int chunk,
+                          std::vector<int> *order)
+{
+    if (nrow < 4096 || npanel < 64 || chunk < 1) return false;
+    // histogram of |col - row| over the locally owned columns, 64-row buckets
+    const int SH = 6;
+    const size_t nb = ((size_t) nrow >> SH) + 2;
+    const int nt = host_threads();
+    std::vector<std::vector<long long>> cnt_t((size_t) nt, std::vector<long long>(nb, 0)), sum_t(cnt_t);
+    parallel_chunks(nrow, 4096, [&](long long b, long long e, int tid) {
+        std::vector<long long> &cnt = cnt_t[(size_t) tid], &sum = sum_t[(size_t) tid];
+        for (long long r = b; r < e; r++)
+            for (int p = rowptr[r]; p < rowptr[r + 1]; p++)
+            {
+                const int c = colidx[p];
+                if (c < 0) continue;
+                long long d = (long long) c - r;
+                if (d < 0) d = -d;
+                const size_t k = std::min((size_t) (d >> SH), nb - 1);
+                cnt[k]++;
+                sum[k] += d;
+            }
+    });
+    std::vector<long long> cnt(nb, 0), sum(nb, 0);
+    long long total = 0;
+    for (int t = 0; t < nt; t++)
+        for (size_t k = 0; k < nb; k++) { cnt[k] += cnt_t[(size_t) t][k]; sum[k] += sum_t[(size_t) t][k]; }
+    for (size_t k = 0; k < nb; k++) total += cnt[k];
+    if (total == 0) return false;
+    // runs of non-empty buckets (one empty bucket allowed inside a run)
+    struct Run { long long w; double center; };
+    std::vector<Run> far;
+    for (size_t k = 0; k < nb;)
+    {
+        if (cnt[k] == 0) { k++; continue; }
+        size_t e = k;
+        long long w = 0, sm = 0;
+        while (e < nb && (cnt[e] > 0 || (e + 1 < nb && cnt[e + 1] > 0)))
+        {
+            w += cnt[e];
+            sm += sum[e];
+            e++;
+        }
+        if (k > 0 && w * 100 >= total * 6) far.push_back({w, (double) sm / (double) w});
+        k = e;
+    }
+    if (far.size() != 2) return false;          // exactly the two-stride shape; anything else is left alone
+    const double D1 = far[0].center, D2 = far[1].center;
+    const double ratio = D2 / D1;
+    const int M = (int) (ratio + 0.5);
+    if (D1 < 32.0 * R || M < 2 || std::abs(ratio - M) > 0.02 * M || D2 * 2 > nrow) return false;
+
+    // tooth coordinates of every panel
+    struct Key { int i, j, t, p; };
+    std::vector<Key> keys((size_t) npanel);
+    for (int p = 0; p < npanel; p++)
+    {
+        const double r = (double) p * R;
+        const int j = (int) (r / D2);
+        const double rem = r - j * D2;
+        int i = (int) (rem / D1);
+        if (i > M) i = M;
+        const int t = (int) ((rem - i * D1) / R);
+        keys[(size_t) p] = {i, j, t, p};
+    }
+    // XCD blocks: consecutive teeth in (i, j) order, cut every `chunk` panels
+    std::sort(keys.begin(), keys.end(), [](const Key &a, const Key &b) {
+        if (a.i != b.i) return a.i < b.i;
+        if (a.j != b.j) return a.j < b.j;
+        return a.p < b.p;
+    });
+    // lockstep sweep along t inside every block
+    for (size_t s0 = 0; s0 < keys.size(); s0 += (size_t) chunk)
+    {
+        const size_t s1 = std::min(keys.size(), s0 + (size_t) chunk);
+        std::sort(keys.begin() + (long) s0, keys.begin() + (long) s1, [](const Key &a, const Key &b) {
+            if (a.t != b.t) return a.t < b.t;
+            return a.p < b.p;
+        });
+    }
+    order->resize((size_t) npanel);
+    for (int q = 0; q < npanel; q++) (*order)[(size_t) q] = keys[(size_t) q].p;
+    return true;
 }
 
 void locality_order(const PanelHost &p, int group, std::vector<int> *order)

@@ -44,6 +44,18 @@ struct PanelHost
 // matrix it reproduces the natural order.  Pure scheduling: which wave computes which panel.
 void locality_order(const PanelHost &p, int group, std::vector<int> *order);
 
+// Stride-lattice order for matrices whose far nonzeros sit on two nested strides D1 < D2 (a 3D mesh in
+// natural order: bands at +-nx and +-nx*ny; the pwtk stand-in: 1200 and 36000).  Rows split into "teeth"
+// of D1 rows; tooth (i, j) starts at row j*D2 + i*D1.  Panels at the same offset t inside their teeth
+// touch the same B rows (one through its near band, its neighbours through a far band), so every XCD
+// gets a block of neighbouring teeth -- consecutive i, all j -- and sweeps them in lockstep along t:
+// the five temporally distant touches of a B row become touches that are in flight together on
+// one XCD.  Strides are detected from the histogram of |col - row| (two far clusters, each >= 6 % of
+// the nonzeros, D2 an integer multiple of D1 within 2 %); returns false when the matrix does not
+// look like that (the caller then uses locality_order()).  `chunk` = order positions per XCD.
+bool stride_lattice_order(int nrow, const int *rowptr, const int *colidx, int R, int npanel, int chunk,
+                          std::vector<int> *order);
+
 // Number of panel entries (before padding) a given R would need: cheap pass used
 // to pick R.  colidx may carry the two-source encoding.
 long long count_panel_entries(int nrow, const int *rowptr, const int *colidx, int R);

@@ -308,6 +308,40 @@ def test_panel_locality_order(crp, monkeypatch):
     assert np.array_equal(hip.panel_format_host(rp, ci, va, 4)["porder"], np.arange(f["npanel"]))
 
 
+def test_panel_stride_lattice_order(crp, monkeypatch):
+    """Two nested far strides (3D mesh in natural order): the order is a permutation in which every
+    XCD block of positions holds neighbouring teeth swept in lockstep -- panels one stride apart sit
+    within a few positions of each other instead of thousands; matrices without that shape keep the
+    breadth-first / natural order."""
+    from crp_spmm_amd import gen, hip
+    nx, ny, nz = 600, 32, 5                                  # strides 600 and 19200 rows
+    m = nx * ny * nz
+    rp, ci, va = gen.banded_fem(m, offsets=(1, 2, 3, nx, nx + 1, nx * ny, nx * ny + 1), seed=3)
+    R = 8
+    monkeypatch.delenv("CRPSPMM_PANEL_ORDER", raising=False)
+    po = hip.panel_format_host(rp, ci, va, R)["porder"]
+    npanel = (m + R - 1) // R
+    assert np.array_equal(np.sort(po), np.arange(npanel))
+    pos = np.empty_like(po)
+    pos[po] = np.arange(po.size)
+    chunk = ((((npanel + 3) // 4) + 7) // 8) * 4
+    for stride in (nx, nx * ny):
+        sp_ = stride // R
+        a, b = pos[:-sp_], pos[sp_:]
+        same_block = (a // chunk) == (b // chunk)
+        assert same_block.mean() > 0.6, (stride, same_block.mean())          # tooth-mates share an XCD ...
+        assert np.median(np.abs(a - b)[same_block]) <= 2 * (ny * nz), stride  # ... and run together
+    monkeypatch.setenv("CRPSPMM_PANEL_ORDER", "1")
+    assert not np.array_equal(hip.panel_format_host(rp, ci, va, R)["porder"], po)
+    monkeypatch.delenv("CRPSPMM_PANEL_ORDER")
+    # one stride only, and no structure at all: not a lattice
+    rp1, ci1, va1 = gen.banded_fem(m, offsets=(1, 2, 3, nx), seed=3)
+    monkeypatch.setenv("CRPSPMM_PANEL_ORDER", "2")
+    assert np.array_equal(hip.panel_format_host(rp1, ci1, va1, R)["porder"], np.arange(npanel))
+    rp2, ci2, va2 = gen.erdos_renyi(8192, 8192, 12, seed=4)
+    assert np.array_equal(hip.panel_format_host(rp2, ci2, va2, R)["porder"], np.arange(1024))
+
+
 def test_crpspmm_grid_rule_matches_oracle(crp, orc):
     """Grid rule of the older all-in-one engine (deprecated/src/crpspmm.c:136-195): library vs the
     oracle's line-by-line restatement, on matrices that meet the reference's assumptions (sorted
