@@ -45,6 +45,19 @@ def build_matrix(name):
     if name == "small":
         rp, ci, va = gen.banded_fem(20000, offsets=(1, 2, 3, 4, 5, 6, 100, 101, 3000))
         return "banded_fem(20000) smoke-size", 20000, 20000, rp, ci, va
+    # stand-ins for the other BASELINE configs at sizes one GPU builds in seconds (parity / side numbers only;
+    # the bench line of record is pwtk n=256)
+    if name == "kkt":
+        rp, ci, va = gen.kkt3d(96)
+        m = len(rp) - 1
+        return "nlpkkt-standin kkt3d(96)", m, m, rp, ci, va
+    if name == "fem3d":
+        rp, ci, va = gen.fem3d(56)
+        m = len(rp) - 1
+        return "Queen-standin fem3d(56, dof 3)", m, m, rp, ci, va
+    if name == "er":
+        rp, ci, va = gen.erdos_renyi(1 << 20, 1 << 20, 32, seed=1)
+        return "Erdos-Renyi 2^20 x 2^20, 32 nnz/row", 1 << 20, 1 << 20, rp, ci, va
     raise SystemExit("unknown --matrix %s" % name)
 
 

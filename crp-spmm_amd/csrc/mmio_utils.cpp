@@ -127,39 +127,127 @@ int mm_read_sparse_RPI(const char *fname, const int need_symm, int *nrow_, int *
     double *val = (double *) malloc(sizeof(double) * (cap ? cap : 1));
     ASSERT_PRINTF(row != NULL && col != NULL && val != NULL, "Failed to allocate COO arrays for %s\n", fname);
 
-    for (int i = 0; i < nnz; i++)
+    // Large files: one entry per line is the rule, so the data region is cut at line ends into one
+    // piece per host thread (count lines, prefix-sum, parse in place).  Anything else -- an entry
+    // spread over two lines, extra tokens on a line, fewer lines than nnz -- falls back to the
+    // token-by-token reader below, which accepts exactly what the reference's fscanf loop accepts.
+    bool parsed = false;
+    if (nnz >= 200000)
     {
-        const long r = strtol(p, &q, 10);
-        bool bad = (q == p);
-        p = q;
-        const long c = strtol(p, &q, 10);
-        bad = bad || (q == p);
-        p = q;
-        double v = 1.0;
-        if (bn.dtype == 'r')
+        const int nt = crp::host_threads();
+        std::vector<const char *> cut((size_t) nt + 1);
+        cut[0] = p;
+        cut[(size_t) nt] = end;
+        for (int t = 1; t < nt; t++)
         {
-            v = strtod(p, &q);
-            bad = bad || (q == p);
-            p = q;
+            const char *c = p + (size_t) ((double) (end - p) * t / nt);
+            const char *e = (const char *) memchr(c, '\n', (size_t) (end - c));
+            cut[(size_t) t] = e ? e + 1 : end;
+            if (cut[(size_t) t] < cut[(size_t) t - 1]) cut[(size_t) t] = cut[(size_t) t - 1];
         }
-        else if (bn.dtype == 'i')
+        auto blank = [](const char *a, const char *b) {
+            for (; a < b; a++)
+                if (*a != ' ' && *a != '\t' && *a != '\r') return false;
+            return true;
+        };
+        std::vector<long long> lines((size_t) nt + 1, 0);
+        crp::parallel_chunks(nt, 1, [&](long long b, long long e2, int) {
+            for (long long t = b; t < e2; t++)
+            {
+                long long c = 0;
+                for (const char *a = cut[(size_t) t]; a < cut[(size_t) t + 1];)
+                {
+                    const char *e = (const char *) memchr(a, '\n', (size_t) (cut[(size_t) t + 1] - a));
+                    const char *le = e ? e : cut[(size_t) t + 1];
+                    if (!blank(a, le)) c++;
+                    a = e ? e + 1 : cut[(size_t) t + 1];
+                }
+                lines[(size_t) t + 1] = c;
+            }
+        });
+        for (int t = 0; t < nt; t++) lines[(size_t) t + 1] += lines[(size_t) t];
+        if (lines[(size_t) nt] >= nnz)
         {
-            v = (double) strtol(p, &q, 10);
-            bad = bad || (q == p);
-            p = q;
+            std::vector<int> bad_t((size_t) nt, 0);
+            const char dtype = bn.dtype;
+            crp::parallel_chunks(nt, 1, [&](long long b, long long e2, int) {
+                for (long long t = b; t < e2; t++)
+                {
+                    long long g = lines[(size_t) t];
+                    for (const char *a = cut[(size_t) t]; a < cut[(size_t) t + 1] && g < nnz;)
+                    {
+                        const char *e = (const char *) memchr(a, '\n', (size_t) (cut[(size_t) t + 1] - a));
+                        const char *le = e ? e : cut[(size_t) t + 1];
+                        if (!blank(a, le))
+                        {
+                            char *qq = NULL;
+                            const long r = strtol(a, &qq, 10);
+                            bool bad = (qq == a) || qq > le;
+                            const char *c1 = qq;
+                            const long c = strtol(c1, &qq, 10);
+                            bad = bad || (qq == c1) || qq > le;
+                            double v = 1.0;
+                            if (!bad && dtype == 'r')
+                            {
+                                const char *c2 = qq;
+                                v = strtod(c2, &qq);
+                                bad = (qq == c2) || qq > le;
+                            }
+                            else if (!bad && dtype == 'i')
+                            {
+                                const char *c2 = qq;
+                                v = (double) strtol(c2, &qq, 10);
+                                bad = (qq == c2) || qq > le;
+                            }
+                            if (bad || !blank(qq, le)) { bad_t[(size_t) t] = 1; break; }
+                            row[g] = (int) r - 1;
+                            col[g] = (int) c - 1;
+                            val[g] = v;
+                            g++;
+                        }
+                        a = e ? e + 1 : cut[(size_t) t + 1];
+                    }
+                }
+            });
+            parsed = true;
+            for (int t = 0; t < nt; t++) parsed = parsed && !bad_t[(size_t) t];
         }
-        if (bad)
-        {
-            // the reference would return uninitialised entries here; fail instead
-            fprintf(stderr, "Premature end of Matrix Market data in file [%s] (entry %d of %d)\n", fname, i, nnz);
-            free(row); free(col); free(val);
-            return -1;
-        }
-        row[i] = (int) r - 1;
-        col[i] = (int) c - 1;
-        val[i] = v;
     }
-
+    if (!parsed)
+    {
+    for (int i = 0; i < nnz; i++)
+        {
+            const long r = strtol(p, &q, 10);
+            bool bad = (q == p);
+            p = q;
+            const long c = strtol(p, &q, 10);
+            bad = bad || (q == p);
+            p = q;
+            double v = 1.0;
+            if (bn.dtype == 'r')
+            {
+                v = strtod(p, &q);
+                bad = bad || (q == p);
+                p = q;
+            }
+            else if (bn.dtype == 'i')
+            {
+                v = (double) strtol(p, &q, 10);
+                bad = bad || (q == p);
+                p = q;
+            }
+            if (bad)
+            {
+                // the reference would return uninitialised entries here; fail instead
+                fprintf(stderr, "Premature end of Matrix Market data in file [%s] (entry %d of %d)\n", fname, i, nnz);
+                free(row); free(col); free(val);
+                return -1;
+            }
+            row[i] = (int) r - 1;
+            col[i] = (int) c - 1;
+            val[i] = v;
+        }
+    }
     int total = nnz;
     if (symm)
     {
@@ -228,6 +316,58 @@ void coo2csr(const int nrow, const int ncol, const int nnz, const int *row, cons
     *row_ptr_ = row_ptr;
     *col_idx_ = col_idx;
     *csr_val_ = csr_val;
+}
+
+// ---- binary CSR cache (extension; include/crp_engine.h) -------------------------------------------
+// Text ingest of a 400 M-line file takes minutes even parsed in parallel; a converted matrix is
+// kept next to it as one little-endian file: magic "CRPCSR01", int64 nrow, ncol, nnz, then rowptr
+// (int32 x (nrow + 1)), colidx (int32 x nnz), val (fp64 x nnz).
+int crp_csr_cache_write(const char *fname, int nrow, int ncol, const int *rowptr, const int *colidx, const double *val)
+{
+    if (fname == NULL || nrow < 0 || rowptr == NULL) return -1;
+    FILE *f = fopen(fname, "wb");
+    if (f == NULL) return -1;
+    const long long hdr[3] = {nrow, ncol, rowptr[nrow]};
+    const size_t nnz = (size_t) rowptr[nrow];
+    bool ok = fwrite("CRPCSR01", 1, 8, f) == 8 && fwrite(hdr, sizeof(long long), 3, f) == 3;
+    ok = ok && fwrite(rowptr, sizeof(int), (size_t) nrow + 1, f) == (size_t) nrow + 1;
+    ok = ok && (nnz == 0 || (fwrite(colidx, sizeof(int), nnz, f) == nnz && fwrite(val, sizeof(double), nnz, f) == nnz));
+    ok = (fclose(f) == 0) && ok;
+    return ok ? 0 : -1;
+}
+
+int crp_csr_cache_read(const char *fname, int *nrow_, int *ncol_, int **rowptr_, int **colidx_, double **val_)
+{
+    if (fname == NULL || !nrow_ || !ncol_ || !rowptr_ || !colidx_ || !val_) return -1;
+    FILE *f = fopen(fname, "rb");
+    if (f == NULL) return -1;
+    char magic[8];
+    long long hdr[3];
+    if (fread(magic, 1, 8, f) != 8 || memcmp(magic, "CRPCSR01", 8) != 0 || fread(hdr, sizeof(long long), 3, f) != 3 ||
+        hdr[0] < 0 || hdr[1] < 0 || hdr[2] < 0 || hdr[0] > 2147483646LL || hdr[2] > 2147483647LL)
+    {
+        fclose(f);
+        return -1;
+    }
+    const size_t nrow = (size_t) hdr[0], nnz = (size_t) hdr[2];
+    int *rp = (int *) malloc(sizeof(int) * (nrow + 1));
+    int *ci = (int *) malloc(sizeof(int) * (nnz ? nnz : 1));
+    double *va = (double *) malloc(sizeof(double) * (nnz ? nnz : 1));
+    bool ok = rp && ci && va && fread(rp, sizeof(int), nrow + 1, f) == nrow + 1;
+    ok = ok && (nnz == 0 || (fread(ci, sizeof(int), nnz, f) == nnz && fread(va, sizeof(double), nnz, f) == nnz));
+    fclose(f);
+    ok = ok && rp[0] == 0 && (long long) rp[nrow] == hdr[2];
+    if (!ok)
+    {
+        free(rp); free(ci); free(va);
+        return -1;
+    }
+    *nrow_ = (int) hdr[0];
+    *ncol_ = (int) hdr[1];
+    *rowptr_ = rp;
+    *colidx_ = ci;
+    *val_ = va;
+    return 0;
 }
 
 }  // extern "C"

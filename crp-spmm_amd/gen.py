@@ -60,6 +60,57 @@ def erdos_renyi(m, k, deg, seed=1):
     return rowptr, cols, vals
 
 
+def _stencil_csr(shape_rows, blocks, seed):
+    """Assemble a CSR from stencil blocks.  blocks: list of (row_lo, row_hi, g, dof_r, col_base, dof_c,
+    offsets) -- rows [row_lo, row_hi) are the dof_r unknowns of the g^3 grid nodes in node-major
+    order; each couples to the dof_c unknowns (starting at column col_base) of the neighbour nodes
+    at the (dx, dy, dz) offsets that stay inside the grid.  Values: hash of (row, col), diagonal
+    boosted; columns ascending per row."""
+    rows_all, cols_all = [], []
+    for (row_lo, g, dof_r, col_base, dof_c, offsets) in blocks:
+        nn = g * g * g
+        node = np.arange(nn, dtype=np.int64)
+        x, y, z = node % g, (node // g) % g, node // (g * g)
+        for (dx, dy, dz) in offsets:
+            ok = (x + dx >= 0) & (x + dx < g) & (y + dy >= 0) & (y + dy < g) & (z + dz >= 0) & (z + dz < g)
+            src = node[ok]
+            dst = src + dx + g * dy + g * g * dz
+            for a in range(dof_r):
+                for b in range(dof_c):
+                    rows_all.append(row_lo + src * dof_r + a)
+                    cols_all.append(col_base + dst * dof_c + b)
+    rows = np.concatenate(rows_all)
+    cols = np.concatenate(cols_all)
+    order = np.lexsort((cols, rows))
+    rows, cols = rows[order], cols[order]
+    rowptr = np.zeros(shape_rows + 1, dtype=np.int64)
+    np.add.at(rowptr, rows + 1, 1)
+    rowptr = np.cumsum(rowptr)
+    lo, hi = np.minimum(rows, cols), np.maximum(rows, cols)
+    u = _u01(lo * np.int64(1 << 26) + hi, seed)                      # symmetric values
+    vals = np.where(rows == cols, 40.0 + u, 2.0 * u - 1.0)
+    return rowptr.astype(np.int32), cols.astype(np.int32), vals
+
+
+_OFF7 = [(0, 0, 0), (1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1)]
+_OFF27 = [(dx, dy, dz) for dz in (-1, 0, 1) for dy in (-1, 0, 1) for dx in (-1, 0, 1)]
+
+
+def kkt3d(g, seed=3):
+    """nlpkkt-like stand-in (BASELINE configs[2]; nlpkkt240 itself is 2*240^3 + ... rows): the KKT matrix
+    [[H, J^T], [J, 0]] of a PDE-constrained problem on a g^3 grid -- H a 27-point stencil on the
+    N = g^3 state unknowns, J a 7-point stencil coupling them to N multipliers; 2N rows, ~20 nnz/row,
+    symmetric, zero (2,2) block."""
+    N = g * g * g
+    return _stencil_csr(2 * N, [(0, g, 1, 0, 1, _OFF27), (0, g, 1, N, 1, _OFF7), (N, g, 1, 0, 1, _OFF7)], seed)
+
+
+def fem3d(g, dof=3, seed=5):
+    """Queen_4147-like stand-in (BASELINE configs[3]): 3D solid mechanics, `dof` unknowns per node of a
+    g^3 grid, every node coupled to its 27 neighbours: dof*g^3 rows, up to 27*dof (= 81) nnz/row."""
+    return _stencil_csr(dof * g * g * g, [(0, g, dof, 0, dof, _OFF27)], seed)
+
+
 def random_csr(m, k, max_deg, seed=7, empty_every=0):
     """General test matrix: row i has (hash % (max_deg + 1)) distinct sorted columns;
     every `empty_every`-th row is empty."""

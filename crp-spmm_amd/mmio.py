@@ -38,16 +38,51 @@ def coo2csr(nrow, ncol, row, col, val):
     return _take(rp, nrow + 1, np.int32), _take(ci, nnz, np.int32), _take(cv, nnz, np.float64)
 
 
-def read_mtx_csr(fname, need_symm=0, glb_n=None, verbose=True):
+def csr_cache_write(fname, nrow, ncol, rowptr, colidx, val):
+    rp = np.ascontiguousarray(rowptr, dtype=np.int32)
+    ci = np.ascontiguousarray(colidx, dtype=np.int32)
+    va = np.ascontiguousarray(val, dtype=np.float64)
+    if ci.size == 0:
+        ci, va = np.zeros(1, np.int32), np.zeros(1)
+    return L.load().crp_csr_cache_write(str(fname).encode(), nrow, ncol, rp.ctypes.data_as(L.c_int_p),
+                                        ci.ctypes.data_as(L.c_int_p), va.ctypes.data_as(L.c_dbl_p))
+
+
+def csr_cache_read(fname):
+    """-> (nrow, ncol, rowptr, colidx, val) or None when the file is absent / not a cache file."""
+    nrow, ncol = C.c_int(), C.c_int()
+    rp, ci, va = L.c_int_p(), L.c_int_p(), L.c_dbl_p()
+    if L.load().crp_csr_cache_read(str(fname).encode(), C.byref(nrow), C.byref(ncol), C.byref(rp), C.byref(ci),
+                                   C.byref(va)) != 0:
+        return None
+    rowptr = _take(rp, nrow.value + 1, np.int32)
+    nnz = int(rowptr[-1])
+    return nrow.value, ncol.value, rowptr, _take(ci, nnz, np.int32), _take(va, nnz, np.float64)
+
+
+def read_mtx_csr(fname, need_symm=0, glb_n=None, verbose=True, cache=False):
     """examples/test_utils.c:21-55: read + convert + the 'A size = ...' banner line.
-    -> (m, k, rowptr, colidx, val)."""
+    -> (m, k, rowptr, colidx, val).  cache=True keeps / reuses a binary copy "<fname>.crpcsr"
+    (only when it is newer than the .mtx)."""
     if verbose and glb_n is not None:
         print("B has %d columns" % glb_n)
     t0 = time.time()
+    if cache:
+        import os
+        cf = str(fname) + ".crpcsr"
+        if os.path.exists(cf) and os.path.getmtime(cf) >= os.path.getmtime(fname):
+            got = csr_cache_read(cf)
+            if got is not None:
+                m, k, rp, ci, cv = got
+                if verbose:
+                    print("Rank 0 read matrix A from cache %s used %.2f s" % (cf, time.time() - t0))
+                return m, k, rp, ci, cv
     st, m, k, row, col, val = mm_read_sparse_RPI(fname, need_symm)
     if st != 0:
         raise ValueError("cannot ingest Matrix Market file %s" % fname)
     rp, ci, cv = coo2csr(m, k, row, col, val)
+    if cache:
+        csr_cache_write(str(fname) + ".crpcsr", m, k, rp, ci, cv)
     t1 = time.time()
     bw = int(np.abs(row.astype(np.int64) - col.astype(np.int64)).max()) if row.size else 0
     if verbose:

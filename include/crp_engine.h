@@ -206,6 +206,15 @@ void crp_spmm_part2d_amortized(int nproc, int m, int n, int k, const int *rb_dis
                                const int *colidx, int rA, int *pm, int *pn, size_t *comm_cost, int **A0_rowptr,
                                int **B_rowptr, int **AC_rowptr, int **BC_colptr);
 
+/* ---- binary CSR cache (ingest extension) ---------------------------------------------------------
+ * A converted matrix kept beside its .mtx so that later runs skip the text parse
+ * (examples/mmio_utils.c:11-190 takes 3 s for pwtk, minutes for nlpkkt240).  One little-endian file:
+ * "CRPCSR01", int64 nrow / ncol / nnz, rowptr, colidx, val.  Return 0, or -1 (unreadable, wrong
+ * magic, inconsistent sizes); read hands back malloc'd arrays (caller frees). */
+int crp_csr_cache_write(const char *fname, int nrow, int ncol, const int *rowptr, const int *colidx,
+                        const double *val);
+int crp_csr_cache_read(const char *fname, int *nrow, int *ncol, int **rowptr, int **colidx, double **val);
+
 /* ---- host-only pieces exposed for tests (no GPU needed) -------------------
  * Build only the exchange plan (everything rp_spmm_init computes on the host,
  * including the alltoall of needed row ids) without touching the device.

@@ -235,6 +235,46 @@ def test_engine_update_values(crp, orc, gpu):
     sc.free()
 
 
+@pytest.mark.parametrize("kind", ["kkt3d", "fem3d", "er"])
+def test_baseline_config_standins(crp, orc, gpu, kind):
+    """Stand-ins for the other BASELINE configs (nlpkkt240 n=128, Queen_4147 n=1024, Erdos-Renyi n=64)
+    at sizes the oracle finishes in seconds: every kernel variant through the engine, plus linearity
+    (C(B1 + 2 B2) = C(B1) + 2 C(B2)) as the size-independent property."""
+    import torch
+    from crp_spmm_amd import comm, engine, gen
+    if kind == "kkt3d":
+        rp, ci, va = gen.kkt3d(20)
+        n = 128
+    elif kind == "fem3d":
+        rp, ci, va = gen.fem3d(12)
+        n = 1024
+    else:
+        rp, ci, va = gen.erdos_renyi(20000, 20000, 32, seed=1)
+        n = 64
+    m = len(rp) - 1
+    B = np.random.default_rng(5).uniform(-1, 1, size=(m, n))
+    ref = orc.spmm_csr(rp, ci, va, B, fast=True)
+    sc = comm.SelfComm()
+    e = engine.RpSpmm(0, m, rp, ci, va, [0, m], n, sc)
+    Bd, Cd = _t(B, gpu), torch.empty((m, n), dtype=torch.float64, device=gpu)
+    for variant in (0, 1, 2, 3):
+        e.set_variant(variant)
+        Cd.fill_(float("nan"))
+        e.exec(0, Bd, Cd)
+        torch.cuda.synchronize()
+        assert orc.rel_fro_err(ref, Cd.cpu().numpy()) <= FP64_TOL, (kind, variant)
+    e.set_variant(0)
+    B2 = _t(np.random.default_rng(6).uniform(-1, 1, size=(m, n)), gpu)
+    C1, C2, C3 = torch.empty_like(Cd), torch.empty_like(Cd), torch.empty_like(Cd)
+    e.exec(0, Bd, C1)
+    e.exec(0, B2, C2)
+    e.exec(0, Bd + 2.0 * B2, C3)
+    torch.cuda.synchronize()
+    assert orc.rel_fro_err((C1 + 2.0 * C2).cpu().numpy(), C3.cpu().numpy()) <= 1e-13
+    e.free()
+    sc.free()
+
+
 def test_row_subset_matrices(crp, orc, gpu):
     """crp_csr_dev_set_rowmap: two row subsets of A write disjoint rows of one C; every kernel
     variant; the untouched rows keep their content."""

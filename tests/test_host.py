@@ -402,3 +402,44 @@ def test_amortized_planner_is_exhaustive_minimum(crp, orc):
     # many reuses of a matrix with a far band: replicate A, exchange nothing
     got = planner.spmm_part2d_amortized(8, m, n, m, planner.csr_mat_row_partition(rp, 8), rp, ci, 1000)
     assert (got["pm"], got["pn"]) == (1, 8)
+
+
+def test_parallel_ingest_and_cache(crp, orc, tmp_path):
+    """Files above 200k entries take the line-parallel parser: same COO as the reference's reader
+    (oracle/_ref) entry for entry; an entry spread over two lines or a line with extra tokens falls
+    back to the token reader and still matches; the binary CSR cache round-trips bit-exactly."""
+    import time
+    from crp_spmm_amd import gen, mmio
+    m = 40000
+    rp, ci, va = gen.banded_fem(m, offsets=(1, 2, 3, 50, 700), seed=8)
+    rows = np.repeat(np.arange(m), np.diff(rp))
+    keep = ci <= rows                                         # lower triangle, symmetric file
+    r, c, v = rows[keep], ci[keep], va[keep]
+    assert r.size > 200000
+    body = "\n".join("%d %d %.17g" % (a + 1, b + 1, x) for a, b, x in zip(r, c, v))
+    f1 = tmp_path / "big.mtx"
+    f1.write_text("%%MatrixMarket matrix coordinate real symmetric\n% generated\n" + "%d %d %d\n" % (m, m, r.size) + body + "\n")
+    t0 = time.time()
+    st, nr, nc, row, col, val = mmio.mm_read_sparse_RPI(f1)
+    t_par = time.time() - t0
+    assert st == 0 and (nr, nc) == (m, m)
+    if orc.ref() is not None:
+        rr = orc.ref_mm_read(str(f1))
+        assert rr[0] == 0 and np.array_equal(row, rr[3]) and np.array_equal(col, rr[4]) and np.array_equal(val, rr[5])
+    # entry 7 split over two lines + trailing junk lines: token reader, same result
+    lines = body.split("\n")
+    a, b, x = lines[7].split()
+    lines[7] = a + " " + b + "\n   " + x
+    f2 = tmp_path / "split.mtx"
+    f2.write_text("%%MatrixMarket matrix coordinate real symmetric\n" + "%d %d %d\n" % (m, m, r.size) + "\n".join(lines) + "\n\n")
+    st2, _, _, row2, col2, val2 = mmio.mm_read_sparse_RPI(f2)
+    assert st2 == 0 and np.array_equal(row, row2) and np.array_equal(col, col2) and np.array_equal(val, val2)
+    # cache
+    mm, kk, rp1, ci1, va1 = mmio.read_mtx_csr(f1, verbose=False, cache=True)
+    assert (tmp_path / "big.mtx.crpcsr").exists()
+    mm2, kk2, rp2, ci2, va2 = mmio.read_mtx_csr(f1, verbose=False, cache=True)
+    assert (mm, kk) == (mm2, kk2) and np.array_equal(rp1, rp2) and np.array_equal(ci1, ci2) and np.array_equal(va1, va2)
+    assert np.array_equal(rp1, rp) and np.array_equal(ci1, ci) and np.allclose(va1, va, rtol=0, atol=0)
+    (tmp_path / "junk.crpcsr").write_bytes(b"not a cache file")
+    assert mmio.csr_cache_read(tmp_path / "junk.crpcsr") is None
+    print("parallel ingest of %d entries: %.3f s" % (r.size, t_par))
