@@ -275,6 +275,35 @@ def test_baseline_config_standins(crp, orc, gpu, kind):
     sc.free()
 
 
+def test_b_block_beyond_4gib(crp, orc, gpu):
+    """B rows addressed past 4 GiB (what one GPU sees for nlpkkt240 x n=256): the row-panel kernels
+    switch from 32-bit buffer offsets to 64-bit addresses.  Reached cheaply with a 4 MiB leading
+    dimension: 1100 rows span 4.6 GB while only n columns of each row hold data."""
+    import torch
+    from crp_spmm_amd import gen, hip
+    k, n, ld = 1100, 256, 1 << 19
+    m = 1500
+    rp, ci, va = gen.random_csr(m, k, 40, seed=21)
+    ci = ci.copy()
+    ci[::5] = k - 1 - (ci[::5] % 7)                      # make sure the last rows (beyond 4 GiB) are hit
+    for r in range(m):                                   # keep columns ascending inside a row
+        ci[rp[r]:rp[r + 1]] = np.sort(ci[rp[r]:rp[r + 1]])
+    B = np.random.default_rng(3).uniform(-1, 1, size=(k, n))
+    ref = orc.spmm_csr(rp, ci, va, B)
+    Bbig = torch.empty((k, ld), dtype=torch.float64, device=gpu)
+    assert Bbig.numel() * 8 > (1 << 32)
+    Bbig[:, :n] = _t(B, gpu)
+    A = hip.CsrDev(m, k, rp, ci, va)
+    for variant in (1, 2, 3):
+        Cd = torch.full((m, n), float("nan"), dtype=torch.float64, device=gpu)
+        hip.spmm_csr(A, Bbig[:, :n], Cd, n=n, variant=variant)
+        torch.cuda.synchronize()
+        assert orc.rel_fro_err(ref, Cd.cpu().numpy()) <= FP64_TOL, variant
+    A.free()
+    del Bbig
+    torch.cuda.empty_cache()
+
+
 def test_row_subset_matrices(crp, orc, gpu):
     """crp_csr_dev_set_rowmap: two row subsets of A write disjoint rows of one C; every kernel
     variant; the untouched rows keep their content."""

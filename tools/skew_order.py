@@ -58,6 +58,18 @@ def main():
     else:
         raise SystemExit("mode?")
     key = A * i + B * j + teeth * (t // U) * U
+    if mode == "iblock" and len(sys.argv) > 6:
+        inner = sys.argv[6]
+        if inner == "ij":        # inside one t: i-major
+            tie = i * 100 + j
+        elif inner == "2x2":     # inside one t: 2x2 blocks of (i, j)
+            tie = (i // 2) * 10000 + (j // 2) * 100 + (j % 2) * 2 + (i % 2)
+        else:
+            tie = p
+        order = np.lexsort((tie, key, xcd)).astype(np.int32)
+        order.tofile(out)
+        print(out, inner)
+        return
     order = np.lexsort((p, key, xcd)).astype(np.int32)
     assert np.array_equal(np.sort(order), p)
     order.tofile(out)
