@@ -23,6 +23,16 @@ struct PanelDev
     long long entries = 0;
 };
 
+struct TeamDev
+{
+    bool built = false;
+    int  nteam = 0;
+    int *torder = nullptr, *tpanel = nullptr, *tptr = nullptr, *tcol = nullptr;
+    uint32_t *tmask = nullptr;
+    long long entries = 0;
+    bool lattice = false;
+};
+
 struct crp_csr_dev
 {
     int       nrow = 0;
@@ -35,6 +45,7 @@ struct crp_csr_dev
     std::vector<int>    h_rowptr, h_colidx;
     std::vector<double> h_val;
     PanelDev pan[2];          // [0]: R = 4, [1]: R = 8
+    TeamDev  team;            // teams of four R = 8 panels (variant 4)
     int      auto_variant = 1; // what variant 0 resolves to (1 rowgroup, 2 panel R4, 3 panel R8)
     long long b0_rows = 0, b1_rows = 0;   // 1 + largest local / receive-buffer row a column index addresses
     int      *rowmap = nullptr;           // row-subset matrices: C row of every row (device), else nullptr
@@ -83,6 +94,36 @@ static int ensure_panel(crp_csr_dev *A, int idx)
         e = hipMemcpy(d.pval, h.pval.data(), sizeof(double) * h.pval.size(), hipMemcpyHostToDevice);
     if (e != hipSuccess) return (int) e;
     d.built = true;
+    return 0;
+}
+
+// Build (once) and upload the team format on top of the R = 8 panels. Blocking.
+static int ensure_team(crp_csr_dev *A)
+{
+    TeamDev &t = A->team;
+    if (t.built) return 0;
+    const int rc = ensure_panel(A, 1);
+    if (rc != 0) return rc;
+    crp::PanelHost h;
+    crp::build_panels(A->nrow, A->h_rowptr.data(), A->h_colidx.data(), A->h_val.data(), 8, &h);
+    crp::TeamHost th;
+    crp::build_teams(h, A->nrow, A->h_rowptr.data(), A->h_colidx.data(), &th);
+    t.nteam = th.nteam;
+    t.entries = (long long) th.tcol.size();
+    t.lattice = th.lattice;
+    auto up = [](void **dst, const void *src, size_t bytes, size_t pad) -> hipError_t {
+        hipError_t e = hipMalloc(dst, bytes + pad);
+        if (e == hipSuccess && pad) e = hipMemset((char *) *dst + bytes, 0, pad);
+        if (e == hipSuccess && bytes) e = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+        return e;
+    };
+    hipError_t e = up((void **) &t.torder, th.torder.data(), sizeof(int) * th.torder.size(), 4);
+    if (e == hipSuccess) e = up((void **) &t.tpanel, th.tpanel.data(), sizeof(int) * th.tpanel.size(), 4);
+    if (e == hipSuccess) e = up((void **) &t.tptr, th.tptr.data(), sizeof(int) * th.tptr.size(), 4);
+    if (e == hipSuccess) e = up((void **) &t.tcol, th.tcol.data(), sizeof(int) * th.tcol.size(), 256);
+    if (e == hipSuccess) e = up((void **) &t.tmask, th.tmask.data(), sizeof(uint32_t) * th.tmask.size(), 256);
+    if (e != hipSuccess) return (int) e;
+    t.built = true;
     return 0;
 }
 
@@ -315,6 +356,11 @@ int crp_csr_dev_destroy(crp_csr_dev_p *A_)
         if (A->pan[i].pmap) (void) hipFree(A->pan[i].pmap);
         if (A->pan[i].pval) (void) hipFree(A->pan[i].pval);
     }
+    if (A->team.torder) (void) hipFree(A->team.torder);
+    if (A->team.tpanel) (void) hipFree(A->team.tpanel);
+    if (A->team.tptr) (void) hipFree(A->team.tptr);
+    if (A->team.tcol) (void) hipFree(A->team.tcol);
+    if (A->team.tmask) (void) hipFree(A->team.tmask);
     if (A->rowptr) (void) hipFree(A->rowptr);
     if (A->colidx) (void) hipFree(A->colidx);
     if (A->val) (void) hipFree(A->val);
@@ -357,7 +403,7 @@ int crp_csr_dev_nrow(crp_csr_dev_p A) { return A ? A->nrow : -1; }
 long long crp_csr_dev_nnz(crp_csr_dev_p A) { return A ? A->nnz : -1; }
 long long crp_csr_dev_bytes(crp_csr_dev_p A) { return A ? 12LL * A->nnz + 4LL * ((long long) A->nrow + 1) : -1; }
 
-static const char *k_variant_names[] = {"auto", "csr-rowgroup", "rowpanel-R4", "rowpanel-R8"};
+static const char *k_variant_names[] = {"auto", "csr-rowgroup", "rowpanel-R4", "rowpanel-R8", "team-R8"};
 int crp_spmm_variant_count(void) { return (int) (sizeof(k_variant_names) / sizeof(k_variant_names[0])); }
 const char *crp_spmm_variant_name(int variant)
 {
@@ -383,7 +429,17 @@ int crp_spmm_csr_f64(crp_csr_dev_p A, int layout, int n, const double *B0, long 
     hipError_t e;
     if (layout == CRP_LAYOUT_COL_MAJOR) return (int) crp::spmm_cm_f64(a, (hipStream_t) stream);
     int v = (variant == 0) ? A->auto_variant : variant;
+    if (v == 4 && (!crp::spmm_team_applicable(a) || A->b1_rows > 0)) v = 3;   // team kernel: one B source, 256-column tile
     if (v >= 2 && (!crp::spmm_panel_applicable(a) || A->nnz == 0)) v = 1;   // narrow / unaligned operands
+    if (v == 4)
+    {
+        const int rc = ensure_team(A);
+        if (rc != 0) return rc;
+        crp::TeamArgs t;
+        t.nteam = A->team.nteam; t.torder = A->team.torder; t.tpanel = A->team.tpanel; t.tptr = A->team.tptr;
+        t.tcol = A->team.tcol; t.tmask = A->team.tmask; t.pptr = A->pan[1].pptr; t.pval = A->pan[1].pval;
+        return (int) crp::spmm_rm_f64_team(t, a, (hipStream_t) stream);
+    }
     if (v >= 2)
     {
         const int rc = ensure_panel(A, v - 2);       // no-op unless an explicit variant asks for a new format

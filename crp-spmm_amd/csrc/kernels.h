@@ -35,11 +35,25 @@ struct PanelArgs
     long long       b1_rows;
 };
 
+struct TeamArgs
+{
+    int nteam;
+    const int      *torder;
+    const int      *tpanel;
+    const int      *tptr;
+    const int      *tcol;
+    const uint32_t *tmask;
+    const int      *pptr;      // of the R = 8 panel format the teams are built on
+    const double   *pval;
+};
+
 // spmm_kernels.hip
 hipError_t spmm_rm_f64_rowgroup(const SpmmArgs &a, hipStream_t s);
 hipError_t spmm_cm_f64(const SpmmArgs &a, hipStream_t s);
 bool spmm_panel_applicable(const SpmmArgs &a);
 hipError_t spmm_rm_f64_panel(const PanelArgs &p, const SpmmArgs &a, hipStream_t s);
+bool spmm_team_applicable(const SpmmArgs &a);
+hipError_t spmm_rm_f64_team(const TeamArgs &t, const SpmmArgs &a, hipStream_t s);
 
 // row_kernels.hip
 hipError_t gather_rows_f64(int layout, int nidx, int n, const int *ridx, const double *src, int64_t lds,

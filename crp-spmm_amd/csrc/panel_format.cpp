@@ -186,10 +186,9 @@ void build_panels(int nrow, const int *rowptr, const int *colidx, const double *
     }
 }
 
-bool stride_lattice_order(int nrow, const int *rowptr, const int *colidx, int R, int npanel, int chunk,
-                          std::vector<int> *order)
+bool detect_stride_lattice(int nrow, const int *rowptr, const int *colidx, int R, double *D1_, double *D2_, int *M_)
 {
-    if (nrow < 4096 || npanel < 64 || chunk < 1) return false;
+    if (nrow < 4096) return false;
     // histogram of |col - row| over the locally owned columns, 64-row buckets
     const int SH = 6;
     const size_t nb = ((size_t) nrow >> SH) + 2;
@@ -237,18 +236,39 @@ bool stride_lattice_order(int nrow, const int *rowptr, const int *colidx, int R,
     const double ratio = D2 / D1;
     const int M = (int) (ratio + 0.5);
     if (D1 < 32.0 * R || M < 2 || std::abs(ratio - M) > 0.02 * M || D2 * 2 > nrow) return false;
+    *D1_ = D1;
+    *D2_ = D2;
+    *M_ = M;
+    return true;
+}
+
+void lattice_coords(int panel, int R, double D1, double D2, int M, int *i_, int *j_, int *t_)
+{
+    const double r = (double) panel * R;
+    const int j = (int) (r / D2);
+    const double rem = r - j * D2;
+    int i = (int) (rem / D1);
+    if (i > M) i = M;
+    *i_ = i;
+    *j_ = j;
+    *t_ = (int) ((rem - i * D1) / R);
+}
+
+bool stride_lattice_order(int nrow, const int *rowptr, const int *colidx, int R, int npanel, int chunk,
+                          std::vector<int> *order)
+{
+    if (npanel < 64 || chunk < 1) return false;
+    double D1, D2;
+    int M;
+    if (!detect_stride_lattice(nrow, rowptr, colidx, R, &D1, &D2, &M)) return false;
 
     // tooth coordinates of every panel
     struct Key { int i, j, t, p; };
     std::vector<Key> keys((size_t) npanel);
     for (int p = 0; p < npanel; p++)
     {
-        const double r = (double) p * R;
-        const int j = (int) (r / D2);
-        const double rem = r - j * D2;
-        int i = (int) (rem / D1);
-        if (i > M) i = M;
-        const int t = (int) ((rem - i * D1) / R);
+        int i, j, t;
+        lattice_coords(p, R, D1, D2, M, &i, &j, &t);
         keys[(size_t) p] = {i, j, t, p};
     }
     // XCD blocks: consecutive teeth in (i, j) order, cut every `chunk` panels
@@ -344,6 +364,159 @@ void locality_order(const PanelHost &p, int group, std::vector<int> *order)
     size_t w = 0;
     for (int g : gorder)
         for (int pn = g * group; pn < std::min(np, (g + 1) * group); pn++) (*order)[w++] = pn;
+}
+
+// ---- teams: four panels whose B rows one workgroup loads once (panel_format.h) --------------------
+void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *colidx, TeamHost *out)
+{
+    const int np = p.npanel, R = p.R;
+    double D1 = 0, D2 = 0;
+    int M = 0;
+    const bool lattice = (np >= 64) && detect_stride_lattice(nrow, rowptr, colidx, R, &D1, &D2, &M);
+    out->lattice = lattice;
+    // membership: (team key, slot)
+    struct Mem { long long key; int slot, panel, a, b, t; };
+    std::vector<Mem> mem((size_t) np);
+    for (int q = 0; q < np; q++)
+    {
+        if (lattice)
+        {
+            int i, j, t;
+            lattice_coords(q, R, D1, D2, M, &i, &j, &t);
+            const int a = i >> 1, b = j >> 1;
+            mem[(size_t) q] = {((long long) a << 40) | ((long long) b << 24) | (long long) t, (i & 1) + 2 * (j & 1), q, a, b, t};
+        }
+        else mem[(size_t) q] = {(long long) (q >> 2), q & 3, q, 0, 0, q >> 2};
+    }
+    std::sort(mem.begin(), mem.end(), [](const Mem &x, const Mem &y) {
+        if (x.key != y.key) return x.key < y.key;
+        if (x.slot != y.slot) return x.slot < y.slot;
+        return x.panel < y.panel;
+    });
+    // teams in key order; a slot that is taken twice (irregular tooth ends) opens a new team
+    struct TeamKey { int a, b, t; };
+    std::vector<TeamKey> tk;
+    out->tpanel.clear();
+    for (size_t s0 = 0; s0 < mem.size();)
+    {
+        size_t s1 = s0;
+        int slots[4] = {-1, -1, -1, -1};
+        while (s1 < mem.size() && mem[s1].key == mem[s0].key && slots[mem[s1].slot] < 0)
+        {
+            slots[mem[s1].slot] = mem[s1].panel;
+            s1++;
+        }
+        for (int w = 0; w < 4; w++) out->tpanel.push_back(slots[w]);
+        tk.push_back({mem[s0].a, mem[s0].b, mem[s0].t});
+        s0 = s1;
+    }
+    const int nteam = (int) tk.size();
+    out->nteam = nteam;
+
+    // union entry lists: 4-way merge by (column key, occurrence inside the panel)
+    auto real_count = [&](int panel) {
+        int c = 0;
+        for (int q = p.pptr[panel]; q < p.pptr[panel + 1]; q++)
+        {
+            const unsigned m = (p.pmask4[(size_t) q >> 2] >> (8 * (q & 3))) & 0xFFu;
+            if (m == 0) break;          // padding starts here: real entries always carry a row
+            c++;
+        }
+        return c;
+    };
+    std::vector<int> cnt((size_t) nteam, 0);
+    std::vector<std::vector<int>> ucol((size_t) nteam);
+    std::vector<std::vector<uint32_t>> umask((size_t) nteam);
+    parallel_chunks(nteam, 64, [&](long long b, long long e, int) {
+        for (long long g = b; g < e; g++)
+        {
+            int head[4], end[4], occ[4];
+            for (int w = 0; w < 4; w++)
+            {
+                const int panel = out->tpanel[(size_t) g * 4 + w];
+                head[w] = panel >= 0 ? p.pptr[panel] : 0;
+                end[w] = panel >= 0 ? head[w] + real_count(panel) : 0;
+                occ[w] = 0;
+            }
+            std::vector<int> &uc = ucol[(size_t) g];
+            std::vector<uint32_t> &um = umask[(size_t) g];
+            for (;;)
+            {
+                bool any = false;
+                uint64_t best = 0;
+                for (int w = 0; w < 4; w++)
+                    if (head[w] < end[w])
+                    {
+                        const uint64_t k = ((uint64_t) col_key(p.pcol[(size_t) head[w]]) << 8) | (uint64_t) occ[w];
+                        if (!any || k < best) best = k;
+                        any = true;
+                    }
+                if (!any) break;
+                uint32_t m = 0;
+                int col = 0;
+                for (int w = 0; w < 4; w++)
+                    if (head[w] < end[w])
+                    {
+                        const int c = p.pcol[(size_t) head[w]];
+                        const uint64_t k = ((uint64_t) col_key(c) << 8) | (uint64_t) occ[w];
+                        if (k != best) continue;
+                        const int q = head[w];
+                        m |= ((p.pmask4[(size_t) q >> 2] >> (8 * (q & 3))) & 0xFFu) << (8 * w);
+                        col = c;
+                        head[w]++;
+                        occ[w] = (head[w] < end[w] && p.pcol[(size_t) head[w]] == c) ? occ[w] + 1 : 0;
+                    }
+                uc.push_back(col);
+                um.push_back(m);
+            }
+            cnt[(size_t) g] = (int) uc.size();
+        }
+    });
+    out->tptr.assign((size_t) nteam + 1, 0);
+    long long real = 0;
+    for (int g = 0; g < nteam; g++)
+    {
+        real += cnt[(size_t) g];
+        out->tptr[(size_t) g + 1] = out->tptr[(size_t) g] + (cnt[(size_t) g] + PANEL_PAD - 1) / PANEL_PAD * PANEL_PAD;
+    }
+    out->real_entries = real;
+    const size_t total = (size_t) out->tptr[(size_t) nteam];
+    out->tcol.assign(total, 0);
+    out->tmask.assign(total, 0u);
+    for (int g = 0; g < nteam; g++)
+    {
+        size_t q = (size_t) out->tptr[(size_t) g];
+        int last = 0;
+        for (size_t t = 0; t < ucol[(size_t) g].size(); t++, q++)
+        {
+            out->tcol[q] = ucol[(size_t) g][t];
+            out->tmask[q] = umask[(size_t) g][t];
+            last = out->tcol[q];
+        }
+        for (; q < (size_t) out->tptr[(size_t) g + 1]; q++) out->tcol[q] = last;      // padding: valid row, no reader
+    }
+
+    // processing order: XCD blocks of neighbouring team columns swept in lockstep along t (lattice),
+    // else the natural order
+    out->torder.resize((size_t) nteam);
+    for (int g = 0; g < nteam; g++) out->torder[(size_t) g] = g;
+    if (lattice)
+    {
+        const int chunk = (nteam + 7) / 8;
+        std::sort(out->torder.begin(), out->torder.end(), [&](int x, int y) {
+            if (tk[(size_t) x].a != tk[(size_t) y].a) return tk[(size_t) x].a < tk[(size_t) y].a;
+            if (tk[(size_t) x].b != tk[(size_t) y].b) return tk[(size_t) x].b < tk[(size_t) y].b;
+            return x < y;
+        });
+        for (size_t s0 = 0; s0 < out->torder.size(); s0 += (size_t) chunk)
+        {
+            const size_t s1 = std::min(out->torder.size(), s0 + (size_t) chunk);
+            std::sort(out->torder.begin() + (long) s0, out->torder.begin() + (long) s1, [&](int x, int y) {
+                if (tk[(size_t) x].t != tk[(size_t) y].t) return tk[(size_t) x].t < tk[(size_t) y].t;
+                return x < y;
+            });
+        }
+    }
 }
 
 }  // namespace crp

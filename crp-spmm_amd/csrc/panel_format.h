@@ -56,6 +56,32 @@ void locality_order(const PanelHost &p, int group, std::vector<int> *order);
 bool stride_lattice_order(int nrow, const int *rowptr, const int *colidx, int R, int npanel, int chunk,
                           std::vector<int> *order);
 
+// Two nested far strides (see stride_lattice_order): detection alone, and the tooth coordinates
+// (i, j, offset t in panels) of a panel.
+bool detect_stride_lattice(int nrow, const int *rowptr, const int *colidx, int R, double *D1, double *D2, int *M);
+void lattice_coords(int panel, int R, double D1, double D2, int M, int *i, int *j, int *t);
+
+// Teams: four panels (one per wave of a workgroup) whose B rows the workgroup loads ONCE into an LDS
+// ring shared by its waves.  For a stride-lattice matrix a team is a 2 x 2 block of teeth at the
+// same offset t -- the panels that read a B row through their near band and through their far
+// bands sit in one team, so that row crosses L2 once instead of three times; otherwise four
+// consecutive panels.  The union of the four panels' columns is stored once (tcol), with one mask
+// word per union entry: byte w = row mask of wave w (0 = wave w does not use the column).  Wave w
+// walks its own panel's values (PanelHost::pval) in its own entry order, which is the order its
+// entries appear in the union.
+struct TeamHost
+{
+    int nteam = 0;
+    bool lattice = false;
+    std::vector<int>      tpanel;  // 4 * nteam: panel of wave w, or -1
+    std::vector<int>      tptr;    // nteam + 1: union entry offsets (multiples of PANEL_PAD)
+    std::vector<int>      tcol;    // union entries: column index
+    std::vector<uint32_t> tmask;   // union entries: 4 row masks
+    std::vector<int>      torder;  // processing order of the teams
+    long long real_entries = 0;    // union entries before padding
+};
+void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *colidx, TeamHost *out);
+
 // Number of panel entries (before padding) a given R would need: cheap pass used
 // to pick R.  colidx may carry the two-source encoding.
 long long count_panel_entries(int nrow, const int *rowptr, const int *colidx, int R);
