@@ -17,6 +17,8 @@ struct PanelDev
     bool      built = false;
     int       R = 0, npanel = 0;
     int      *pptr = nullptr, *pcol = nullptr, *porder = nullptr;
+    int       norder = 0;
+    int      *psync = nullptr;
     uint32_t *pmask4 = nullptr, *pmap = nullptr;
     double   *pval = nullptr;
     double    fill = 0.0;
@@ -29,6 +31,9 @@ struct TeamDev
     int  nteam = 0;
     int *torder = nullptr, *tpanel = nullptr, *tptr = nullptr, *tcol = nullptr;
     uint32_t *tmask = nullptr;
+    long long *tvoff = nullptr;
+    double   *tval = nullptr;
+    uint32_t *tmap = nullptr;      // per CSR nonzero: its slot in tval (value updates)
     long long entries = 0;
     bool lattice = false;
 };
@@ -68,6 +73,7 @@ static int ensure_panel(crp_csr_dev *A, int idx)
     crp::build_panels(A->nrow, A->h_rowptr.data(), A->h_colidx.data(), A->h_val.data(), idx == 0 ? 4 : 8, &h);
     d.R = h.R;
     d.npanel = h.npanel;
+    d.norder = (int) h.porder.size();
     d.fill = h.fill();
     d.entries = (long long) h.pcol.size();
     hipError_t e = hipMalloc((void **) &d.pptr, sizeof(int) * h.pptr.size());
@@ -80,6 +86,14 @@ static int ensure_panel(crp_csr_dev *A, int idx)
     if (e == hipSuccess) e = hipMalloc((void **) &d.porder, sizeof(int) * (h.porder.size() + 1));
     if (e == hipSuccess && !h.porder.empty())
         e = hipMemcpy(d.porder, h.porder.data(), sizeof(int) * h.porder.size(), hipMemcpyHostToDevice);
+    // team schedule: the waves of a workgroup start their rounds together (CRPSPMM_TEAM_SYNC=0: free-running)
+    static const bool use_sync = getenv("CRPSPMM_TEAM_SYNC") ? atoi(getenv("CRPSPMM_TEAM_SYNC")) != 0 : true;
+    if (e == hipSuccess && !h.psync.empty() && use_sync)
+    {
+        e = hipMalloc((void **) &d.psync, sizeof(int) * (h.psync.size() + 8));
+        if (e == hipSuccess) e = hipMemset(d.psync, 0, sizeof(int) * (h.psync.size() + 8));
+        if (e == hipSuccess) e = hipMemcpy(d.psync, h.psync.data(), sizeof(int) * h.psync.size(), hipMemcpyHostToDevice);
+    }
     if (e == hipSuccess) e = hipMemcpy(d.pptr, h.pptr.data(), sizeof(int) * h.pptr.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess && !h.pcol.empty())
     {
@@ -105,7 +119,7 @@ static int ensure_team(crp_csr_dev *A)
     const int rc = ensure_panel(A, 1);
     if (rc != 0) return rc;
     crp::PanelHost h;
-    crp::build_panels(A->nrow, A->h_rowptr.data(), A->h_colidx.data(), A->h_val.data(), 8, &h);
+    crp::build_panels(A->nrow, A->h_rowptr.data(), A->h_colidx.data(), A->h_val.data(), 8, &h, false);
     crp::TeamHost th;
     crp::build_teams(h, A->nrow, A->h_rowptr.data(), A->h_colidx.data(), &th);
     t.nteam = th.nteam;
@@ -122,6 +136,16 @@ static int ensure_team(crp_csr_dev *A)
     if (e == hipSuccess) e = up((void **) &t.tptr, th.tptr.data(), sizeof(int) * th.tptr.size(), 4);
     if (e == hipSuccess) e = up((void **) &t.tcol, th.tcol.data(), sizeof(int) * th.tcol.size(), 256);
     if (e == hipSuccess) e = up((void **) &t.tmask, th.tmask.data(), sizeof(uint32_t) * th.tmask.size(), 256);
+    // value streams and the update map, from the panel format's values and slot map
+    const long long nent = th.tvoff.back();
+    std::vector<double> tval((size_t) nent * 8, 0.0);
+    for (size_t q = 0; q < th.tq.size(); q++)
+        if (th.tq[q] >= 0) memcpy(&tval[(size_t) th.tq[q] * 8], &h.pval[q * 8], sizeof(double) * 8);
+    std::vector<uint32_t> tmap(h.pmap.size());
+    for (size_t pz = 0; pz < h.pmap.size(); pz++) tmap[pz] = (uint32_t) (th.tq[h.pmap[pz] >> 3] * 8 + (h.pmap[pz] & 7));
+    if (e == hipSuccess) e = up((void **) &t.tvoff, th.tvoff.data(), sizeof(long long) * th.tvoff.size(), 8);
+    if (e == hipSuccess) e = up((void **) &t.tval, tval.data(), sizeof(double) * tval.size(), 1024);
+    if (e == hipSuccess) e = up((void **) &t.tmap, tmap.data(), sizeof(uint32_t) * tmap.size(), 4);
     if (e != hipSuccess) return (int) e;
     t.built = true;
     return 0;
@@ -351,6 +375,7 @@ int crp_csr_dev_destroy(crp_csr_dev_p *A_)
     {
         if (A->pan[i].pptr) (void) hipFree(A->pan[i].pptr);
         if (A->pan[i].porder) (void) hipFree(A->pan[i].porder);
+        if (A->pan[i].psync) (void) hipFree(A->pan[i].psync);
         if (A->pan[i].pcol) (void) hipFree(A->pan[i].pcol);
         if (A->pan[i].pmask4) (void) hipFree(A->pan[i].pmask4);
         if (A->pan[i].pmap) (void) hipFree(A->pan[i].pmap);
@@ -361,6 +386,9 @@ int crp_csr_dev_destroy(crp_csr_dev_p *A_)
     if (A->team.tptr) (void) hipFree(A->team.tptr);
     if (A->team.tcol) (void) hipFree(A->team.tcol);
     if (A->team.tmask) (void) hipFree(A->team.tmask);
+    if (A->team.tvoff) (void) hipFree(A->team.tvoff);
+    if (A->team.tval) (void) hipFree(A->team.tval);
+    if (A->team.tmap) (void) hipFree(A->team.tmap);
     if (A->rowptr) (void) hipFree(A->rowptr);
     if (A->colidx) (void) hipFree(A->colidx);
     if (A->val) (void) hipFree(A->val);
@@ -382,6 +410,7 @@ int crp_csr_dev_update_values(crp_csr_dev_p A, const double *val, void *stream)
     for (int i = 0; i < 2; i++)
         if (A->pan[i].built)
             CRP_TRY(crp::scatter_vals_f64(A->nnz, A->pan[i].pmap, A->val, A->pan[i].pval, (hipStream_t) stream));
+    if (A->team.built) CRP_TRY(crp::scatter_vals_f64(A->nnz, A->team.tmap, A->val, A->team.tval, (hipStream_t) stream));
     return 0;
 }
 
@@ -437,7 +466,7 @@ int crp_spmm_csr_f64(crp_csr_dev_p A, int layout, int n, const double *B0, long 
         if (rc != 0) return rc;
         crp::TeamArgs t;
         t.nteam = A->team.nteam; t.torder = A->team.torder; t.tpanel = A->team.tpanel; t.tptr = A->team.tptr;
-        t.tcol = A->team.tcol; t.tmask = A->team.tmask; t.pptr = A->pan[1].pptr; t.pval = A->pan[1].pval;
+        t.tcol = A->team.tcol; t.tmask = A->team.tmask; t.tvoff = A->team.tvoff; t.tval = A->team.tval;
         return (int) crp::spmm_rm_f64_team(t, a, (hipStream_t) stream);
     }
     if (v >= 2)
@@ -447,7 +476,7 @@ int crp_spmm_csr_f64(crp_csr_dev_p A, int layout, int n, const double *B0, long 
         const PanelDev &d = A->pan[v - 2];
         crp::PanelArgs p;
         memset(&p, 0, sizeof(p));
-        p.R = d.R; p.npanel = d.npanel; p.pptr = d.pptr; p.porder = d.porder; p.pcol = d.pcol; p.pmask4 = d.pmask4; p.pval = d.pval;
+        p.R = d.R; p.npanel = d.npanel; p.pptr = d.pptr; p.porder = d.porder; p.norder = d.norder; p.psync = d.psync; p.pcol = d.pcol; p.pmask4 = d.pmask4; p.pval = d.pval;
         p.b0_rows = A->b0_rows; p.b1_rows = A->b1_rows;
         e = crp::spmm_rm_f64_panel(p, a, (hipStream_t) stream);
     }
@@ -459,7 +488,7 @@ int crp_csr_dev_auto_variant(crp_csr_dev_p A) { return A ? A->auto_variant : -1;
 
 int crp_panel_format_host(int nrow, const int *rowptr, const int *colidx, const double *val, int R, int *npanel,
                           int **pptr, int **pcol, unsigned **pmask4, double **pval, long long *real_entries,
-                          int **porder)
+                          int **porder, int *norder)
 {
     if (nrow < 0 || rowptr == NULL || (R != 4 && R != 8) || !npanel || !pptr || !pcol || !pmask4 || !pval) return -1;
     crp::PanelHost h;
@@ -474,11 +503,36 @@ int crp_panel_format_host(int nrow, const int *rowptr, const int *colidx, const 
     memcpy(*pmask4, h.pmask4.data(), sizeof(unsigned) * h.pmask4.size());
     if (!h.pval.empty()) memcpy(*pval, h.pval.data(), sizeof(double) * h.pval.size());
     if (real_entries) *real_entries = h.real_entries;
+    if (norder) *norder = (int) h.porder.size();
     if (porder)
     {
         *porder = (int *) malloc(sizeof(int) * (h.porder.size() + 1));
         if (!h.porder.empty()) memcpy(*porder, h.porder.data(), sizeof(int) * h.porder.size());
     }
+    return 0;
+}
+
+int crp_team_format_host(int nrow, const int *rowptr, const int *colidx, const double *val, int *nteam, int *lattice,
+                         int **tpanel, int **tptr, int **tcol, unsigned **tmask, int **torder)
+{
+    if (nrow < 0 || rowptr == NULL || !nteam || !tpanel || !tptr || !tcol || !tmask || !torder) return -1;
+    crp::PanelHost h;
+    crp::build_panels(nrow, rowptr, colidx, val, 8, &h, false);
+    crp::TeamHost th;
+    crp::build_teams(h, nrow, rowptr, colidx, &th);
+    *nteam = th.nteam;
+    if (lattice) *lattice = th.lattice ? 1 : 0;
+    auto dup_i = [](const std::vector<int> &v) {
+        int *p = (int *) malloc(sizeof(int) * (v.size() + 1));
+        if (!v.empty()) memcpy(p, v.data(), sizeof(int) * v.size());
+        return p;
+    };
+    *tpanel = dup_i(th.tpanel);
+    *tptr = dup_i(th.tptr);
+    *tcol = dup_i(th.tcol);
+    *torder = dup_i(th.torder);
+    *tmask = (unsigned *) malloc(sizeof(unsigned) * (th.tmask.size() + 1));
+    if (!th.tmask.empty()) memcpy(*tmask, th.tmask.data(), sizeof(unsigned) * th.tmask.size());
     return 0;
 }
 

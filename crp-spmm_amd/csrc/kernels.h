@@ -27,7 +27,9 @@ struct PanelArgs
     int R;
     int npanel;
     const int      *pptr;
-    const int      *porder;    // processing order of the panels
+    const int      *porder;    // processing order of the panels (norder positions; -1 = no panel)
+    int             norder;
+    const int      *psync;     // per workgroup (4 positions): rounds that start at a barrier, or nullptr
     const int      *pcol;
     const uint32_t *pmask4;
     const double   *pval;
@@ -43,8 +45,8 @@ struct TeamArgs
     const int      *tptr;
     const int      *tcol;
     const uint32_t *tmask;
-    const int      *pptr;      // of the R = 8 panel format the teams are built on
-    const double   *pval;
+    const long long *tvoff;    // 4 * nteam: first entry of every wave's value stream
+    const double   *tval;      // value streams, 8 values per own entry
 };
 
 // spmm_kernels.hip

@@ -95,7 +95,8 @@ long long count_panel_entries(int nrow, const int *rowptr, const int *colidx, in
     return tot;
 }
 
-void build_panels(int nrow, const int *rowptr, const int *colidx, const double *val, int R, PanelHost *out)
+void build_panels(int nrow, const int *rowptr, const int *colidx, const double *val, int R, PanelHost *out,
+                  bool team_schedule)
 {
     const int npanel = (nrow + R - 1) / R;
     out->R = R;
@@ -150,16 +151,31 @@ void build_panels(int nrow, const int *rowptr, const int *colidx, const double *
             for (; q < qend; q++) out->pcol[q] = last_col;   // padding: valid address, mask 0
         }
     });
-    // processing order.  CRPSPMM_PANEL_ORDER: 0 natural, 1 breadth-first groups, 2 stride lattice when the
-    // matrix has one (else natural); unset = stride lattice when detected, else breadth-first groups.
+    // processing order.  CRPSPMM_PANEL_ORDER: 0 natural, 1 breadth-first groups, 2 stride lattice of panels,
+    // 3 team schedule (2 and 3 only when the matrix has a stride lattice, else natural); unset = team
+    // schedule (R = 8) or panel lattice (R = 4) when a lattice is detected, else breadth-first groups.
     // CRPSPMM_PANEL_GROUP = panels per breadth-first group.
     const char *eo = getenv("CRPSPMM_PANEL_ORDER"), *eg = getenv("CRPSPMM_PANEL_GROUP");
     const int group = (eg && atoi(eg) > 0) ? atoi(eg) : 16;
     const int mode = eo ? atoi(eo) : -1;
     const int chunk = ((((npanel + 3) / 4) + 7) / 8) * 4;      // order positions per XCD (the kernels' block -> XCD map)
     bool done = false;
-    if (mode == 2 || mode == -1) done = stride_lattice_order(nrow, rowptr, colidx, R, npanel, chunk, &out->porder);
-    if (!done && (mode == 0 || mode == 2))
+    out->psync.clear();
+    if ((mode == 3 || mode == -1) && R == 8 && team_schedule && npanel >= 64)
+    {
+        double D1, D2;
+        int M;
+        if (detect_stride_lattice(nrow, rowptr, colidx, R, &D1, &D2, &M))
+        {
+            TeamHost th;
+            build_teams(*out, nrow, rowptr, colidx, &th);
+            apply_team_schedule(out, th);
+            done = true;
+        }
+    }
+    if (!done && (mode == 2 || mode == 3 || mode == -1))
+        done = stride_lattice_order(nrow, rowptr, colidx, R, npanel, chunk, &out->porder);
+    if (!done && (mode == 0 || mode == 2 || mode == 3))
     {
         out->porder.resize((size_t) npanel);
         for (int i = 0; i < npanel; i++) out->porder[(size_t) i] = i;
@@ -167,7 +183,7 @@ void build_panels(int nrow, const int *rowptr, const int *colidx, const double *
     }
     if (!done) locality_order(*out, group, &out->porder);
     // experiment hook: a processing order read from a file of npanel int32 (must be a permutation)
-    if (const char *ef = getenv("CRPSPMM_PANEL_ORDER_FILE"))
+    if (const char *ef = getenv("CRPSPMM_PANEL_ORDER_FILE"); ef != NULL && out->psync.empty())
     {
         std::vector<int> perm((size_t) npanel);
         FILE *f = fopen(ef, "rb");
@@ -427,6 +443,7 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
     std::vector<int> cnt((size_t) nteam, 0);
     std::vector<std::vector<int>> ucol((size_t) nteam);
     std::vector<std::vector<uint32_t>> umask((size_t) nteam);
+    std::vector<std::vector<int>> usrc((size_t) nteam);
     parallel_chunks(nteam, 64, [&](long long b, long long e, int) {
         for (long long g = b; g < e; g++)
         {
@@ -440,6 +457,11 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
             }
             std::vector<int> &uc = ucol[(size_t) g];
             std::vector<uint32_t> &um = umask[(size_t) g];
+            std::vector<int> &us = usrc[(size_t) g];       // per union entry: panel entry of wave 0..3 (or -1)
+            // Nodes: the union of the four entry lists, equal (column, occurrence) keys merged.
+            struct Node { int col; uint32_t mask; int src[4]; int users; bool done; };
+            std::vector<Node> nodes;
+            std::vector<int> list[4];                       // node ids of every wave, in column order
             for (;;)
             {
                 bool any = false;
@@ -452,8 +474,9 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
                         any = true;
                     }
                 if (!any) break;
-                uint32_t m = 0;
-                int col = 0;
+                Node nd;
+                nd.col = 0; nd.mask = 0; nd.users = 0; nd.done = false;
+                for (int w = 0; w < 4; w++) nd.src[w] = -1;
                 for (int w = 0; w < 4; w++)
                     if (head[w] < end[w])
                     {
@@ -461,13 +484,61 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
                         const uint64_t k = ((uint64_t) col_key(c) << 8) | (uint64_t) occ[w];
                         if (k != best) continue;
                         const int q = head[w];
-                        m |= ((p.pmask4[(size_t) q >> 2] >> (8 * (q & 3))) & 0xFFu) << (8 * w);
-                        col = c;
+                        nd.mask |= ((p.pmask4[(size_t) q >> 2] >> (8 * (q & 3))) & 0xFFu) << (8 * w);
+                        nd.col = c;
+                        nd.src[w] = q;
+                        nd.users++;
+                        list[w].push_back((int) nodes.size());
                         head[w]++;
                         occ[w] = (head[w] < end[w] && p.pcol[(size_t) head[w]] == c) ? occ[w] + 1 : 0;
                     }
-                uc.push_back(col);
-                um.push_back(m);
+                nodes.push_back(nd);
+            }
+            // Rounds of 8 union entries end at a barrier, so a round costs what its busiest wave
+            // costs; a wave's columns are clustered, and in column order the four waves would work
+            // one after the other.  The order inside a team is free (a row's products are summed in
+            // the order its wave meets them), so the slots are dealt out: each slot goes to the wave
+            // that has the least in this round (most left overall), which takes its first open
+            // shared node if that does not overload a partner, else its first open private node.
+            int remaining[4], cursor[4] = {0, 0, 0, 0};
+            for (int w = 0; w < 4; w++) remaining[w] = (int) list[w].size();
+            size_t left = nodes.size();
+            while (left > 0)
+            {
+                int rc[4] = {0, 0, 0, 0};
+                for (int slot = 0; slot < PANEL_PAD && left > 0; slot++)
+                {
+                    int ws = -1;
+                    for (int w = 0; w < 4; w++)
+                    {
+                        if (remaining[w] == 0) continue;
+                        if (ws < 0 || rc[w] < rc[ws] || (rc[w] == rc[ws] && remaining[w] > remaining[ws])) ws = w;
+                    }
+                    while (cursor[ws] < (int) list[ws].size() && nodes[(size_t) list[ws][(size_t) cursor[ws]]].done) cursor[ws]++;
+                    int pick = -1, first_private = -1, first_any = -1;
+                    for (int t = cursor[ws], seen = 0; t < (int) list[ws].size() && seen < 64; t++)
+                    {
+                        const int id = list[ws][(size_t) t];
+                        const Node &nd = nodes[(size_t) id];
+                        if (nd.done) continue;
+                        seen++;
+                        if (first_any < 0) first_any = id;
+                        if (nd.users == 1) { if (first_private < 0) first_private = id; continue; }
+                        bool fits = true;
+                        for (int u = 0; u < 4; u++)
+                            if (u != ws && nd.src[u] >= 0 && rc[u] > rc[ws]) fits = false;
+                        if (fits) { pick = id; break; }
+                    }
+                    if (pick < 0) pick = first_private >= 0 ? first_private : first_any;
+                    Node &nd = nodes[(size_t) pick];
+                    nd.done = true;
+                    left--;
+                    for (int u = 0; u < 4; u++)
+                        if (nd.src[u] >= 0) { rc[u]++; remaining[u]--; }
+                    uc.push_back(nd.col);
+                    um.push_back(nd.mask);
+                    for (int u = 0; u < 4; u++) us.push_back(nd.src[u]);
+                }
             }
             cnt[(size_t) g] = (int) uc.size();
         }
@@ -496,6 +567,30 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
         for (; q < (size_t) out->tptr[(size_t) g + 1]; q++) out->tcol[q] = last;      // padding: valid row, no reader
     }
 
+    out->tsrc.assign(total * 4, -1);
+    for (int g = 0; g < nteam; g++)
+        memcpy(&out->tsrc[(size_t) out->tptr[(size_t) g] * 4], usrc[(size_t) g].data(), sizeof(int) * usrc[(size_t) g].size());
+
+    // value streams: wave w of team g reads 8 values per own entry from tvoff[4g + w] on, in the
+    // order it meets its entries; tq = where every entry of the panel format went
+    out->tvoff.assign((size_t) nteam * 4 + 1, 0);
+    out->tq.assign(p.pcol.size(), -1);
+    {
+        long long run = 0;
+        for (int g = 0; g < nteam; g++)
+            for (int w = 0; w < 4; w++)
+            {
+                out->tvoff[(size_t) g * 4 + w] = run;
+                const std::vector<int> &us = usrc[(size_t) g];
+                for (size_t t = 0; t < us.size() / 4; t++)
+                {
+                    const int q = us[t * 4 + (size_t) w];
+                    if (q >= 0) out->tq[(size_t) q] = run++;
+                }
+            }
+        out->tvoff[(size_t) nteam * 4] = run;
+    }
+
     // processing order: XCD blocks of neighbouring team columns swept in lockstep along t (lattice),
     // else the natural order
     out->torder.resize((size_t) nteam);
@@ -516,6 +611,53 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
                 return x < y;
             });
         }
+    }
+}
+
+void apply_team_schedule(PanelHost *p, const TeamHost &t)
+{
+    const int R = p->R;
+    std::vector<int> ncol(p->pcol.size());
+    std::vector<uint32_t> nmask4(p->pmask4.size(), 0u);
+    std::vector<double> nval(p->pval.size(), 0.0);
+    std::vector<long long> moved(p->pcol.size(), -1);        // old entry -> new entry
+    auto mask_of = [&](size_t q) { return (p->pmask4[q >> 2] >> (8 * (q & 3))) & 0xFFu; };
+    for (int g = 0; g < t.nteam; g++)
+        for (int w = 0; w < 4; w++)
+        {
+            const int panel = t.tpanel[(size_t) g * 4 + w];
+            if (panel < 0) continue;
+            size_t dst = (size_t) p->pptr[panel];
+            int last = 0;
+            for (int q = t.tptr[(size_t) g]; q < t.tptr[(size_t) g + 1]; q++)
+            {
+                const int src = t.tsrc[(size_t) q * 4 + w];
+                if (src < 0) continue;
+                ncol[dst] = p->pcol[(size_t) src];
+                nmask4[dst >> 2] |= mask_of((size_t) src) << (8 * (dst & 3));
+                memcpy(&nval[dst * R], &p->pval[(size_t) src * R], sizeof(double) * R);
+                moved[(size_t) src] = (long long) dst;
+                last = ncol[dst];
+                dst++;
+            }
+            for (; dst < (size_t) p->pptr[panel + 1]; dst++) ncol[dst] = last;       // padding: valid row, mask 0
+        }
+    for (uint32_t &slot : p->pmap) slot = (uint32_t) (moved[slot / R] * R + slot % R);
+    p->pcol.swap(ncol);
+    p->pmask4.swap(nmask4);
+    p->pval.swap(nval);
+    p->porder.assign((size_t) t.nteam * 4, -1);
+    p->psync.assign((size_t) t.nteam, 0);
+    for (int pos = 0; pos < t.nteam; pos++)
+    {
+        int minnr = 1 << 30;
+        for (int w = 0; w < 4; w++)
+        {
+            const int panel = t.tpanel[(size_t) t.torder[(size_t) pos] * 4 + w];
+            p->porder[(size_t) pos * 4 + w] = panel;
+            if (panel >= 0) minnr = std::min(minnr, (p->pptr[panel + 1] - p->pptr[panel]) / PANEL_PAD);
+        }
+        p->psync[(size_t) pos] = (minnr == (1 << 30) || minnr < 2) ? 0 : minnr - 1;
     }
 }
 

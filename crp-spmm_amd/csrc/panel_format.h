@@ -29,7 +29,8 @@ struct PanelHost
     std::vector<uint32_t> pmask4;  // entries / 4 words: byte u of word g = mask of entry 4g + u
     std::vector<double>   pval;    // entries * R, value of row r of entry q at q*R + r
     std::vector<uint32_t> pmap;    // nnz: slot (q*R + r) in pval of CSR nonzero p (for value updates)
-    std::vector<int>      porder;  // npanel: processing order of the panels (locality_order())
+    std::vector<int>      porder;  // processing order of the panels (npanel positions; team schedule: 4 per team, -1 = none)
+    std::vector<int>      psync;   // team schedule only: per workgroup, the rounds its waves start together
     long long real_entries = 0;    // entries before padding
     double fill() const;           // nnz / (real_entries * R)
     long long nnz = 0;
@@ -66,9 +67,10 @@ void lattice_coords(int panel, int R, double D1, double D2, int M, int *i, int *
 // same offset t -- the panels that read a B row through their near band and through their far
 // bands sit in one team, so that row crosses L2 once instead of three times; otherwise four
 // consecutive panels.  The union of the four panels' columns is stored once (tcol), with one mask
-// word per union entry: byte w = row mask of wave w (0 = wave w does not use the column).  Wave w
-// walks its own panel's values (PanelHost::pval) in its own entry order, which is the order its
-// entries appear in the union.
+// word per union entry: byte w = row mask of wave w (0 = wave w does not use the column).  The
+// order of the union entries is a balanced schedule, not column order (see build_teams); wave w
+// reads the 8 values of its k-th own entry from the value stream starting at entry tvoff[4g + w]
+// (tq maps every entry of the panel format to its place in the streams).
 struct TeamHost
 {
     int nteam = 0;
@@ -78,14 +80,27 @@ struct TeamHost
     std::vector<int>      tcol;    // union entries: column index
     std::vector<uint32_t> tmask;   // union entries: 4 row masks
     std::vector<int>      torder;  // processing order of the teams
+    std::vector<long long> tvoff;  // 4 * nteam + 1: first entry of wave w's value stream
+    std::vector<long long> tq;     // per panel-format entry: its entry index in the value streams, or -1
+    std::vector<int>      tsrc;    // 4 per union entry: the panel-format entry of wave w behind it, or -1
     long long real_entries = 0;    // union entries before padding
 };
 void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *colidx, TeamHost *out);
+
+// Team schedule for the row-panel kernel itself (no LDS sharing): the entries of every panel are
+// re-ordered to the order in which its wave meets them in the team's balanced schedule, and the
+// processing order becomes team after team, four positions per team (-1 where a team has no
+// panel for a wave).  The four waves of a workgroup then reach an entry they share after the same
+// number of own entries, i.e. at nearly the same time, and the later ones find the row in L2.
+void apply_team_schedule(PanelHost *p, const TeamHost &t);
 
 // Number of panel entries (before padding) a given R would need: cheap pass used
 // to pick R.  colidx may carry the two-source encoding.
 long long count_panel_entries(int nrow, const int *rowptr, const int *colidx, int R);
 
-void build_panels(int nrow, const int *rowptr, const int *colidx, const double *val, int R, PanelHost *out);
+// team_schedule = false keeps the entries of every panel in column order whatever CRPSPMM_PANEL_ORDER
+// says (the team format is built on that order).
+void build_panels(int nrow, const int *rowptr, const int *colidx, const double *val, int R, PanelHost *out,
+                  bool team_schedule = true);
 
 }  // namespace crp

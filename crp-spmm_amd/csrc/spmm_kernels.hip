@@ -376,11 +376,11 @@ __device__ __forceinline__ void panel_consume1(const typename SlotT<VW>::type (&
 // slot, with round r + DEPTH while it is consumed, so 8*DEPTH - 1 entries stay in flight.
 template <int R, int NV, int VW, int DEPTH, bool ADDR64, bool HAS_B1>
 __global__ __launch_bounds__(256) void spmm_panel_f64_kernel(
-    const int npanel, const int nrow, const int n, const int *__restrict__ porder,
+    const int norder, const int nrow, const int n, const int *__restrict__ porder,
     const int *__restrict__ pptr, const int *__restrict__ pcol, const uint32_t *__restrict__ pmask4,
     const double *__restrict__ pval,
     const double *__restrict__ B0, const int64_t ldB0, const double *__restrict__ B1, const int64_t ldB1,
-    double *__restrict__ C, const int64_t ldC, const int *__restrict__ rowmap)
+    double *__restrict__ C, const int64_t ldC, const int *__restrict__ rowmap, const int *__restrict__ psync)
 {
     constexpr int TW = 64 * VW * NV;
     constexpr int RING = PANEL_RING;             // entries per round = slots per ring set
@@ -400,8 +400,19 @@ __global__ __launch_bounds__(256) void spmm_panel_f64_kernel(
     const int cpx   = (gridDim.x + 7) >> 3;
     const int wg    = (blockIdx.x & 7) * cpx + (blockIdx.x >> 3);
     const int slot_id = __builtin_amdgcn_readfirstlane((int) (wg * 4 + wave));
-    if (slot_id >= npanel) return;
-    const int panel = porder[slot_id];       // which panel this wave computes (locality order)
+    if (slot_id >= norder) return;
+    const int panel = porder[slot_id];       // which panel this wave computes (processing order; -1: none)
+    // team schedule: the four waves of the workgroup meet at a barrier before each of the first nb
+    // rounds (nb < the rounds of every panel of the team), so that they reach shared B rows together
+#ifndef CRP_TEAM_SYNC_K
+#define CRP_TEAM_SYNC_K 1
+#endif
+    const int nb = psync ? psync[wg] : 0;
+    if (panel < 0)
+    {
+        for (int r = 0; r < nb; r += CRP_TEAM_SYNC_K) asm volatile("s_barrier" ::: "memory");
+        return;
+    }
     double *myvals = &lds_vals[__builtin_amdgcn_readfirstlane(wave)][0][0];
 
     const int col0 = blockIdx.y * TW + lane * VW;
@@ -538,7 +549,11 @@ __global__ __launch_bounds__(256) void spmm_panel_f64_kernel(
         int r = 0;
         if constexpr (DEPTH == 1)
         {
-            for (; r + 1 < nr; r++) round(r, std::integral_constant<int, 0>{}, std::true_type{});
+            for (; r + 1 < nr; r++)
+            {
+                if (r < nb && (r % CRP_TEAM_SYNC_K) == 0) asm volatile("s_barrier" ::: "memory");
+                round(r, std::integral_constant<int, 0>{}, std::true_type{});
+            }
             round(r, std::integral_constant<int, 0>{}, std::false_type{});
         }
         else
@@ -592,10 +607,10 @@ template <int R, int NV, int VW, int DEPTH, bool ADDR64, bool HAS_B1>
 static hipError_t launch_panel(const PanelArgs &p, const SpmmArgs &a, hipStream_t s)
 {
     constexpr int TW = 64 * VW * NV;
-    const int nwg = (p.npanel + 3) / 4;
+    const int nwg = (p.norder + 3) / 4;
     dim3 grid((nwg + 7) / 8 * 8, (a.n + TW - 1) / TW);      // multiple of 8 for the XCD remap
-    hipLaunchKernelGGL((spmm_panel_f64_kernel<R, NV, VW, DEPTH, ADDR64, HAS_B1>), grid, dim3(256), 0, s, p.npanel, a.nrow, a.n,
-                       p.porder, p.pptr, p.pcol, p.pmask4, p.pval, a.B0, a.ldB0, a.B1, a.ldB1, a.C, a.ldC, a.rowmap);
+    hipLaunchKernelGGL((spmm_panel_f64_kernel<R, NV, VW, DEPTH, ADDR64, HAS_B1>), grid, dim3(256), 0, s, p.norder, a.nrow, a.n,
+                       p.porder, p.pptr, p.pcol, p.pmask4, p.pval, a.B0, a.ldB0, a.B1, a.ldB1, a.C, a.ldC, a.rowmap, p.psync);
     return hipGetLastError();
 }
 
@@ -613,9 +628,11 @@ static hipError_t launch_panel_addr(const PanelArgs &p, const SpmmArgs &a, hipSt
     const bool deep = (env_depth == 2);
     if (deep && R == 8 && NV == 2 && VW == 2)
     {
+        PanelArgs q = p;
+        q.psync = nullptr;          // the two-set body has no team barriers
         if (small)
-            return has_b1 ? launch_panel<R, NV, VW, 2, false, true>(p, a, s) : launch_panel<R, NV, VW, 2, false, false>(p, a, s);
-        return has_b1 ? launch_panel<R, NV, VW, 2, true, true>(p, a, s) : launch_panel<R, NV, VW, 2, true, false>(p, a, s);
+            return has_b1 ? launch_panel<R, NV, VW, 2, false, true>(q, a, s) : launch_panel<R, NV, VW, 2, false, false>(q, a, s);
+        return has_b1 ? launch_panel<R, NV, VW, 2, true, true>(q, a, s) : launch_panel<R, NV, VW, 2, true, false>(q, a, s);
     }
     if (small)
         return has_b1 ? launch_panel<R, NV, VW, 1, false, true>(p, a, s) : launch_panel<R, NV, VW, 1, false, false>(p, a, s);
@@ -654,22 +671,44 @@ hipError_t spmm_rm_f64_panel(const PanelArgs &p, const SpmmArgs &a, hipStream_t 
 // of the following TEAM_D - 1 rounds stay in flight), after it the set is readable by all and the
 // set consumed in the previous round is free for the round issued next.  A wave then takes the
 // entries whose mask byte names it: slice from the ring (2 x ds_read_b128), its 8 values from its
-// own LDS value buffer (filled by LDS-DMA too, 16 entries = 1 KiB per chunk, double buffered),
-// masked FMAs as in the row-panel kernel -- per row the same products in the same order.
+// own LDS value buffer (the wave's value stream arrives by LDS-DMA too, 16 entries = 1 KiB per
+// chunk, double buffered: scalar loads one entry ahead were tried and stall for the full memory
+// latency under load), masked FMAs as in the row-panel kernel.  The union is walked in a balanced schedule,
+// not in column order, so a row's products are summed in the order the team meets them.
 // Columns: 256-wide tile (16 B per lane x 2), n in (128, 256], operands 16-byte aligned.
 // ---------------------------------------------------------------------------
 constexpr int TEAM_D = 3;
 constexpr int TEAM_NSET = TEAM_D + 1;
 constexpr int TEAM_RING_BYTES = TEAM_NSET * 8 * 2048;
-constexpr int TEAM_LDS_BYTES = TEAM_RING_BYTES + 4 * 2 * 1024;
+constexpr int TEAM_LDS_BYTES = TEAM_RING_BYTES + 4 * 2 * 1024;      // + two 1 KiB value buffers per wave
 
 #define CRP_GPTR(p) ((const __attribute__((address_space(1))) void *) (p))
 #define CRP_LPTR(p) ((__attribute__((address_space(3))) void *) (p))
 
+// acc[v][w] += a * slot[v][w] when bit BIT of the mask is set; `a` lives in SGPRs (it came by a
+// scalar load: the 8 values of an entry are wave-uniform)
+template <int BIT>
+__device__ __forceinline__ void fmac_row_masked_s(double (&acc)[2][2], const double a, const d2 (&slot)[2], const uint32_t mask)
+{
+    asm volatile("s_bitcmp0_b32 %9, %10\n\ts_cbranch_scc1 1f\n\t"
+                 "v_fmac_f64 %0, %4, %5\n\tv_fmac_f64 %1, %4, %6\n\t"
+                 "v_fmac_f64 %2, %4, %7\n\tv_fmac_f64 %3, %4, %8\n1:"
+                 : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1])
+                 : "s"(a), "v"(slot[0].x), "v"(slot[0].y), "v"(slot[1].x), "v"(slot[1].y), "s"(mask), "n"(BIT)
+                 : "scc");
+}
+
+template <int BIT = 0>
+__device__ __forceinline__ void fmac_rows_s(double (&acc)[8][2][2], const double (&a)[8], const d2 (&slot)[2], const uint32_t mask)
+{
+    fmac_row_masked_s<BIT>(acc[BIT], a[BIT], slot, mask);
+    if constexpr (BIT + 1 < 8) fmac_rows_s<BIT + 1>(acc, a, slot, mask);
+}
+
 __global__ __launch_bounds__(256) void spmm_team_f64_kernel(
     const int nteam, const int nrow, const int n, const int *__restrict__ torder, const int *__restrict__ tpanel,
     const int *__restrict__ tptr, const int *__restrict__ tcol, const uint32_t *__restrict__ tmask,
-    const int *__restrict__ pptr, const double *__restrict__ pval,
+    const long long *__restrict__ tvoff, const double *__restrict__ tval,
     const double *__restrict__ B0, const int64_t ldB0, double *__restrict__ C, const int64_t ldC,
     const int *__restrict__ rowmap)
 {
@@ -691,10 +730,17 @@ __global__ __launch_bounds__(256) void spmm_team_f64_kernel(
     const char *Bb = reinterpret_cast<const char *>(B0);
     const int64_t ldbytes = ldB0 * 8;
     char *ring = team_lds;
-    char *vbuf = team_lds + TEAM_RING_BYTES + wave * 2048;     // this wave's two 1 KiB value buffers
-    const char *vsrc = reinterpret_cast<const char *>(pval + (int64_t) (panel >= 0 ? pptr[panel] : 0) * R) + lane * 16;
+    // this wave's value stream: 16 entries (1 KiB) per LDS-DMA chunk, two buffers
+    char *vbuf = team_lds + TEAM_RING_BYTES + wave * 2048;
+    const char *vsrc = reinterpret_cast<const char *>(tval + tvoff[team * 4 + wave] * R) + lane * 16;
+    auto issue_vals = [&](const int chunk) {
+        __builtin_amdgcn_global_load_lds(CRP_GPTR(vsrc + (int64_t) chunk * 1024), CRP_LPTR(vbuf + ((chunk & 1) << 10)), 16, 0, 0);
+    };
 
     auto issue_round = [&](const int r) {
+#if defined(CRP_TEAM_ABL) && CRP_TEAM_ABL == 2   // timing experiment: no B row is loaded
+        return;
+#endif
         const int qa = q0 + r * 8 + 2 * wave;
         const int c0 = tcol[qa], c1 = tcol[qa + 1];
         char *dst = ring + (((r % TEAM_NSET) * 8 + 2 * wave) << 11);
@@ -704,9 +750,6 @@ __global__ __launch_bounds__(256) void spmm_team_f64_kernel(
         __builtin_amdgcn_global_load_lds(CRP_GPTR(r1 + off0), CRP_LPTR(dst + 2048), 16, 0, 0);
         __builtin_amdgcn_global_load_lds(CRP_GPTR(r1 + off1), CRP_LPTR(dst + 3072), 16, 0, 0);
     };
-    auto issue_vals = [&](const int chunk) {                  // 16 own entries x 8 values = 1 KiB
-        __builtin_amdgcn_global_load_lds(CRP_GPTR(vsrc + (int64_t) chunk * 1024), CRP_LPTR(vbuf + ((chunk & 1) << 10)), 16, 0, 0);
-    };
 
     double acc[R][2][2];
 #pragma unroll
@@ -714,14 +757,14 @@ __global__ __launch_bounds__(256) void spmm_team_f64_kernel(
 #pragma unroll
         for (int v = 0; v < 2; v++) { acc[r][v][0] = 0.0; acc[r][v][1] = 0.0; }
 
-    // prologue: value chunks 0 and 1, then the first TEAM_D rounds of B rows
+    // prologue: value chunks 0 and 1 (the streams are padded: reading past a wave's last entry is
+    // harmless), then the first TEAM_D rounds of B rows
     issue_vals(0);
     issue_vals(1);
     int iss0 = -100, iss1 = -100;                             // round in which the chunk in buffer 0 / 1 was issued
 #pragma unroll
     for (int d = 0; d < TEAM_D; d++)
         if (d < nr) issue_round(d);
-
     int k = 0;                                                // own entries consumed so far
     for (int r = 0; r < nr; r++)
     {
@@ -730,13 +773,20 @@ __global__ __launch_bounds__(256) void spmm_team_f64_kernel(
         else wait_vmcnt<0>();
         asm volatile("s_barrier" ::: "memory");
         if (r + TEAM_D < nr) issue_round(r + TEAM_D);         // into the set consumed in round r - 1
-        const uint32_t *mk = tmask + q0 + r * 8;
+        // the round's 8 mask words in two aligned 16-byte scalar loads (tptr is a multiple of 8)
+        const uint4 mka = *reinterpret_cast<const uint4 *>(tmask + q0 + r * 8);
+        const uint4 mkb = *reinterpret_cast<const uint4 *>(tmask + q0 + r * 8 + 4);
+        const uint32_t mk[8] = {mka.x, mka.y, mka.z, mka.w, mkb.x, mkb.y, mkb.z, mkb.w};
         const char *setb = ring + ((r % TEAM_NSET) << 14) + lane * 16;
 #pragma unroll
         for (int e = 0; e < 8; e++)
         {
             const uint32_t m = (uint32_t) __builtin_amdgcn_readfirstlane((int) ((mk[e] >> (8 * wave)) & 0xFFu));
+#if defined(CRP_TEAM_ABL) && CRP_TEAM_ABL == 1   // timing experiment: nothing is consumed
+            if (false)
+#else
             if (m != 0)
+#endif
             {
                 const int kk = k & 15;
                 if (kk == 0 && k > 0)
@@ -812,7 +862,7 @@ hipError_t spmm_rm_f64_team(const TeamArgs &t, const SpmmArgs &a, hipStream_t s)
     }
     dim3 grid((t.nteam + 7) / 8 * 8);
     hipLaunchKernelGGL(spmm_team_f64_kernel, grid, dim3(256), TEAM_LDS_BYTES, s, t.nteam, a.nrow, a.n, t.torder, t.tpanel,
-                       t.tptr, t.tcol, t.tmask, t.pptr, t.pval, a.B0, a.ldB0, a.C, a.ldC, a.rowmap);
+                       t.tptr, t.tcol, t.tmask, t.tvoff, t.tval, a.B0, a.ldB0, a.C, a.ldC, a.rowmap);
     return hipGetLastError();
 }
 

@@ -92,19 +92,46 @@ def panel_format_host(rowptr, colidx, val, R):
     va = np.ascontiguousarray(val, dtype=np.float64)
     if ci.size == 0:
         ci, va = np.zeros(1, np.int32), np.zeros(1, np.float64)
-    npanel, ent = C.c_int(), C.c_longlong()
+    npanel, ent, nord = C.c_int(), C.c_longlong(), C.c_int()
     pptr, pcol, pmask, pval, pord = L.c_int_p(), L.c_int_p(), C.POINTER(C.c_uint)(), L.c_dbl_p(), L.c_int_p()
     L.check(lib.crp_panel_format_host(rp.size - 1, rp.ctypes.data_as(L.c_int_p), ci.ctypes.data_as(L.c_int_p),
                                       va.ctypes.data_as(L.c_dbl_p), R, C.byref(npanel), C.byref(pptr), C.byref(pcol),
-                                      C.byref(pmask), C.byref(pval), C.byref(ent), C.byref(pord)), "crp_panel_format_host")
+                                      C.byref(pmask), C.byref(pval), C.byref(ent), C.byref(pord), C.byref(nord)),
+            "crp_panel_format_host")
     P = npanel.value
     pp = np.ctypeslib.as_array(pptr, (P + 1,)).copy()
     tot = int(pp[P])
     out = dict(R=R, npanel=P, pptr=pp, real_entries=ent.value,
-               porder=np.ctypeslib.as_array(pord, (max(P, 1),))[:P].copy(),
+               porder=np.ctypeslib.as_array(pord, (max(nord.value, 1),))[:nord.value].copy(),
                pcol=np.ctypeslib.as_array(pcol, (max(tot, 1),))[:tot].copy(),
                pmask4=np.ctypeslib.as_array(pmask, (tot // 4 + 2,)).copy(),
                pval=np.ctypeslib.as_array(pval, (max(tot * R, 1),))[:tot * R].copy().reshape(tot, R))
     for p in (pptr, pcol, pmask, pval, pord):
         L.c_free(C.cast(p, C.c_void_p))
     return out
+
+
+def team_format_host(rowptr, colidx, val):
+    """crp_team_format_host -> dict(nteam, lattice, tpanel, tptr, tcol, tmask, torder)."""
+    lib = L.load()
+    rp = np.ascontiguousarray(rowptr, dtype=np.int32)
+    ci = np.ascontiguousarray(colidx, dtype=np.int32)
+    va = np.ascontiguousarray(val, dtype=np.float64)
+    if ci.size == 0:
+        ci, va = np.zeros(1, np.int32), np.zeros(1)
+    nteam, lat = C.c_int(), C.c_int()
+    tp, tt, tc, to = L.c_int_p(), L.c_int_p(), L.c_int_p(), L.c_int_p()
+    tm = C.POINTER(C.c_uint)()
+    L.check(lib.crp_team_format_host(rp.size - 1, rp.ctypes.data_as(L.c_int_p), ci.ctypes.data_as(L.c_int_p),
+                                     va.ctypes.data_as(L.c_dbl_p), C.byref(nteam), C.byref(lat), C.byref(tp), C.byref(tt),
+                                     C.byref(tc), C.byref(tm), C.byref(to)), "crp_team_format_host")
+    nt = nteam.value
+
+    def take(ptr, cnt, dt):
+        out = np.ctypeslib.as_array(ptr, (max(cnt, 1),))[:cnt].astype(dt).copy()
+        L.c_free(C.cast(ptr, C.c_void_p))
+        return out
+    tptr = take(tt, nt + 1, np.int32)
+    tot = int(tptr[-1]) if nt else 0
+    return dict(nteam=nt, lattice=bool(lat.value), tpanel=take(tp, 4 * nt, np.int32).reshape(nt, 4), tptr=tptr,
+                tcol=take(tc, tot, np.int32), tmask=take(tm, tot, np.uint32), torder=take(to, nt, np.int32))

@@ -101,18 +101,40 @@ int crp_csr_dev_auto_variant(crp_csr_dev_p A);
  * and return malloc'd copies (caller frees).  Panel p owns entries pptr[p] .. pptr[p+1]
  * (padded to multiples of 8 with mask-0 entries); entry q has column pcol[q] (two-source
  * encoding), row-presence mask byte (pmask4[q/4] >> 8*(q%4)) & 0xFF and values
- * pval[q*R .. q*R+R-1].  porder (optional) receives the order in which the kernel's waves take
- * the panels: groups of consecutive panels visited breadth-first over shared B rows (temporal
- * locality of B; CRPSPMM_PANEL_ORDER=0 disables, CRPSPMM_PANEL_GROUP sets the group size).
- * Used by the CPU tests of the format. */
+ * pval[q*R .. q*R+R-1].  The entries of a panel are in column order, except under the team schedule
+ * (below) where they are in the order the panel's wave meets them.
+ * porder (optional) receives the processing order: *norder positions, position s is the panel the
+ * s-th wave takes (4 consecutive positions = one workgroup), -1 = none.  Which order:
+ *   - matrices with two nested far strides (3D meshes in natural order), R = 8: the TEAM SCHEDULE --
+ *     the four waves of a workgroup take a 2 x 2 block of tooth-mate panels (panels that read the
+ *     same B rows through different bands), every panel's entries are re-ordered so that the four
+ *     waves reach a shared row after the same number of entries, and the workgroups sweep the
+ *     teeth in lockstep per XCD; norder = 4 * teams;
+ *   - the same matrices with R = 4: the stride-lattice order of single panels; norder = npanel;
+ *   - otherwise groups of consecutive panels visited breadth-first over shared B rows.
+ * CRPSPMM_PANEL_ORDER=0|1|2|3 forces natural / breadth-first / lattice / team schedule,
+ * CRPSPMM_PANEL_GROUP sets the breadth-first group size.  Used by the CPU tests of the format. */
 int crp_panel_format_host(int nrow, const int *rowptr, const int *colidx, const double *val, int R,
                           int *npanel, int **pptr, int **pcol, unsigned **pmask4, double **pval,
-                          long long *real_entries, int **porder);
+                          long long *real_entries, int **porder, int *norder);
+
+/* Host-only: the team format variant 4 ("team-R8") consumes, built on the R = 8 panels: team g owns
+ * panels tpanel[4g .. 4g+3] (-1 = none), one per wave of a workgroup, and union entries
+ * tptr[g] .. tptr[g+1] (padded to multiples of 8 with mask-0 entries): column tcol[q], and in
+ * tmask[q] byte w the row mask of wave w's panel for that column (0: wave w skips the entry).  Every
+ * wave meets its own panel's entries in that panel's own order.  torder = processing order of
+ * the teams; *lattice = 1 when the teams are 2 x 2 blocks of a stride lattice, 0 for four consecutive
+ * panels.  malloc'd copies (caller frees).  Used by the CPU tests of the format. */
+int crp_team_format_host(int nrow, const int *rowptr, const int *colidx, const double *val, int *nteam, int *lattice,
+                         int **tpanel, int **tptr, int **tcol, unsigned **tmask, int **torder);
 
 /* ---- the hot kernel --------------------------------------------------------
  * C[nrow x n] := A * B (alpha = 1, beta = 0; C is overwritten, never read),
  * the arithmetic of mkl_sparse_d_mm as called at src/rowpara_spmm.c:403-406:
- * C[i][j] = sum_p val[p] * B[col[p]][j], p ascending within the row.
+ * C[i][j] = sum_p val[p] * B[col[p]][j]; every product is formed once (absent pairs are skipped,
+ * never multiplied by zero) and a row's products are summed one after the other with FMAs -- in
+ * ascending p, except under the team schedule / variant 4 where the order is the team's schedule
+ * (fixed at create time, so repeated calls are bit-identical).
  * layout 0: B0/B1/C row-major (ld >= n); layout 1: column-major
  * (ldB0 >= rows of B0, ldB1 >= rows of B1, ldC >= nrow).  All pointers are
  * device pointers; the launch is asynchronous on `stream`.  `variant` picks a

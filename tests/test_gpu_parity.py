@@ -56,7 +56,7 @@ def test_kernel_vs_oracle_all_widths(crp, orc, gpu, n):
     rp, ci, va = gen.random_csr(m, k, 70, seed=n, empty_every=13)
     B = np.random.default_rng(n).uniform(-2, 2, size=(k, n))
     ref = orc.spmm_csr(rp, ci, va, B)
-    for variant in (0, 1, 2, 3):                       # auto, csr-rowgroup, rowpanel-R4, rowpanel-R8
+    for variant in (0, 1, 2, 3, 4):                    # auto, csr-rowgroup, rowpanel-R4, rowpanel-R8, team-R8
         for ldpad in (0, 1, 2):
             got = _spmm(crp, gpu, rp, ci, va, k, B, n, ldpad=ldpad, variant=variant)
             assert orc.rel_fro_err(ref, got) <= FP64_TOL, (n, ldpad, variant)
@@ -304,6 +304,48 @@ def test_b_block_beyond_4gib(crp, orc, gpu):
     torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("order", ["default", "0", "1", "2", "3", "3-free"])
+def test_lattice_matrix_team_paths(crp, orc, gpu, monkeypatch, order):
+    """A stride-lattice matrix (two nested far strides) through every processing order of the
+    row-panel kernels -- default = team schedule with the per-round workgroup barrier, "3-free" = the
+    same schedule free-running -- and through the LDS-sharing team kernel (variant 4), at widths on
+    both sides of its 256-column tile; then new values on the same pattern (both formats refresh)."""
+    import torch
+    from crp_spmm_amd import comm, engine, gen
+    if order == "3-free":
+        monkeypatch.setenv("CRPSPMM_PANEL_ORDER", "3")
+        monkeypatch.setenv("CRPSPMM_TEAM_SYNC", "0")
+    elif order != "default":
+        monkeypatch.setenv("CRPSPMM_PANEL_ORDER", order)
+    nx, ny, nz = 300, 7, 5
+    m = nx * ny * nz + 13                                      # ragged last tooth / partial teams
+    rp, ci, va = gen.banded_fem(m, offsets=(1, 2, 3, nx, nx + 1, nx * ny, nx * ny + 1), seed=3)
+    sc = comm.SelfComm()
+    for n in (256, 200, 64, 512):
+        B = np.random.default_rng(n).uniform(-1, 1, size=(m, n))
+        ref = orc.spmm_csr(rp, ci, va, B, fast=True)
+        e = engine.RpSpmm(0, m, rp, ci, va, [0, m], n, sc)
+        Bd, Cd = _t(B, gpu), torch.empty((m, n), dtype=torch.float64, device=gpu)
+        for variant in (3, 4, 2):
+            e.set_variant(variant)
+            Cd.fill_(float("nan"))
+            e.exec(0, Bd, Cd)
+            torch.cuda.synchronize()
+            assert orc.rel_fro_err(ref, Cd.cpu().numpy()) <= FP64_TOL, (order, n, variant)
+            first = Cd.clone()
+            e.exec(0, Bd, Cd)
+            torch.cuda.synchronize()
+            assert torch.equal(first, Cd), (order, n, variant, "not reproducible")
+        e.update_values(va * 3.0)
+        for variant in (3, 4):
+            e.set_variant(variant)
+            e.exec(0, Bd, Cd)
+            torch.cuda.synchronize()
+            assert orc.rel_fro_err(3.0 * ref, Cd.cpu().numpy()) <= FP64_TOL, (order, n, variant, "update_values")
+        e.free()
+    sc.free()
+
+
 def test_row_subset_matrices(crp, orc, gpu):
     """crp_csr_dev_set_rowmap: two row subsets of A write disjoint rows of one C; every kernel
     variant; the untouched rows keep their content."""
@@ -322,7 +364,7 @@ def test_row_subset_matrices(crp, orc, gpu):
     sel[2000::3] = True
     parts = [np.nonzero(sel)[0].astype(np.int32), np.nonzero(~sel)[0].astype(np.int32)]
     Bd = _t(B, gpu)
-    for variant in (1, 2, 3):
+    for variant in (1, 2, 3, 4):
         Cd = torch.full((m, n), -3.0, dtype=torch.float64, device=gpu)
         for pi, rows in enumerate(parts):
             cnt = (rp[rows + 1] - rp[rows]).astype(np.int64)

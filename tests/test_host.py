@@ -318,8 +318,9 @@ def test_panel_stride_lattice_order(crp, monkeypatch):
     m = nx * ny * nz
     rp, ci, va = gen.banded_fem(m, offsets=(1, 2, 3, nx, nx + 1, nx * ny, nx * ny + 1), seed=3)
     R = 8
-    monkeypatch.delenv("CRPSPMM_PANEL_ORDER", raising=False)
+    monkeypatch.setenv("CRPSPMM_PANEL_ORDER", "2")            # single panels on the lattice (what R = 4 gets by default)
     po = hip.panel_format_host(rp, ci, va, R)["porder"]
+    monkeypatch.delenv("CRPSPMM_PANEL_ORDER")
     npanel = (m + R - 1) // R
     assert np.array_equal(np.sort(po), np.arange(npanel))
     pos = np.empty_like(po)
@@ -340,6 +341,86 @@ def test_panel_stride_lattice_order(crp, monkeypatch):
     assert np.array_equal(hip.panel_format_host(rp1, ci1, va1, R)["porder"], np.arange(npanel))
     rp2, ci2, va2 = gen.erdos_renyi(8192, 8192, 12, seed=4)
     assert np.array_equal(hip.panel_format_host(rp2, ci2, va2, R)["porder"], np.arange(1024))
+
+
+def _expand_panels(f, R, B0, B1):
+    """C rows computed straight from a row-panel format (mask-selected rows, entry order)."""
+    got = np.zeros((f["npanel"] * R, B0.shape[1]))
+    for p in range(f["npanel"]):
+        for q in range(f["pptr"][p], f["pptr"][p + 1]):
+            mask = (int(f["pmask4"][q >> 2]) >> (8 * (q & 3))) & 0xFF
+            c = int(f["pcol"][q])
+            brow = B0[c] if c >= 0 else B1[~c]
+            for r in range(R):
+                if mask >> r & 1:
+                    got[p * R + r] += f["pval"][q, r] * brow
+    return got
+
+
+def test_team_schedule_and_team_format(crp, orc, monkeypatch):
+    """Stride-lattice matrix, R = 8 (the default there): workgroups of four tooth-mate panels.
+    The processing order has 4 positions per team (-1 = none) and covers every panel once; a
+    team's panels sit one stride apart; the re-ordered entries still expand to A * B; every wave
+    meets a column it shares with a team-mate after (nearly) the same number of its own entries.
+    The team format (variant 4) lists every panel entry exactly once per wave, in that same order."""
+    from crp_spmm_amd import gen, hip
+    nx, ny, nz = 600, 8, 4
+    m = nx * ny * nz
+    rp, ci, va = gen.banded_fem(m, offsets=(1, 2, 3, nx, nx + 1, nx * ny, nx * ny + 1), seed=3)
+    R = 8
+    npanel = (m + R - 1) // R
+    monkeypatch.delenv("CRPSPMM_PANEL_ORDER", raising=False)
+    f = hip.panel_format_host(rp, ci, va, R)
+    po = f["porder"]
+    assert po.size % 4 == 0 and po.size >= npanel
+    assert np.array_equal(np.sort(po[po >= 0]), np.arange(npanel))
+    teams = po.reshape(-1, 4)
+    full = teams[(teams >= 0).all(axis=1)]
+    assert full.shape[0] > 0.8 * teams.shape[0]
+    d1, d2 = nx / R, nx * ny / R
+    assert np.abs(np.median(full[:, 1] - full[:, 0]) - d1) <= 2 and np.abs(np.median(full[:, 2] - full[:, 0]) - d2) <= 2
+    n = 2
+    B0 = np.random.default_rng(1).normal(size=(m, n))
+    ref = orc.spmm_csr(rp, ci, va, B0)
+    assert orc.rel_fro_err(ref, _expand_panels(f, R, B0, B0)[:m]) <= 1e-14
+    # shared columns are met together: own-entry index of a shared column differs by a few entries at most
+    worst = []
+    for t in full[:200]:
+        pos = {}
+        for w, panel in enumerate(t):
+            cols = f["pcol"][f["pptr"][panel]:f["pptr"][panel + 1]]
+            msk = [(int(f["pmask4"][q >> 2]) >> (8 * (q & 3))) & 0xFF for q in range(f["pptr"][panel], f["pptr"][panel + 1])]
+            for k_, (c, mk) in enumerate(zip(cols, msk)):
+                if mk:
+                    pos.setdefault(int(c), []).append(k_)
+        worst += [max(v) - min(v) for v in pos.values() if len(v) > 1]
+    assert len(worst) > 0 and np.percentile(worst, 95) <= 6, np.percentile(worst, [50, 95, 100])
+    # natural-order format for comparison: same matrix, CRPSPMM_PANEL_ORDER=0
+    monkeypatch.setenv("CRPSPMM_PANEL_ORDER", "0")
+    f0 = hip.panel_format_host(rp, ci, va, R)
+    assert np.array_equal(f0["porder"], np.arange(npanel))
+    monkeypatch.delenv("CRPSPMM_PANEL_ORDER")
+
+    t = hip.team_format_host(rp, ci, va)
+    assert t["lattice"] and np.array_equal(np.sort(t["tpanel"][t["tpanel"] >= 0]), np.arange(npanel))
+    assert (t["tptr"] % 8 == 0).all() and np.array_equal(np.sort(t["torder"]), np.arange(t["nteam"]))
+    for g in range(0, t["nteam"], 37):
+        for w in range(4):
+            panel = t["tpanel"][g, w]
+            sl = slice(t["tptr"][g], t["tptr"][g + 1])
+            mine = ((t["tmask"][sl] >> (8 * w)) & 0xFF) != 0
+            if panel < 0:
+                assert not mine.any()
+                continue
+            q0, q1 = f0["pptr"][panel], f0["pptr"][panel + 1]
+            real = np.array([(int(f0["pmask4"][q >> 2]) >> (8 * (q & 3))) & 0xFF for q in range(q0, q1)]) != 0
+            assert sorted(t["tcol"][sl][mine].tolist()) == sorted(f0["pcol"][q0:q1][real].tolist()), (g, w)
+            # the team-scheduled panel format holds the wave's entries in exactly this order
+            assert t["tcol"][sl][mine].tolist() == f["pcol"][f["pptr"][panel]:f["pptr"][panel + 1]][:mine.sum()].tolist()
+    # matrices without a lattice: four consecutive panels per team
+    rp2, ci2, va2 = gen.random_csr(300, 300, 12, seed=5)
+    t2 = hip.team_format_host(rp2, ci2, va2)
+    assert not t2["lattice"] and np.array_equal(t2["tpanel"].reshape(-1)[:38], np.arange(38))
 
 
 def test_crpspmm_grid_rule_matches_oracle(crp, orc):
