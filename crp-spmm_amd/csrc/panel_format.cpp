@@ -165,7 +165,8 @@ void build_panels(int nrow, const int *rowptr, const int *colidx, const double *
     {
         double D1, D2;
         int M;
-        if (detect_stride_lattice(nrow, rowptr, colidx, R, &D1, &D2, &M))
+        static const bool force = getenv("CRPSPMM_TEAM_FORCE") != NULL;      // experiment: teams of 4 consecutive panels
+        if (detect_stride_lattice(nrow, rowptr, colidx, R, &D1, &D2, &M) || (force && mode == 3))
         {
             TeamHost th;
             build_teams(*out, nrow, rowptr, colidx, &th);

@@ -654,8 +654,12 @@ static hipError_t launch_panel_shape(const PanelArgs &p, const SpmmArgs &a, hipS
     return launch_panel_addr<R, 1, 1>(p, a, s);                          // n <= 64: one column per lane
 }
 
-hipError_t spmm_rm_f64_panel(const PanelArgs &p, const SpmmArgs &a, hipStream_t s)
+hipError_t spmm_rm_f64_panel(const PanelArgs &p_, const SpmmArgs &a, hipStream_t s)
 {
+    PanelArgs p = p_;
+    // team schedule: the per-round workgroup barrier pays from 128 columns on (n = 128: 0.204 -> 0.184 ms,
+    // n = 1024: 1.40 -> 1.27 ms on the pwtk stand-in); at n <= 64 the rounds are too short (0.096 -> 0.099 ms)
+    if (a.n <= 64) p.psync = nullptr;
     if (p.R == 4) return launch_panel_shape<4>(p, a, s);
     if (p.R == 8) return launch_panel_shape<8>(p, a, s);
     return hipErrorInvalidValue;
