@@ -402,6 +402,10 @@ int crp_csr_dev_update_values(crp_csr_dev_p A, const double *val, void *stream)
 {
     if (A == NULL || (val == NULL && A->nnz > 0)) return -1;
     if (A->nnz == 0) return 0;
+    // the slot maps of the derived formats are 32-bit
+    for (int i = 0; i < 2; i++)
+        if (A->pan[i].built && A->pan[i].entries * (long long) A->pan[i].R >= (1LL << 32)) return -5;
+    if (A->team.built && A->team.entries * 8LL >= (1LL << 32)) return -5;
     int is_dev = 0;
     crp_dev_ptr_is_device(val, &is_dev);
     CRP_TRY(hipMemcpyAsync(A->val, val, sizeof(double) * (size_t) A->nnz, is_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,

@@ -689,26 +689,6 @@ constexpr int TEAM_LDS_BYTES = TEAM_RING_BYTES + 4 * 2 * 1024;      // + two 1 K
 #define CRP_GPTR(p) ((const __attribute__((address_space(1))) void *) (p))
 #define CRP_LPTR(p) ((__attribute__((address_space(3))) void *) (p))
 
-// acc[v][w] += a * slot[v][w] when bit BIT of the mask is set; `a` lives in SGPRs (it came by a
-// scalar load: the 8 values of an entry are wave-uniform)
-template <int BIT>
-__device__ __forceinline__ void fmac_row_masked_s(double (&acc)[2][2], const double a, const d2 (&slot)[2], const uint32_t mask)
-{
-    asm volatile("s_bitcmp0_b32 %9, %10\n\ts_cbranch_scc1 1f\n\t"
-                 "v_fmac_f64 %0, %4, %5\n\tv_fmac_f64 %1, %4, %6\n\t"
-                 "v_fmac_f64 %2, %4, %7\n\tv_fmac_f64 %3, %4, %8\n1:"
-                 : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1])
-                 : "s"(a), "v"(slot[0].x), "v"(slot[0].y), "v"(slot[1].x), "v"(slot[1].y), "s"(mask), "n"(BIT)
-                 : "scc");
-}
-
-template <int BIT = 0>
-__device__ __forceinline__ void fmac_rows_s(double (&acc)[8][2][2], const double (&a)[8], const d2 (&slot)[2], const uint32_t mask)
-{
-    fmac_row_masked_s<BIT>(acc[BIT], a[BIT], slot, mask);
-    if constexpr (BIT + 1 < 8) fmac_rows_s<BIT + 1>(acc, a, slot, mask);
-}
-
 __global__ __launch_bounds__(256) void spmm_team_f64_kernel(
     const int nteam, const int nrow, const int n, const int *__restrict__ torder, const int *__restrict__ tpanel,
     const int *__restrict__ tptr, const int *__restrict__ tcol, const uint32_t *__restrict__ tmask,
