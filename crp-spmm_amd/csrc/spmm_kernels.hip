@@ -504,7 +504,11 @@ __global__ __launch_bounds__(256) void spmm_panel_f64_kernel(
             {
                 double a_cur[R];
 #pragma unroll
+#ifdef CRP_ABL_NOVALS      // timing experiment: no LDS broadcast of the values
+                for (int rr = 0; rr < R; rr++) a_cur[rr] = 1.0 + rr;
+#else
                 for (int rr = 0; rr < R; rr++) a_cur[rr] = lv[k * R + rr];      // uniform-address LDS broadcast
+#endif
                 const uint32_t mask = ((k < 4 ? m_lo : m_hi) >> (8 * (k & 3))) & 0xFFu;
                 // younger than slot k of this round: slots k+1..7 of the round, the DEPTH-1 rounds issued
                 // after it, and (refill) the k slots re-issued so far; the staging loads of a chunk's
