@@ -359,6 +359,51 @@ __device__ __forceinline__ void fmac_rows(double (&acc)[R][NV][VW], const double
     if constexpr (BIT + 1 < R) fmac_rows<R, NV, VW, BIT + 1>(acc, a, slot, mask);
 }
 
+// Narrow tiles (one vector access per lane): the scalar unit, shared by the four SIMDs of a CU, is
+// what bounds them -- s_bitcmp + s_cbranch per row is 16 scalar instructions per entry against 8 FMAs.
+// Here the row mask goes into EXEC instead: one s_bfe_i64 per row writes all-ones or zero, the FMA
+// that follows runs for all lanes or for none (so an absent pair still multiplies nothing), EXEC
+// is restored at the end.  All eight rows sit in ONE asm statement so that no compiler-scheduled
+// vector instruction can land between the EXEC writes.
+template <int VW>
+__device__ __forceinline__ void fmac_rows_exec8(double (&acc)[8][1][VW], const double (&a)[8],
+                                                const typename SlotT<VW>::type (&slot)[1], const uint32_t mask)
+{
+    const uint64_t m64 = mask;
+    if constexpr (VW == 1)
+        asm volatile("s_bfe_i64 exec, %[m], 0x10000\n\tv_fmac_f64 %0, %8, %16\n\t"
+                     "s_bfe_i64 exec, %[m], 0x10001\n\tv_fmac_f64 %1, %9, %16\n\t"
+                     "s_bfe_i64 exec, %[m], 0x10002\n\tv_fmac_f64 %2, %10, %16\n\t"
+                     "s_bfe_i64 exec, %[m], 0x10003\n\tv_fmac_f64 %3, %11, %16\n\t"
+                     "s_bfe_i64 exec, %[m], 0x10004\n\tv_fmac_f64 %4, %12, %16\n\t"
+                     "s_bfe_i64 exec, %[m], 0x10005\n\tv_fmac_f64 %5, %13, %16\n\t"
+                     "s_bfe_i64 exec, %[m], 0x10006\n\tv_fmac_f64 %6, %14, %16\n\t"
+                     "s_bfe_i64 exec, %[m], 0x10007\n\tv_fmac_f64 %7, %15, %16\n\t"
+                     "s_mov_b64 exec, -1"
+                     : "+v"(acc[0][0][0]), "+v"(acc[1][0][0]), "+v"(acc[2][0][0]), "+v"(acc[3][0][0]),
+                       "+v"(acc[4][0][0]), "+v"(acc[5][0][0]), "+v"(acc[6][0][0]), "+v"(acc[7][0][0])
+                     : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]),
+                       "v"(slot[0]), [m] "s"(m64)
+                     : "scc");
+    else
+        asm volatile("s_bfe_i64 exec, %[m], 0x10000\n\tv_fmac_f64 %0, %16, %24\n\tv_fmac_f64 %1, %16, %25\n\t"
+                     "s_bfe_i64 exec, %[m], 0x10001\n\tv_fmac_f64 %2, %17, %24\n\tv_fmac_f64 %3, %17, %25\n\t"
+                     "s_bfe_i64 exec, %[m], 0x10002\n\tv_fmac_f64 %4, %18, %24\n\tv_fmac_f64 %5, %18, %25\n\t"
+                     "s_bfe_i64 exec, %[m], 0x10003\n\tv_fmac_f64 %6, %19, %24\n\tv_fmac_f64 %7, %19, %25\n\t"
+                     "s_bfe_i64 exec, %[m], 0x10004\n\tv_fmac_f64 %8, %20, %24\n\tv_fmac_f64 %9, %20, %25\n\t"
+                     "s_bfe_i64 exec, %[m], 0x10005\n\tv_fmac_f64 %10, %21, %24\n\tv_fmac_f64 %11, %21, %25\n\t"
+                     "s_bfe_i64 exec, %[m], 0x10006\n\tv_fmac_f64 %12, %22, %24\n\tv_fmac_f64 %13, %22, %25\n\t"
+                     "s_bfe_i64 exec, %[m], 0x10007\n\tv_fmac_f64 %14, %23, %24\n\tv_fmac_f64 %15, %23, %25\n\t"
+                     "s_mov_b64 exec, -1"
+                     : "+v"(acc[0][0][0]), "+v"(acc[0][0][1]), "+v"(acc[1][0][0]), "+v"(acc[1][0][1]),
+                       "+v"(acc[2][0][0]), "+v"(acc[2][0][1]), "+v"(acc[3][0][0]), "+v"(acc[3][0][1]),
+                       "+v"(acc[4][0][0]), "+v"(acc[4][0][1]), "+v"(acc[5][0][0]), "+v"(acc[5][0][1]),
+                       "+v"(acc[6][0][0]), "+v"(acc[6][0][1]), "+v"(acc[7][0][0]), "+v"(acc[7][0][1])
+                     : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]),
+                       "v"(slot[0].x), "v"(slot[0].y), [m] "s"(m64)
+                     : "scc");
+}
+
 template <int R, int NV, int VW>
 __device__ __forceinline__ void panel_consume1(const typename SlotT<VW>::type (&slot)[NV], const uint32_t mask,
                                                const double (&a)[R], double (&acc)[R][NV][VW])
@@ -368,7 +413,10 @@ __device__ __forceinline__ void panel_consume1(const typename SlotT<VW>::type (&
 #elif defined(CRP_ABL_NOFMA)    // timing experiment only: no row takes the FMA path
     fmac_rows<R, NV, VW>(acc, a, slot, (uint32_t) __builtin_amdgcn_readfirstlane((int) (mask & 0u)));
 #else
-    fmac_rows<R, NV, VW>(acc, a, slot, (uint32_t) __builtin_amdgcn_readfirstlane((int) mask));
+    if constexpr (R == 8 && NV == 1)
+        fmac_rows_exec8<VW>(acc, a, slot, (uint32_t) __builtin_amdgcn_readfirstlane((int) mask));
+    else
+        fmac_rows<R, NV, VW>(acc, a, slot, (uint32_t) __builtin_amdgcn_readfirstlane((int) mask));
 #endif
 }
 
