@@ -86,6 +86,29 @@ def main():
             e2.print_stat()
             e2.free()
             dist.barrier()
+    # ---- a stride-lattice matrix: the local matrices (whole, or the interior / boundary row subsets
+    #      of the overlap split) get the team schedule, with remote columns inside the teams
+    nx, ny, nz = 300, 8, 6
+    ml = nx * ny * nz
+    rpl, cil, val = gen.banded_fem(ml, offsets=(1, 2, 3, nx, nx + 1, nx * ny, nx * ny + 1), seed=7)
+    rbl = planner.csr_mat_row_partition(rpl, P)
+    s, e = int(rbl[me]), int(rbl[me + 1])
+    for n in (256, 96):
+        Bl = orc.fill_B(0, ml, 0, n)
+        Cl_ref = orc.spmm_csr(rpl[s:e + 1] - rpl[s], cil[rpl[s]:rpl[e]], val[rpl[s]:rpl[e]], Bl, fast=True)
+        eng = engine.RpSpmm(s, e - s, rpl[s:e + 1], cil[rpl[s]:rpl[e]], val[rpl[s]:rpl[e]], rbl, n, world)
+        Bd = torch.from_numpy(Bl[s:e].copy()).to(dev)
+        Cd = torch.full((e - s, n), float("nan"), dtype=torch.float64, device=dev)
+        for timing in (True, False):
+            eng.set_timing(timing)
+            for variant in (0, 3, 4, 1):
+                eng.set_variant(variant)
+                Cd.fill_(float("nan"))
+                eng.exec(0, Bd, Cd)
+                torch.cuda.synchronize()
+                assert orc.rel_fro_err(Cl_ref, Cd.cpu().numpy()) <= 1e-12, (me, n, timing, variant, "lattice")
+        eng.free()
+        dist.barrier()
     # ---- mat_redist with device-resident blocks (dev_type 1: staged through pinned host memory;
     #      2: device to device through the communicator's device all-to-all) against the fixture
     #      produced by the reference's own engine
