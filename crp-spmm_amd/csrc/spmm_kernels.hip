@@ -500,14 +500,14 @@ __global__ __launch_bounds__(256) void spmm_panel_f64_kernel(
         int cA[RING];                                   // column indices of the round refilled next
         int cP[RING];                                   // ... and of the round after it (scalar loads run two rounds ahead)
 
-        // ---- prologue: values of chunk 0 (synchronous: nothing is in flight yet), rounds 0..DEPTH-1
+        // ---- prologue: the values of chunk 0 are requested first (asm-issued like every load of the
+        // loop), the B rows of rounds 0..DEPTH-1 right behind them, and only then are the values
+        // waited for and parked in LDS: one memory latency instead of two in a row per wave
         {
             // the chunk's CHUNK*R values are contiguous: lane l moves doubles [2*NS*l, 2*NS*(l+1))
-            const double *src = pval + (int64_t) q0 * R + lane * (2 * NS);
-            double *dst = myvals + lane * (2 * NS);
+            const char *src = reinterpret_cast<const char *>(pval + (int64_t) q0 * R + lane * (2 * NS));
 #pragma unroll
-            for (int t = 0; t < NS; t++)
-                *reinterpret_cast<d2 *>(dst + 2 * t) = *reinterpret_cast<const d2 *>(src + 2 * t);
+            for (int t = 0; t < NS; t++) glb_load_asm<2>(stage[t], src + 16 * t);
         }
 #pragma unroll
         for (int d = 0; d < DEPTH; d++)
@@ -520,6 +520,14 @@ __global__ __launch_bounds__(256) void spmm_panel_f64_kernel(
 #pragma unroll
                 for (int k = 0; k < RING; k++) panel_issue1<ADDR64, HAS_B1, NV, VW>(ring[d][k], c0[k], s0, s1, voff);
             }
+        }
+        {
+            // younger than the staging loads: the ring loads just issued (at least one set; waiting for
+            // "at most RING*NV outstanding" only over-waits when a second set was issued)
+            wait_vmcnt<RING * NV>();
+            double *dst = myvals + lane * (2 * NS);
+#pragma unroll
+            for (int t = 0; t < NS; t++) *reinterpret_cast<d2 *>(dst + 2 * t) = stage[t];
         }
 #pragma unroll
         for (int k = 0; k < RING; k++) cA[k] = pcol[q0 + DEPTH * RING + k];     // (arrays are padded)
