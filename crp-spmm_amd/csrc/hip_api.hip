@@ -83,9 +83,23 @@ static int ensure_panel(crp_csr_dev *A, int idx)
     if (e == hipSuccess) e = hipMalloc((void **) &d.pmap, sizeof(uint32_t) * (h.pmap.size() + 1));
     if (e == hipSuccess && !h.pmap.empty())
         e = hipMemcpy(d.pmap, h.pmap.data(), sizeof(uint32_t) * h.pmap.size(), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMalloc((void **) &d.porder, sizeof(int) * (h.porder.size() + 1));
-    if (e == hipSuccess && !h.porder.empty())
-        e = hipMemcpy(d.porder, h.porder.data(), sizeof(int) * h.porder.size(), hipMemcpyHostToDevice);
+    // processing order as 16-byte records {panel (-1: none), first entry, rounds, 0}, one per position
+    {
+        std::vector<int> rec(4 * (h.porder.size() + 4), 0);
+        for (size_t i = 0; i < h.porder.size(); i++)
+        {
+            const int pnl = h.porder[i];
+            rec[4 * i] = pnl;
+            if (pnl >= 0)
+            {
+                rec[4 * i + 1] = h.pptr[(size_t) pnl];
+                rec[4 * i + 2] = (h.pptr[(size_t) pnl + 1] - h.pptr[(size_t) pnl]) / crp::PANEL_PAD;
+            }
+        }
+        for (size_t i = h.porder.size(); i < h.porder.size() + 4; i++) rec[4 * i] = -1;
+        if (e == hipSuccess) e = hipMalloc((void **) &d.porder, sizeof(int) * rec.size());
+        if (e == hipSuccess) e = hipMemcpy(d.porder, rec.data(), sizeof(int) * rec.size(), hipMemcpyHostToDevice);
+    }
     // team schedule: the waves of a workgroup start their rounds together (CRPSPMM_TEAM_SYNC=0: free-running)
     static const bool use_sync = getenv("CRPSPMM_TEAM_SYNC") ? atoi(getenv("CRPSPMM_TEAM_SYNC")) != 0 : true;
     if (e == hipSuccess && !h.psync.empty() && use_sync)

@@ -27,7 +27,7 @@ struct PanelArgs
     int R;
     int npanel;
     const int      *pptr;
-    const int      *porder;    // processing order of the panels (norder positions; -1 = no panel)
+    const int      *porder;    // processing order: norder records {panel or -1, first entry, rounds, 0}
     int             norder;
     const int      *psync;     // per workgroup (4 positions): rounds that start at a barrier, or nullptr
     const int      *pcol;

@@ -449,7 +449,10 @@ __global__ __launch_bounds__(256) void spmm_panel_f64_kernel(
     const int wg    = (blockIdx.x & 7) * cpx + (blockIdx.x >> 3);
     const int slot_id = __builtin_amdgcn_readfirstlane((int) (wg * 4 + wave));
     if (slot_id >= norder) return;
-    const int panel = porder[slot_id];       // which panel this wave computes (processing order; -1: none)
+    // one 16-byte record per position: panel (-1: none), first entry, rounds -- a single scalar load
+    // instead of the chain order -> panel -> entry range
+    const int4 rec = reinterpret_cast<const int4 *>(porder)[slot_id];
+    const int panel = rec.x;
     // team schedule: the four waves of the workgroup meet at a barrier before each of the first nb
     // rounds (nb < the rounds of every panel of the team), so that they reach shared B rows together
 #ifndef CRP_TEAM_SYNC_K
@@ -491,8 +494,8 @@ __global__ __launch_bounds__(256) void spmm_panel_f64_kernel(
 #pragma unroll
             for (int w = 0; w < VW; w++) acc[r][v][w] = 0.0;
 
-    const int q0 = pptr[panel];
-    const int nr = (pptr[panel + 1] - q0) / RING;      // rounds of this panel (entry counts are padded)
+    const int q0 = rec.y;
+    const int nr = rec.z;                              // rounds of this panel (entry counts are padded to whole rounds)
     if (nr > 0)
     {
         ST ring[DEPTH][RING][NV];
