@@ -1,0 +1,164 @@
+// Host-side format builders, planner and ingest under AddressSanitizer / UBSan (CPU only; built and
+// run by tests/test_host_sanitizers.py).  No device code is linked: everything here is the host
+// half of the product (csrc/panel_format.cpp, spmat_part.cpp, mmio_utils.cpp, utils.cpp).
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <vector>
+#include "panel_format.h"
+#include "mmio_utils.h"
+#include "spmat_part.h"
+#include "utils.h"
+
+extern "C" int crp_csr_cache_write(const char *, int, int, const int *, const int *, const double *);
+extern "C" int crp_csr_cache_read(const char *, int *, int *, int **, int **, double **);
+
+static uint64_t rng_state = 88172645463325252ull;
+static uint32_t rnd()
+{
+    rng_state ^= rng_state << 13;
+    rng_state ^= rng_state >> 7;
+    rng_state ^= rng_state << 17;
+    return (uint32_t) (rng_state >> 11);
+}
+
+struct Csr { int m, k; std::vector<int> rp, ci; std::vector<double> va; };
+
+static Csr banded(int m, const std::vector<int> &offs)
+{
+    Csr a; a.m = a.k = m; a.rp.assign(m + 1, 0);
+    std::vector<int> all;
+    for (int d : offs) { all.push_back(d); all.push_back(-d); }
+    all.push_back(0);
+    std::sort(all.begin(), all.end());
+    for (int i = 0; i < m; i++)
+    {
+        for (int d : all)
+            if (i + d >= 0 && i + d < m) { a.ci.push_back(i + d); a.va.push_back(1.0 + (rnd() % 100) * 0.01); }
+        a.rp[i + 1] = (int) a.ci.size();
+    }
+    return a;
+}
+
+static Csr random_csr(int m, int k, int maxdeg, bool dup, bool two_source)
+{
+    Csr a; a.m = m; a.k = k; a.rp.assign(m + 1, 0);
+    for (int i = 0; i < m; i++)
+    {
+        const int deg = (i % 7 == 3) ? 0 : (int) (rnd() % (maxdeg + 1));
+        std::vector<int> c;
+        for (int t = 0; t < deg; t++) c.push_back((int) (rnd() % k));
+        std::sort(c.begin(), c.end());
+        if (!dup) c.erase(std::unique(c.begin(), c.end()), c.end());
+        for (int x : c)
+        {
+            a.ci.push_back(two_source && x >= k / 2 ? ~(x - k / 2) : x);
+            a.va.push_back((rnd() % 2000) * 0.001 - 1.0);
+        }
+        a.rp[i + 1] = (int) a.ci.size();
+    }
+    return a;
+}
+
+// every CSR nonzero must be reachable through the format exactly once
+static void check_format(const Csr &a, const crp::PanelHost &h)
+{
+    const int R = h.R;
+    for (size_t p = 0; p < h.pmap.size(); p++)
+    {
+        const uint32_t slot = h.pmap[p];
+        const size_t q = slot / R, r = slot % R;
+        if (q >= h.pcol.size() || h.pval[q * R + r] != a.va[p] || h.pcol[q] != a.ci[p]) { printf("FAIL pmap %zu\n", p); exit(1); }
+        if (!((h.pmask4[q >> 2] >> (8 * (q & 3))) >> r & 1)) { printf("FAIL mask %zu\n", p); exit(1); }
+    }
+    std::vector<int> cnt((size_t) h.npanel, 0);
+    for (int x : h.porder)
+        if (x >= 0) { if (x >= h.npanel) { printf("FAIL order\n"); exit(1); } cnt[(size_t) x]++; }
+    for (int c : cnt) if (c != 1) { printf("FAIL order is not a cover\n"); exit(1); }
+}
+
+int main()
+{
+    std::vector<Csr> mats;
+    mats.push_back(banded(300 * 8 * 5 + 13, {1, 2, 3, 300, 301, 2400, 2401}));       // stride lattice, ragged end
+    mats.push_back(banded(5000, {1, 2, 3, 40, 900}));
+    mats.push_back(random_csr(777, 1234, 40, true, false));
+    mats.push_back(random_csr(301, 500, 9, false, true));
+    mats.push_back(random_csr(5, 9, 3, false, false));
+    mats.push_back(random_csr(0, 4, 3, false, false));
+    const char *orders[] = {NULL, "0", "1", "2", "3"};
+    for (const Csr &a : mats)
+        for (const char *o : orders)
+        {
+            if (o) setenv("CRPSPMM_PANEL_ORDER", o, 1); else unsetenv("CRPSPMM_PANEL_ORDER");
+            for (int R : {4, 8})
+            {
+                crp::PanelHost h;
+                crp::build_panels(a.m, a.rp.data(), a.ci.data(), a.va.data(), R, &h);
+                check_format(a, h);
+                (void) crp::count_panel_entries(a.m, a.rp.data(), a.ci.data(), R);
+            }
+            crp::PanelHost h8;
+            crp::build_panels(a.m, a.rp.data(), a.ci.data(), a.va.data(), 8, &h8, false);
+            crp::TeamHost t;
+            crp::build_teams(h8, a.m, a.rp.data(), a.ci.data(), &t);
+            long long own = 0;
+            for (uint32_t m : t.tmask) for (int w = 0; w < 4; w++) own += ((m >> (8 * w)) & 0xFF) != 0;
+            if (own != t.tvoff.back()) { printf("FAIL team value streams %lld %lld\n", own, t.tvoff.back()); return 1; }
+        }
+    unsetenv("CRPSPMM_PANEL_ORDER");
+
+    // planner
+    {
+        const Csr a = banded(6000, {1, 2, 3, 40, 41, 900});
+        for (int P : {1, 2, 3, 4, 6, 8, 12})
+        {
+            std::vector<int> rb(P + 1), sizes(P);
+            csr_mat_row_partition(a.m, a.rp.data(), P, rb.data());
+            int tot = 0;
+            csr_mat_row_part_comm_size(a.m, a.k, a.rp.data(), a.ci.data(), P, rb.data(), rb.data(), sizes.data(), &tot);
+            int pm, pn, *a0, *br, *ac, *bc;
+            size_t cost;
+            calc_spmm_part2d_from_1d(P, a.m, 48, a.k, rb.data(), a.rp.data(), a.ci.data(), 1, &pm, &pn, &cost, &a0, &br, &ac, &bc, 0);
+            if (pm * pn != P || a0[P] != a.m || ac[pm] != a.m || bc[pn] != 48) { printf("FAIL planner\n"); return 1; }
+            free(a0); free(br); free(ac); free(bc);
+            int *fac = NULL;
+            const int nf = prime_factorization(P, &fac);
+            int prod = 1;
+            for (int i = 0; i < nf; i++) prod *= fac[i];
+            free(fac);
+            if (prod != P) { printf("FAIL factors\n"); return 1; }
+        }
+    }
+
+    // ingest: parallel path (> 200k entries), cache round trip
+    {
+        const Csr a = banded(40000, {1, 2, 3, 50, 700});
+        const char *fn = "/tmp/crp_asan_big.mtx";
+        FILE *f = fopen(fn, "w");
+        long cnt = 0;
+        for (int i = 0; i < a.m; i++) for (int p = a.rp[i]; p < a.rp[i + 1]; p++) cnt += a.ci[p] <= i;
+        fprintf(f, "%%%%MatrixMarket matrix coordinate real symmetric\n%% c\n%d %d %ld\n", a.m, a.m, cnt);
+        for (int i = 0; i < a.m; i++)
+            for (int p = a.rp[i]; p < a.rp[i + 1]; p++)
+                if (a.ci[p] <= i) fprintf(f, "%d %d %.17g\n", i + 1, a.ci[p] + 1, a.va[p]);
+        fclose(f);
+        int nr, nc, nnz, *row, *col, *rp, *ci;
+        double *val, *va;
+        if (mm_read_sparse_RPI(fn, 0, &nr, &nc, &nnz, &row, &col, &val) != 0 || nnz != (int) a.ci.size()) { printf("FAIL ingest\n"); return 1; }
+        coo2csr(nr, nc, nnz, row, col, val, &rp, &ci, &va);
+        if (memcmp(rp, a.rp.data(), sizeof(int) * (a.m + 1)) || memcmp(ci, a.ci.data(), sizeof(int) * a.ci.size())) { printf("FAIL coo2csr\n"); return 1; }
+        const char *cf = "/tmp/crp_asan_big.crpcsr";
+        if (crp_csr_cache_write(cf, nr, nc, rp, ci, va) != 0) { printf("FAIL cache write\n"); return 1; }
+        int m2, k2, *rp2, *ci2;
+        double *va2;
+        if (crp_csr_cache_read(cf, &m2, &k2, &rp2, &ci2, &va2) != 0 || m2 != nr || memcmp(va2, va, sizeof(double) * (size_t) nnz)) { printf("FAIL cache read\n"); return 1; }
+        free(row); free(col); free(val); free(rp); free(ci); free(va); free(rp2); free(ci2); free(va2);
+        remove(fn);
+        remove(cf);
+    }
+    printf("HOST_ASAN_OK\n");
+    return 0;
+}
