@@ -498,48 +498,51 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
             // Rounds of 8 union entries end at a barrier, so a round costs what its busiest wave
             // costs; a wave's columns are clustered, and in column order the four waves would work
             // one after the other.  The order inside a team is free (a row's products are summed in
-            // the order its wave meets them), so the slots are dealt out: each slot goes to the wave
-            // that has the least in this round (most left overall), which takes its first open
-            // shared node if that does not overload a partner, else its first open private node.
-            int remaining[4], cursor[4] = {0, 0, 0, 0};
-            for (int w = 0; w < 4; w++) remaining[w] = (int) list[w].size();
+            // the order its wave meets them), so the entries are dealt out in balanced passes.
+            // Passes: every pass hands each wave that still has entries exactly ONE of them -- a set of open
+            // nodes whose user sets are disjoint and cover the waves (a node shared by A and B plus one
+            // shared by C and D; or four private nodes; ...).  All waves then meet a shared node after
+            // exactly the same number of own entries, i.e. in the same ring slot of the same round.
+            int cursor[4] = {0, 0, 0, 0};
             size_t left = nodes.size();
+            auto emit = [&](int id) {
+                Node &nd = nodes[(size_t) id];
+                nd.done = true;
+                left--;
+                uc.push_back(nd.col);
+                um.push_back(nd.mask);
+                for (int u = 0; u < 4; u++) us.push_back(nd.src[u]);
+            };
             while (left > 0)
             {
-                int rc[4] = {0, 0, 0, 0};
-                for (int slot = 0; slot < PANEL_PAD && left > 0; slot++)
+                bool covered[4] = {false, false, false, false};
+                for (int w = 0; w < 4; w++)
                 {
-                    int ws = -1;
-                    for (int w = 0; w < 4; w++)
+                    if (covered[w]) continue;
+                    while (cursor[w] < (int) list[w].size() && nodes[(size_t) list[w][(size_t) cursor[w]]].done) cursor[w]++;
+                    // among the wave's next open nodes: the one with the most users, all of them uncovered
+                    int pick = -1, pick_users = 0;
+                    for (int t = cursor[w], seen = 0; t < (int) list[w].size() && seen < 96; t++)
                     {
-                        if (remaining[w] == 0) continue;
-                        if (ws < 0 || rc[w] < rc[ws] || (rc[w] == rc[ws] && remaining[w] > remaining[ws])) ws = w;
-                    }
-                    while (cursor[ws] < (int) list[ws].size() && nodes[(size_t) list[ws][(size_t) cursor[ws]]].done) cursor[ws]++;
-                    int pick = -1, first_private = -1, first_any = -1;
-                    for (int t = cursor[ws], seen = 0; t < (int) list[ws].size() && seen < 64; t++)
-                    {
-                        const int id = list[ws][(size_t) t];
+                        const int id = list[w][(size_t) t];
                         const Node &nd = nodes[(size_t) id];
                         if (nd.done) continue;
                         seen++;
-                        if (first_any < 0) first_any = id;
-                        if (nd.users == 1) { if (first_private < 0) first_private = id; continue; }
-                        bool fits = true;
+                        bool ok = true;
                         for (int u = 0; u < 4; u++)
-                            if (u != ws && nd.src[u] >= 0 && rc[u] > rc[ws]) fits = false;
-                        if (fits) { pick = id; break; }
+                            if (nd.src[u] >= 0 && covered[u]) ok = false;
+                        if (ok && nd.users > pick_users) { pick = id; pick_users = nd.users; if (nd.users >= 3) break; }
                     }
-                    if (pick < 0) pick = first_private >= 0 ? first_private : first_any;
-                    Node &nd = nodes[(size_t) pick];
-                    nd.done = true;
-                    left--;
+                    if (pick < 0) continue;              // everything this wave has left is shared with a covered wave
                     for (int u = 0; u < 4; u++)
-                        if (nd.src[u] >= 0) { rc[u]++; remaining[u]--; }
-                    uc.push_back(nd.col);
-                    um.push_back(nd.mask);
-                    for (int u = 0; u < 4; u++) us.push_back(nd.src[u]);
+                        if (nodes[(size_t) pick].src[u] >= 0) covered[u] = true;
+                    emit(pick);
                 }
+                // a pass that could place nothing would loop forever: take any open node (cannot happen while
+                // a wave has an open node at all, its first open node is always eligible when it comes first)
+                if (!(covered[0] || covered[1] || covered[2] || covered[3]))
+                    for (size_t id = 0; id < nodes.size(); id++)
+                        if (!nodes[id].done) { emit((int) id); break; }
             }
             cnt[(size_t) g] = (int) uc.size();
         }
