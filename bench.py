@@ -206,11 +206,17 @@ def main():
 
     # ---- spin the clocks up: after the host-side check the GPU has idled and a handful of warm-up
     #      steps (a few ms) is not enough for it to leave the low-power state; untimed
-    t_spin = time.perf_counter()
-    while time.perf_counter() - t_spin < 0.25:
-        for _ in range(20):
+    if distributed and pm > 1:
+        # a step holds a collective (the B exchange): every rank must run the same number of them
+        for _ in range(300):
             step()
         torch.cuda.synchronize()
+    else:
+        t_spin = time.perf_counter()
+        while time.perf_counter() - t_spin < 0.25:
+            for _ in range(20):
+                step()
+            torch.cuda.synchronize()
 
     # ---- timed region: K steps between barrier + synchronize; HIP events per step on the launch stream
     ev = [(C.c_void_p(), C.c_void_p()) for _ in range(args.steps)]
