@@ -1,12 +1,13 @@
 // Host-side format builders, planner and ingest under AddressSanitizer / UBSan (CPU only; built and
 // run by tests/test_host_sanitizers.py).  No device code is linked: everything here is the host
-// half of the product (csrc/panel_format.cpp, spmat_part.cpp, mmio_utils.cpp, utils.cpp).
+// half of the product (csrc/panel_format.cpp, spmat_part.cpp, mmio_utils.cpp, host_support.cpp).
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <vector>
+#include "dev_type.h"
 #include "panel_format.h"
 #include "mmio_utils.h"
 #include "spmat_part.h"
@@ -14,6 +15,19 @@
 
 extern "C" int crp_csr_cache_write(const char *, int, int, const int *, const int *, const double *);
 extern "C" int crp_csr_cache_read(const char *, int *, int *, int **, int **, double **);
+
+// host_support.cpp also holds the device branch of dev_type_*: with no GPU library linked, the
+// device ABI it calls is stubbed to "no runtime" (the host branches then take plain malloc)
+extern "C" {
+int crp_dev_malloc(void **p, size_t) { *p = NULL; return -1; }
+int crp_dev_free(void *) { return -1; }
+int crp_dev_memset(void *, int, size_t, void *) { return -1; }
+int crp_dev_memcpy(void *, const void *, size_t, int, void *) { return -1; }
+int crp_dev_memcpy2d(void *, size_t, const void *, size_t, size_t, size_t, int, void *) { return -1; }
+int crp_host_malloc(void **p, size_t) { *p = NULL; return -1; }
+int crp_host_free(void *) { return -1; }
+int crp_stream_sync(void *) { return -1; }
+}
 
 static uint64_t rng_state = 88172645463325252ull;
 static uint32_t rnd()
@@ -158,6 +172,34 @@ int main()
         free(row); free(col); free(val); free(rp); free(ci); free(va); free(rp2); free(ci2); free(va2);
         remove(fn);
         remove(cf);
+    }
+    // utils.h / dev_type.h, host branches
+    {
+        for (int len : {0, 1, 7, 100})
+            for (int nblk : {1, 3, 8})
+            {
+                int pos, size, sum = 0;
+                for (int b = 0; b < nblk; b++)
+                {
+                    calc_block_spos_size(len, nblk, b, &pos, &size);
+                    if (pos != sum) { printf("FAIL block split\n"); return 1; }
+                    sum += size;
+                }
+                calc_block_spos_size(len, nblk, nblk, &pos, &size);
+                if (sum != len || pos != len) { printf("FAIL block split end\n"); return 1; }     /* (size of the sentinel: len / nblk, as the reference) */
+            }
+        size_t cap = 0;
+        void *buf = NULL;
+        dev_type_realloc(&cap, 1000, DEV_TYPE_HOST, &buf);
+        dev_type_memset(buf, 7, 1000, DEV_TYPE_HOST);
+        std::vector<char> dst(1000);
+        dev_type_memcpy(dst.data(), buf, 1000, DEV_TYPE_HOST, DEV_TYPE_HOST);
+        dev_type_copy_matrix(4, 10, 5, buf, 20, dst.data(), 7, DEV_TYPE_HOST);
+        dev_type_free(buf, DEV_TYPE_HOST);
+        if (dst[999] != 7 || is_dev_type_valid((dev_type_t) 9) || dev_type_malloc(8, (dev_type_t) 9) != NULL) { printf("FAIL dev_type\n"); return 1; }
+        double x[3] = {3, 4, 0}, y[3] = {3, 4, 2}, nx, ne;
+        calc_err_2norm(3, x, y, &nx, &ne);
+        if (calc_2norm(3, x) != 5.0 || nx != 5.0 || ne != 2.0) { printf("FAIL norms\n"); return 1; }
     }
     printf("HOST_ASAN_OK\n");
     return 0;
