@@ -80,7 +80,7 @@ class CrpspmmView(C.Structure):
     _fields_ = [(k, C.c_int) for k in ("np_glb", "rank_glb", "np_row", "np_col", "rank_row", "rank_col", "glb_m", "glb_n",
                                        "glb_k", "loc_A_srow", "loc_A_erow", "loc_A_nrow", "loc_A_nnz", "loc_A_nnz_s",
                                        "rd_B_srow", "rd_B_erow", "loc_B_scol", "loc_B_ecol", "loc_B_ncol", "loc_B_srow",
-                                       "loc_B_erow", "loc_B_nrow")] + \
+                                       "loc_B_erow", "loc_B_nrow", "a2a_B_finegrain")] + \
                [("loc_A_rowptr", c_int_p), ("loc_A_colidx", c_int_p), ("loc_A_val", c_dbl_p), ("red_B", c_dbl_p),
                 ("loc_C", c_dbl_p), ("n_exec", C.c_int)] + \
                [(k, C.c_double) for k in ("t_init", "t_exec", "t_rd_A", "t_agv_A", "t_rd_B", "t_a2a_B", "t_spmm", "t_rd_C",

@@ -100,6 +100,9 @@ static void crpspmm_init_impl(int m, int n, int k, int src_A_srow, int src_A_nro
     e->comm = comm;
     const int P = comm->nproc, me = comm->rank;
     e->v.np_glb = P; e->v.rank_glb = me; e->v.glb_m = m; e->v.glb_n = n; e->v.glb_k = k;
+    // the reference's knob (deprecated/src/crpspmm.c:294): read and reported with the reference's
+    // message; the exchange here always moves exactly the rows a panel needs, whatever it says
+    GET_ENV_INT_VAR(e->v.a2a_B_finegrain, "A2A_B_FINEGRAIN", "a2a_B_finegrain", 0, 0, 1, me == 0);
     const char *st = getenv("CRPSPMM_ENGINE_A_STATIC");
     e->a_static = (st != NULL && atoi(st) == 1);
 

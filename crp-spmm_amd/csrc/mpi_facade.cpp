@@ -262,6 +262,7 @@ void ce_sync_public(crpspmm_engine_p s)
     s->loc_A_nnz = v.loc_A_nnz; s->loc_A_nnz_s = v.loc_A_nnz_s;
     s->rd_B_srow = v.rd_B_srow; s->rd_B_erow = v.rd_B_erow;
     s->loc_B_srow = v.loc_B_srow; s->loc_B_erow = v.loc_B_erow; s->loc_B_nrow = v.loc_B_nrow;
+    s->a2a_B_finegrain = v.a2a_B_finegrain;
     s->loc_B_scol = v.loc_B_scol; s->loc_B_ecol = v.loc_B_ecol; s->loc_B_ncol = v.loc_B_ncol;
     s->loc_A_rowptr = (int *) v.loc_A_rowptr; s->loc_A_colidx = (int *) v.loc_A_colidx;
     s->loc_A_val = (double *) v.loc_A_val; s->red_B = (double *) v.red_B; s->loc_C = (double *) v.loc_C;
@@ -292,7 +293,6 @@ void crpspmm_engine_init(const int m, const int n, const int k, const int src_A_
     s->comm_row = MPI_COMM_NULL;
     s->comm_col = MPI_COMM_NULL;    // owned by the engine's communicator wrapper
     s->use_CUDA = use_CUDA;
-    s->a2a_B_finegrain = 1;
     s->alloc_workbuf = 1;
     if (workbuf_bytes != NULL) *workbuf_bytes = 0;
     ce_sync_public(s);

@@ -168,6 +168,7 @@ typedef struct crp_crpspmm_view
     int loc_A_srow, loc_A_erow, loc_A_nrow, loc_A_nnz, loc_A_nnz_s;
     int rd_B_srow, rd_B_erow, loc_B_scol, loc_B_ecol, loc_B_ncol;
     int loc_B_srow, loc_B_erow, loc_B_nrow;   /* hull and count of the B rows the panel touches */
+    int a2a_B_finegrain;                      /* value of the A2A_B_FINEGRAIN knob (reported only) */
     const int *loc_A_rowptr, *loc_A_colidx;   /* panel CSR on the host (rowptr rebased to 0) */
     const double *loc_A_val, *red_B, *loc_C;
     int n_exec;

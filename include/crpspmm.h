@@ -9,7 +9,8 @@
  *   - the engine owns its buffers.  With workbuf_bytes != NULL init reports 0 bytes and
  *     crpspmm_engine_attach_workbuf() is accepted and ignored.
  *   - the B replication inside a grid column always moves exactly the rows the panel needs
- *     (what the reference calls A2A_B_FINEGRAIN=1); a2a_B_finegrain reads 1.
+ *     (what the reference calls A2A_B_FINEGRAIN=1); the knob is still read -- a2a_B_finegrain holds
+ *     its value and the reference's "[INFO] ... Overriding parameter a2a_B_finegrain" line is printed.
  *   - pointer members describing the reference's internal buffers that have no host counterpart
  *     here (a2a_* arrays, loc_B, workbuf) are NULL; loc_A_*, red_B and loc_C are live.
  */

@@ -60,3 +60,8 @@ def test_crpspmm_engine_driver(np_):
     assert "Alltoallv B necessary" in out
     out = _run("test_crpspmm.exe", np_, "g_gen.mtx", 5, tail=("1", "1"))      # non-square A, narrow B
     assert "SpMM total (avg of   1 runs)" in out
+
+
+def test_crpspmm_engine_driver_env_knob():
+    out = _run("test_crpspmm.exe", 2, "g_symm.mtx", 16, {"A2A_B_FINEGRAIN": "1"}, tail=("1", "1"))
+    assert "Overriding parameter a2a_B_finegrain: 0 (default) --> 1 (runtime)" in out
