@@ -17,7 +17,7 @@ struct PanelDev
     bool      built = false;
     int       R = 0, npanel = 0;
     int      *pptr = nullptr, *pcol = nullptr, *porder = nullptr;
-    int       norder = 0;
+    int       norder = 0, team_waves = 4;
     int      *psync = nullptr;
     uint32_t *pmask4 = nullptr, *pmap = nullptr;
     double   *pval = nullptr;
@@ -74,6 +74,7 @@ static int ensure_panel(crp_csr_dev *A, int idx)
     d.R = h.R;
     d.npanel = h.npanel;
     d.norder = (int) h.porder.size();
+    d.team_waves = h.team_waves;
     d.fill = h.fill();
     d.entries = (long long) h.pcol.size();
     hipError_t e = hipMalloc((void **) &d.pptr, sizeof(int) * h.pptr.size());
@@ -101,7 +102,7 @@ static int ensure_panel(crp_csr_dev *A, int idx)
         if (e == hipSuccess) e = hipMemcpy(d.porder, rec.data(), sizeof(int) * rec.size(), hipMemcpyHostToDevice);
     }
     // team schedule: the waves of a workgroup start their rounds together (CRPSPMM_TEAM_SYNC=0: free-running)
-    static const bool use_sync = getenv("CRPSPMM_TEAM_SYNC") ? atoi(getenv("CRPSPMM_TEAM_SYNC")) != 0 : true;
+    const bool use_sync = getenv("CRPSPMM_TEAM_SYNC") ? atoi(getenv("CRPSPMM_TEAM_SYNC")) != 0 : true;
     if (e == hipSuccess && !h.psync.empty() && use_sync)
     {
         e = hipMalloc((void **) &d.psync, sizeof(int) * (h.psync.size() + 8));
@@ -494,7 +495,7 @@ int crp_spmm_csr_f64(crp_csr_dev_p A, int layout, int n, const double *B0, long 
         const PanelDev &d = A->pan[v - 2];
         crp::PanelArgs p;
         memset(&p, 0, sizeof(p));
-        p.R = d.R; p.npanel = d.npanel; p.pptr = d.pptr; p.porder = d.porder; p.norder = d.norder; p.psync = d.psync; p.pcol = d.pcol; p.pmask4 = d.pmask4; p.pval = d.pval;
+        p.R = d.R; p.npanel = d.npanel; p.pptr = d.pptr; p.porder = d.porder; p.norder = d.norder; p.team_waves = d.team_waves; p.psync = d.psync; p.pcol = d.pcol; p.pmask4 = d.pmask4; p.pval = d.pval;
         p.b0_rows = A->b0_rows; p.b1_rows = A->b1_rows;
         e = crp::spmm_rm_f64_panel(p, a, (hipStream_t) stream);
     }

@@ -29,6 +29,7 @@ struct PanelArgs
     const int      *pptr;
     const int      *porder;    // processing order: norder records {panel or -1, first entry, rounds, 0}
     int             norder;
+    int             team_waves; // waves per workgroup the order is laid out for (4 or 6)
     const int      *psync;     // per workgroup (4 positions): rounds that start at a barrier, or nullptr
     const int      *pcol;
     const uint32_t *pmask4;

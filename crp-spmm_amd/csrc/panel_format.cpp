@@ -168,8 +168,12 @@ void build_panels(int nrow, const int *rowptr, const int *colidx, const double *
         static const bool force = getenv("CRPSPMM_TEAM_FORCE") != NULL;      // experiment: teams of 4 consecutive panels
         if (detect_stride_lattice(nrow, rowptr, colidx, R, &D1, &D2, &M) || (force && mode == 3))
         {
+            // workgroups of four waves = 2 x 2 teeth.  CRPSPMM_TEAM_WAVES=6 lays the order out for six-wave
+            // workgroups (3 x 2 teeth: fewer B rows cross L2 twice) -- measured slower, 0.44 vs 0.34 ms on the
+            // pwtk stand-in: at 3 waves per SIMD only one six-wave workgroup fits a CU
+            const int tw = getenv("CRPSPMM_TEAM_WAVES") ? atoi(getenv("CRPSPMM_TEAM_WAVES")) : 4;
             TeamHost th;
-            build_teams(*out, nrow, rowptr, colidx, &th);
+            build_teams(*out, nrow, rowptr, colidx, &th, tw == 6 ? 6 : 4);
             apply_team_schedule(out, th);
             done = true;
         }
@@ -384,8 +388,12 @@ void locality_order(const PanelHost &p, int group, std::vector<int> *order)
 }
 
 // ---- teams: four panels whose B rows one workgroup loads once (panel_format.h) --------------------
-void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *colidx, TeamHost *out)
+void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *colidx, TeamHost *out, int T)
 {
+    constexpr int TMAX = 8;
+    if (T != 4 && T != 6) T = 4;
+    const int TI = T / 2;                 // lattice teams: TI teeth along i times 2 along j
+    out->T = T;
     const int np = p.npanel, R = p.R;
     double D1 = 0, D2 = 0;
     int M = 0;
@@ -400,10 +408,10 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
         {
             int i, j, t;
             lattice_coords(q, R, D1, D2, M, &i, &j, &t);
-            const int a = i >> 1, b = j >> 1;
-            mem[(size_t) q] = {((long long) a << 40) | ((long long) b << 24) | (long long) t, (i & 1) + 2 * (j & 1), q, a, b, t};
+            const int a = i / TI, b = j >> 1;
+            mem[(size_t) q] = {((long long) a << 40) | ((long long) b << 24) | (long long) t, (i % TI) + TI * (j & 1), q, a, b, t};
         }
-        else mem[(size_t) q] = {(long long) (q >> 2), q & 3, q, 0, 0, q >> 2};
+        else mem[(size_t) q] = {(long long) (q / T), q % T, q, 0, 0, q / T};
     }
     std::sort(mem.begin(), mem.end(), [](const Mem &x, const Mem &y) {
         if (x.key != y.key) return x.key < y.key;
@@ -417,13 +425,13 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
     for (size_t s0 = 0; s0 < mem.size();)
     {
         size_t s1 = s0;
-        int slots[4] = {-1, -1, -1, -1};
+        int slots[TMAX] = {-1, -1, -1, -1, -1, -1, -1, -1};
         while (s1 < mem.size() && mem[s1].key == mem[s0].key && slots[mem[s1].slot] < 0)
         {
             slots[mem[s1].slot] = mem[s1].panel;
             s1++;
         }
-        for (int w = 0; w < 4; w++) out->tpanel.push_back(slots[w]);
+        for (int w = 0; w < T; w++) out->tpanel.push_back(slots[w]);
         tk.push_back({mem[s0].a, mem[s0].b, mem[s0].t});
         s0 = s1;
     }
@@ -448,10 +456,10 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
     parallel_chunks(nteam, 64, [&](long long b, long long e, int) {
         for (long long g = b; g < e; g++)
         {
-            int head[4], end[4], occ[4];
-            for (int w = 0; w < 4; w++)
+            int head[TMAX], end[TMAX], occ[TMAX];
+            for (int w = 0; w < T; w++)
             {
-                const int panel = out->tpanel[(size_t) g * 4 + w];
+                const int panel = out->tpanel[(size_t) g * T + w];
                 head[w] = panel >= 0 ? p.pptr[panel] : 0;
                 end[w] = panel >= 0 ? head[w] + real_count(panel) : 0;
                 occ[w] = 0;
@@ -460,14 +468,14 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
             std::vector<uint32_t> &um = umask[(size_t) g];
             std::vector<int> &us = usrc[(size_t) g];       // per union entry: panel entry of wave 0..3 (or -1)
             // Nodes: the union of the four entry lists, equal (column, occurrence) keys merged.
-            struct Node { int col; uint32_t mask; int src[4]; int users; bool done; };
+            struct Node { int col; uint32_t mask; int src[TMAX]; int users; bool done; };
             std::vector<Node> nodes;
-            std::vector<int> list[4];                       // node ids of every wave, in column order
+            std::vector<int> list[TMAX];                       // node ids of every wave, in column order
             for (;;)
             {
                 bool any = false;
                 uint64_t best = 0;
-                for (int w = 0; w < 4; w++)
+                for (int w = 0; w < T; w++)
                     if (head[w] < end[w])
                     {
                         const uint64_t k = ((uint64_t) col_key(p.pcol[(size_t) head[w]]) << 8) | (uint64_t) occ[w];
@@ -477,15 +485,15 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
                 if (!any) break;
                 Node nd;
                 nd.col = 0; nd.mask = 0; nd.users = 0; nd.done = false;
-                for (int w = 0; w < 4; w++) nd.src[w] = -1;
-                for (int w = 0; w < 4; w++)
+                for (int w = 0; w < T; w++) nd.src[w] = -1;
+                for (int w = 0; w < T; w++)
                     if (head[w] < end[w])
                     {
                         const int c = p.pcol[(size_t) head[w]];
                         const uint64_t k = ((uint64_t) col_key(c) << 8) | (uint64_t) occ[w];
                         if (k != best) continue;
                         const int q = head[w];
-                        nd.mask |= ((p.pmask4[(size_t) q >> 2] >> (8 * (q & 3))) & 0xFFu) << (8 * w);
+                        if (w < 4) nd.mask |= ((p.pmask4[(size_t) q >> 2] >> (8 * (q & 3))) & 0xFFu) << (8 * w);
                         nd.col = c;
                         nd.src[w] = q;
                         nd.users++;
@@ -503,7 +511,7 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
             // nodes whose user sets are disjoint and cover the waves (a node shared by A and B plus one
             // shared by C and D; or four private nodes; ...).  All waves then meet a shared node after
             // exactly the same number of own entries, i.e. in the same ring slot of the same round.
-            int cursor[4] = {0, 0, 0, 0};
+            int cursor[TMAX] = {0, 0, 0, 0, 0, 0, 0, 0};
             size_t left = nodes.size();
             auto emit = [&](int id) {
                 Node &nd = nodes[(size_t) id];
@@ -511,12 +519,12 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
                 left--;
                 uc.push_back(nd.col);
                 um.push_back(nd.mask);
-                for (int u = 0; u < 4; u++) us.push_back(nd.src[u]);
+                for (int u = 0; u < T; u++) us.push_back(nd.src[u]);
             };
             while (left > 0)
             {
-                bool covered[4] = {false, false, false, false};
-                for (int w = 0; w < 4; w++)
+                bool covered[TMAX] = {false, false, false, false, false, false, false, false};
+                for (int w = 0; w < T; w++)
                 {
                     if (covered[w]) continue;
                     while (cursor[w] < (int) list[w].size() && nodes[(size_t) list[w][(size_t) cursor[w]]].done) cursor[w]++;
@@ -529,18 +537,20 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
                         if (nd.done) continue;
                         seen++;
                         bool ok = true;
-                        for (int u = 0; u < 4; u++)
+                        for (int u = 0; u < T; u++)
                             if (nd.src[u] >= 0 && covered[u]) ok = false;
                         if (ok && nd.users > pick_users) { pick = id; pick_users = nd.users; if (nd.users >= 3) break; }
                     }
                     if (pick < 0) continue;              // everything this wave has left is shared with a covered wave
-                    for (int u = 0; u < 4; u++)
+                    for (int u = 0; u < T; u++)
                         if (nodes[(size_t) pick].src[u] >= 0) covered[u] = true;
                     emit(pick);
                 }
                 // a pass that could place nothing would loop forever: take any open node (cannot happen while
                 // a wave has an open node at all, its first open node is always eligible when it comes first)
-                if (!(covered[0] || covered[1] || covered[2] || covered[3]))
+                bool any_cov = false;
+                for (int w = 0; w < T; w++) any_cov = any_cov || covered[w];
+                if (!any_cov)
                     for (size_t id = 0; id < nodes.size(); id++)
                         if (!nodes[id].done) { emit((int) id); break; }
             }
@@ -571,28 +581,28 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
         for (; q < (size_t) out->tptr[(size_t) g + 1]; q++) out->tcol[q] = last;      // padding: valid row, no reader
     }
 
-    out->tsrc.assign(total * 4, -1);
+    out->tsrc.assign(total * (size_t) T, -1);
     for (int g = 0; g < nteam; g++)
-        memcpy(&out->tsrc[(size_t) out->tptr[(size_t) g] * 4], usrc[(size_t) g].data(), sizeof(int) * usrc[(size_t) g].size());
+        memcpy(&out->tsrc[(size_t) out->tptr[(size_t) g] * T], usrc[(size_t) g].data(), sizeof(int) * usrc[(size_t) g].size());
 
     // value streams: wave w of team g reads 8 values per own entry from tvoff[4g + w] on, in the
     // order it meets its entries; tq = where every entry of the panel format went
-    out->tvoff.assign((size_t) nteam * 4 + 1, 0);
+    out->tvoff.assign((size_t) nteam * T + 1, 0);
     out->tq.assign(p.pcol.size(), -1);
     {
         long long run = 0;
         for (int g = 0; g < nteam; g++)
-            for (int w = 0; w < 4; w++)
+            for (int w = 0; w < T; w++)
             {
-                out->tvoff[(size_t) g * 4 + w] = run;
+                out->tvoff[(size_t) g * T + w] = run;
                 const std::vector<int> &us = usrc[(size_t) g];
-                for (size_t t = 0; t < us.size() / 4; t++)
+                for (size_t t = 0; t < us.size() / (size_t) T; t++)
                 {
-                    const int q = us[t * 4 + (size_t) w];
+                    const int q = us[t * (size_t) T + (size_t) w];
                     if (q >= 0) out->tq[(size_t) q] = run++;
                 }
             }
-        out->tvoff[(size_t) nteam * 4] = run;
+        out->tvoff[(size_t) nteam * T] = run;
     }
 
     // processing order: XCD blocks of neighbouring team columns swept in lockstep along t (lattice),
@@ -620,22 +630,23 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
 
 void apply_team_schedule(PanelHost *p, const TeamHost &t)
 {
-    const int R = p->R;
+    const int R = p->R, T = t.T;
+    p->team_waves = T;
     std::vector<int> ncol(p->pcol.size());
     std::vector<uint32_t> nmask4(p->pmask4.size(), 0u);
     std::vector<double> nval(p->pval.size(), 0.0);
     std::vector<long long> moved(p->pcol.size(), -1);        // old entry -> new entry
     auto mask_of = [&](size_t q) { return (p->pmask4[q >> 2] >> (8 * (q & 3))) & 0xFFu; };
     for (int g = 0; g < t.nteam; g++)
-        for (int w = 0; w < 4; w++)
+        for (int w = 0; w < T; w++)
         {
-            const int panel = t.tpanel[(size_t) g * 4 + w];
+            const int panel = t.tpanel[(size_t) g * T + w];
             if (panel < 0) continue;
             size_t dst = (size_t) p->pptr[panel];
             int last = 0;
             for (int q = t.tptr[(size_t) g]; q < t.tptr[(size_t) g + 1]; q++)
             {
-                const int src = t.tsrc[(size_t) q * 4 + w];
+                const int src = t.tsrc[(size_t) q * T + w];
                 if (src < 0) continue;
                 ncol[dst] = p->pcol[(size_t) src];
                 nmask4[dst >> 2] |= mask_of((size_t) src) << (8 * (dst & 3));
@@ -650,15 +661,15 @@ void apply_team_schedule(PanelHost *p, const TeamHost &t)
     p->pcol.swap(ncol);
     p->pmask4.swap(nmask4);
     p->pval.swap(nval);
-    p->porder.assign((size_t) t.nteam * 4, -1);
+    p->porder.assign((size_t) t.nteam * T, -1);
     p->psync.assign((size_t) t.nteam, 0);
     for (int pos = 0; pos < t.nteam; pos++)
     {
         int minnr = 1 << 30;
-        for (int w = 0; w < 4; w++)
+        for (int w = 0; w < T; w++)
         {
-            const int panel = t.tpanel[(size_t) t.torder[(size_t) pos] * 4 + w];
-            p->porder[(size_t) pos * 4 + w] = panel;
+            const int panel = t.tpanel[(size_t) t.torder[(size_t) pos] * T + w];
+            p->porder[(size_t) pos * T + w] = panel;
             if (panel >= 0) minnr = std::min(minnr, (p->pptr[panel + 1] - p->pptr[panel]) / PANEL_PAD);
         }
         p->psync[(size_t) pos] = (minnr == (1 << 30) || minnr < 2) ? 0 : minnr - 1;

@@ -31,6 +31,7 @@ struct PanelHost
     std::vector<uint32_t> pmap;    // nnz: slot (q*R + r) in pval of CSR nonzero p (for value updates)
     std::vector<int>      porder;  // processing order of the panels (npanel positions; team schedule: 4 per team, -1 = none)
     std::vector<int>      psync;   // team schedule only: per workgroup, the rounds its waves start together
+    int team_waves = 4;            // waves per workgroup the processing order is laid out for (4, or 6 under the team schedule)
     long long real_entries = 0;    // entries before padding
     double fill() const;           // nnz / (real_entries * R)
     long long nnz = 0;
@@ -74,18 +75,19 @@ void lattice_coords(int panel, int R, double D1, double D2, int M, int *i, int *
 struct TeamHost
 {
     int nteam = 0;
+    int T = 4;                     // panels (= waves) per team: 4 (2 x 2 teeth) or 6 (3 x 2 teeth)
     bool lattice = false;
-    std::vector<int>      tpanel;  // 4 * nteam: panel of wave w, or -1
+    std::vector<int>      tpanel;  // T * nteam: panel of wave w, or -1
     std::vector<int>      tptr;    // nteam + 1: union entry offsets (multiples of PANEL_PAD)
     std::vector<int>      tcol;    // union entries: column index
-    std::vector<uint32_t> tmask;   // union entries: 4 row masks
+    std::vector<uint32_t> tmask;   // union entries: row masks of waves 0..3 (complete for T = 4 only)
     std::vector<int>      torder;  // processing order of the teams
-    std::vector<long long> tvoff;  // 4 * nteam + 1: first entry of wave w's value stream
+    std::vector<long long> tvoff;  // T * nteam + 1: first entry of wave w's value stream
     std::vector<long long> tq;     // per panel-format entry: its entry index in the value streams, or -1
-    std::vector<int>      tsrc;    // 4 per union entry: the panel-format entry of wave w behind it, or -1
+    std::vector<int>      tsrc;    // T per union entry: the panel-format entry of wave w behind it, or -1
     long long real_entries = 0;    // union entries before padding
 };
-void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *colidx, TeamHost *out);
+void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *colidx, TeamHost *out, int T = 4);
 
 // Team schedule for the row-panel kernel itself (no LDS sharing): the entries of every panel are
 // re-ordered to the order in which its wave meets them in the team's balanced schedule, and the

@@ -422,8 +422,9 @@ __device__ __forceinline__ void panel_consume1(const typename SlotT<VW>::type (&
 
 // DEPTH = number of 8-slot ring sets: round r lives in set r % DEPTH and is refilled, slot by
 // slot, with round r + DEPTH while it is consumed, so 8*DEPTH - 1 entries stay in flight.
-template <int R, int NV, int VW, int DEPTH, bool ADDR64, bool HAS_B1>
-__global__ __launch_bounds__(256) void spmm_panel_f64_kernel(
+// WPW = waves per workgroup: 4, or 6 when the processing order was laid out for teams of six panels
+template <int R, int NV, int VW, int DEPTH, bool ADDR64, bool HAS_B1, int WPW>
+__global__ __launch_bounds__(64 * WPW) void spmm_panel_f64_kernel(
     const int norder, const int nrow, const int n, const int *__restrict__ porder,
     const int *__restrict__ pptr, const int *__restrict__ pcol, const uint32_t *__restrict__ pmask4,
     const double *__restrict__ pval,
@@ -437,7 +438,7 @@ __global__ __launch_bounds__(256) void spmm_panel_f64_kernel(
     constexpr int NS = (CHUNK * R) / 128;        // staging loads per lane and chunk (16 B each, 64 lanes)
     static_assert(NS >= 1 && NS * 128 == CHUNK * R, "chunk must be a whole number of wave-wide 16-byte loads");
     typedef typename SlotT<VW>::type ST;
-    __shared__ __attribute__((aligned(16))) double lds_vals[4][2][CHUNK * R];
+    __shared__ __attribute__((aligned(16))) double lds_vals[WPW][2][CHUNK * R];
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -447,7 +448,7 @@ __global__ __launch_bounds__(256) void spmm_panel_f64_kernel(
     // row into all eight.  Placement only affects speed, never the result.
     const int cpx   = (gridDim.x + 7) >> 3;
     const int wg    = (blockIdx.x & 7) * cpx + (blockIdx.x >> 3);
-    const int slot_id = __builtin_amdgcn_readfirstlane((int) (wg * 4 + wave));
+    const int slot_id = __builtin_amdgcn_readfirstlane((int) (wg * WPW + wave));
     if (slot_id >= norder) return;
     // one 16-byte record per position: panel (-1: none), first entry, rounds -- a single scalar load
     // instead of the chain order -> panel -> entry range
@@ -666,15 +667,24 @@ __global__ __launch_bounds__(256) void spmm_panel_f64_kernel(
     }
 }
 
+template <int R, int NV, int VW, int DEPTH, bool ADDR64, bool HAS_B1, int WPW>
+static hipError_t launch_panel_w(const PanelArgs &p, const SpmmArgs &a, hipStream_t s)
+{
+    constexpr int TW = 64 * VW * NV;
+    const int nwg = (p.norder + WPW - 1) / WPW;
+    dim3 grid((nwg + 7) / 8 * 8, (a.n + TW - 1) / TW);      // multiple of 8 for the XCD remap
+    hipLaunchKernelGGL((spmm_panel_f64_kernel<R, NV, VW, DEPTH, ADDR64, HAS_B1, WPW>), grid, dim3(64 * WPW), 0, s, p.norder, a.nrow,
+                       a.n, p.porder, p.pptr, p.pcol, p.pmask4, p.pval, a.B0, a.ldB0, a.B1, a.ldB1, a.C, a.ldC, a.rowmap, p.psync);
+    return hipGetLastError();
+}
+
 template <int R, int NV, int VW, int DEPTH, bool ADDR64, bool HAS_B1>
 static hipError_t launch_panel(const PanelArgs &p, const SpmmArgs &a, hipStream_t s)
 {
-    constexpr int TW = 64 * VW * NV;
-    const int nwg = (p.norder + 3) / 4;
-    dim3 grid((nwg + 7) / 8 * 8, (a.n + TW - 1) / TW);      // multiple of 8 for the XCD remap
-    hipLaunchKernelGGL((spmm_panel_f64_kernel<R, NV, VW, DEPTH, ADDR64, HAS_B1>), grid, dim3(256), 0, s, p.norder, a.nrow, a.n,
-                       p.porder, p.pptr, p.pcol, p.pmask4, p.pval, a.B0, a.ldB0, a.B1, a.ldB1, a.C, a.ldC, a.rowmap, p.psync);
-    return hipGetLastError();
+    if constexpr (R == 8 && DEPTH == 1)
+        if (p.team_waves == 6) return launch_panel_w<R, NV, VW, DEPTH, ADDR64, HAS_B1, 6>(p, a, s);
+    if (p.team_waves != 4) return hipErrorInvalidValue;      // an order laid out for six-wave teams needs the six-wave body
+    return launch_panel_w<R, NV, VW, DEPTH, ADDR64, HAS_B1, 4>(p, a, s);
 }
 
 template <int R, int NV, int VW>
@@ -688,7 +698,7 @@ static hipError_t launch_panel_addr(const PanelArgs &p, const SpmmArgs &a, hipSt
     // R = 8 wide tiles only) are kept as a measurement knob: hipcc needs 326 VGPRs for that body (one
     // wave per SIMD) and it runs 40 % slower than the one-set body at three waves per SIMD.
     static const int env_depth = getenv("CRPSPMM_PANEL_DEPTH") ? atoi(getenv("CRPSPMM_PANEL_DEPTH")) : 0;
-    const bool deep = (env_depth == 2);
+    const bool deep = (env_depth == 2) && p.team_waves == 4;
     if (deep && R == 8 && NV == 2 && VW == 2)
     {
         PanelArgs q = p;

@@ -304,7 +304,7 @@ def test_b_block_beyond_4gib(crp, orc, gpu):
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("order", ["default", "0", "1", "2", "3", "3-free"])
+@pytest.mark.parametrize("order", ["default", "0", "1", "2", "3", "3-free", "3-six"])
 def test_lattice_matrix_team_paths(crp, orc, gpu, monkeypatch, order):
     """A stride-lattice matrix (two nested far strides) through every processing order of the
     row-panel kernels -- default = team schedule with the per-round workgroup barrier, "3-free" = the
@@ -315,6 +315,9 @@ def test_lattice_matrix_team_paths(crp, orc, gpu, monkeypatch, order):
     if order == "3-free":
         monkeypatch.setenv("CRPSPMM_PANEL_ORDER", "3")
         monkeypatch.setenv("CRPSPMM_TEAM_SYNC", "0")
+    elif order == "3-six":                                 # six-wave workgroups (3 x 2 teeth)
+        monkeypatch.setenv("CRPSPMM_PANEL_ORDER", "3")
+        monkeypatch.setenv("CRPSPMM_TEAM_WAVES", "6")
     elif order != "default":
         monkeypatch.setenv("CRPSPMM_PANEL_ORDER", order)
     nx, ny, nz = 300, 7, 5

@@ -370,6 +370,16 @@ def test_team_schedule_and_team_format(crp, orc, monkeypatch):
     R = 8
     npanel = (m + R - 1) // R
     monkeypatch.delenv("CRPSPMM_PANEL_ORDER", raising=False)
+    # optional layout for workgroups of six waves (3 x 2 teeth); the order covers every panel once
+    monkeypatch.setenv("CRPSPMM_TEAM_WAVES", "6")
+    po6 = hip.panel_format_host(rp, ci, va, R)["porder"]
+    assert po6.size % 6 == 0 and np.array_equal(np.sort(po6[po6 >= 0]), np.arange(npanel))
+    t6 = po6.reshape(-1, 6)
+    full6 = t6[(t6 >= 0).all(axis=1)]
+    assert full6.shape[0] > 0.6 * t6.shape[0]          # (8 teeth per block: two full 3 x 2 teams and one 2 x 2 remainder)
+    assert np.abs(np.median(full6[:, 1] - full6[:, 0]) - nx / R) <= 2 and np.abs(np.median(full6[:, 3] - full6[:, 0]) - nx * ny / R) <= 2
+    # the default: workgroups of four (2 x 2 teeth)
+    monkeypatch.delenv("CRPSPMM_TEAM_WAVES")
     f = hip.panel_format_host(rp, ci, va, R)
     po = f["porder"]
     assert po.size % 4 == 0 and po.size >= npanel
