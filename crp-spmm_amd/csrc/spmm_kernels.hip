@@ -16,6 +16,12 @@
 #include <type_traits>
 #include "kernels.h"
 
+#ifdef CRP_ABL_PLAINSTORE     // timing experiment: C through the default (write-back) store path
+#define CRP_STORE(val, ptr) (*(ptr) = (val))
+#else
+#define CRP_STORE(val, ptr) __builtin_nontemporal_store((val), (ptr))
+#endif
+
 namespace crp {
 
 typedef double d2 __attribute__((ext_vector_type(2)));
@@ -659,9 +665,9 @@ __global__ __launch_bounds__(64 * WPW) void spmm_panel_f64_kernel(
                         d2 t;
                         t.x = acc[r][v][0];
                         t.y = acc[r][v][1];
-                        __builtin_nontemporal_store(t, reinterpret_cast<d2 *>(crow + coff[v]));
+                        CRP_STORE(t, reinterpret_cast<d2 *>(crow + coff[v]));
                     }
-                    else __builtin_nontemporal_store(acc[r][v][0], crow + coff[v]);
+                    else CRP_STORE(acc[r][v][0], crow + coff[v]);
                 }
         }
     }
