@@ -249,11 +249,32 @@ bool detect_stride_lattice(int nrow, const int *rowptr, const int *colidx, int R
             sm += sum[e];
             e++;
         }
-        if (k > 0 && w * 100 >= total * 6) far.push_back({w, (double) sm / (double) w});
+        if (k > 0 && w * 100 >= total * 2) far.push_back({w, (double) sm / (double) w});
         k = e;
     }
-    if (far.size() != 2) return false;          // exactly the two-stride shape; anything else is left alone
-    const double D1 = far[0].center, D2 = far[1].center;
+    // D1 = the nearest far cluster that carries >= 6 % of the nonzeros.  The outer stride may show up as
+    // several clusters (a 27-point stencil has nx*ny - nx, nx*ny, nx*ny + nx): clusters within 1.5 D1 of
+    // each other are one group, D2 = centre of mass of the heaviest group beyond D1 (>= 6 % as well).
+    // Anything between the two, or beyond the second, means another shape: left alone.
+    size_t i1 = far.size();
+    for (size_t t = 0; t < far.size(); t++)
+        if (far[t].w * 100 >= total * 6) { i1 = t; break; }
+    if (i1 > 0 || i1 + 1 >= far.size()) return false;        // (a light cluster in front of D1 would be a third stride)
+    const double D1 = far[0].center;
+    double D2 = 0.0;
+    {
+        long long gw = 0;
+        double gs = 0.0, first = far[1].center, last = far[1].center;
+        for (size_t t = 1; t < far.size(); t++)
+        {
+            if (far[t].center - last > 1.5 * D1) return false;          // a second group further out
+            gw += far[t].w;
+            gs += far[t].center * (double) far[t].w;
+            last = far[t].center;
+        }
+        if (gw * 100 < total * 6 || last - first > 3.0 * D1) return false;
+        D2 = gs / (double) gw;
+    }
     const double ratio = D2 / D1;
     const int M = (int) (ratio + 0.5);
     if (D1 < 32.0 * R || M < 2 || std::abs(ratio - M) > 0.02 * M || D2 * 2 > nrow) return false;

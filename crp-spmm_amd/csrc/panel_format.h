@@ -52,9 +52,10 @@ void locality_order(const PanelHost &p, int group, std::vector<int> *order);
 // touch the same B rows (one through its near band, its neighbours through a far band), so every XCD
 // gets a block of neighbouring teeth -- consecutive i, all j -- and sweeps them in lockstep along t:
 // the five temporally distant touches of a B row become touches that are in flight together on
-// one XCD.  Strides are detected from the histogram of |col - row| (two far clusters, each >= 6 % of
-// the nonzeros, D2 an integer multiple of D1 within 2 %); returns false when the matrix does not
-// look like that (the caller then uses locality_order()).  `chunk` = order positions per XCD.
+// one XCD.  Strides are detected from the histogram of |col - row|: D1 = the nearest far cluster, D2 =
+// the centre of the group of clusters beyond it (a 27-point stencil spreads the outer stride over
+// nx*ny - nx, nx*ny, nx*ny + nx), each >= 6 % of the nonzeros, D2 an integer multiple of D1 within 2 %;
+// returns false when the matrix does not look like that (the caller then uses locality_order()).  `chunk` = order positions per XCD.
 bool stride_lattice_order(int nrow, const int *rowptr, const int *colidx, int R, int npanel, int chunk,
                           std::vector<int> *order);
 

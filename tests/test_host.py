@@ -427,6 +427,14 @@ def test_team_schedule_and_team_format(crp, orc, monkeypatch):
             assert sorted(t["tcol"][sl][mine].tolist()) == sorted(f0["pcol"][q0:q1][real].tolist()), (g, w)
             # the team-scheduled panel format holds the wave's entries in exactly this order
             assert t["tcol"][sl][mine].tolist() == f["pcol"][f["pptr"][panel]:f["pptr"][panel + 1]][:mine.sum()].tolist()
+    # the outer stride may be a group of clusters (27-point stencil: nx*ny - nx, nx*ny, nx*ny + nx); one stride
+    # alone, or a third one further out, is not a lattice
+    gx, gy, gz = 300, 10, 6
+    mm = gx * gy * gz
+    o27 = (1, 2, gx - 1, gx, gx + 1, gx * gy - gx, gx * gy - gx + 1, gx * gy - 1, gx * gy, gx * gy + 1, gx * gy + gx - 1, gx * gy + gx)
+    assert hip.team_format_host(*gen.banded_fem(mm, offsets=o27, seed=1))["lattice"]
+    assert not hip.team_format_host(*gen.banded_fem(mm, offsets=(1, 2, gx), seed=1))["lattice"]
+    assert not hip.team_format_host(*gen.banded_fem(mm, offsets=(1, 2, gx, gx * gy, 3 * gx * gy + 7), seed=1))["lattice"]
     # matrices without a lattice: four consecutive panels per team
     rp2, ci2, va2 = gen.random_csr(300, 300, 12, seed=5)
     t2 = hip.team_format_host(rp2, ci2, va2)
