@@ -102,6 +102,7 @@ SIGNATURES = {
     "crp_hip_set_device": (_I, [_I]),
     "crp_hip_get_device": (_I, [c_int_p]),
     "crp_hip_device_info": (_I, [_I, C.c_char_p, c_int_p, c_sz_p]),
+    "crp_hip_device_bus_id": (_I, [C.c_char_p, C.c_size_t]),
     "crp_dev_malloc": (_I, [C.POINTER(_V), C.c_size_t]),
     "crp_dev_free": (_I, [_V]),
     "crp_dev_memset": (_I, [_V, _I, C.c_size_t, _V]),

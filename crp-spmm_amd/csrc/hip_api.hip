@@ -194,6 +194,15 @@ int crp_hip_device_info(int dev, char *name, int *cu_count, size_t *hbm_bytes)
     return 0;
 }
 
+int crp_hip_device_bus_id(char *out, size_t len)
+{
+    if (out == NULL || len < 16) return -1;
+    int dev = 0;
+    CRP_TRY(hipGetDevice(&dev));
+    CRP_TRY(hipDeviceGetPCIBusId(out, (int) len, dev));
+    return 0;
+}
+
 int crp_dev_malloc(void **ptr, size_t bytes)
 {
     if (ptr == NULL) return -1;

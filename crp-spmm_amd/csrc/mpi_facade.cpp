@@ -4,16 +4,20 @@
 //
 // crp_comm_t over MPI: the control-plane members call the same MPI routines the
 // reference calls (src/rowpara_spmm.c:154-162,439-442; src/para2d_spmm.c:41-83).
-// The per-multiply B exchange moves DEVICE buffers; with a plain (not GPU-aware)
-// MPI it is staged through pinned host buffers the way the reference's
-// mat_redist stages CUDA memory (src/mat_redist.c:362-378), honouring RP_SPMM_P2P
-// (ring-ordered Isend/Irecv, src/rowpara_spmm.c:275-303) or MPI_Alltoallv (:305-308).
+// The per-multiply B exchange moves DEVICE buffers.  With one GPU per rank it is RCCL: an RCCL
+// communicator is bootstrapped over the MPI one (unique id broadcast by rank 0) the first time a
+// device exchange is asked for, and the sparse all-to-all is one group of ncclSend / ncclRecv on the
+// caller's stream (peers with nothing to exchange are skipped) -- device to device over xGMI, no
+// host copy, asynchronous.  When ranks share a GPU (RCCL refuses that), when RCCL cannot be set
+// up, or with CRPSPMM_EXCHANGE=host, the payload is staged through host buffers and plain MPI
+// point-to-point in the reference's ring order (src/rowpara_spmm.c:275-303).
 #include <limits.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
 #include <mpi.h>
+#include <rccl/rccl.h>
 #include "crp_engine.h"
 #include "crpspmm_hip.h"
 #include "mat_redist.h"
@@ -30,7 +34,50 @@ struct MpiCtx
     bool     owned;
     int      p2p;
     std::vector<double> hsend, hrecv;   // host staging of the device exchange
+    ncclComm_t nccl = nullptr;
+    int        nccl_state = 0;          // 0 not tried yet, 1 usable, -1 host staging
 };
+
+// Collective over x->comm: decide once how device payloads travel.
+bool rccl_ready(MpiCtx *x)
+{
+    if (x->nccl_state != 0) return x->nccl_state > 0;
+    x->nccl_state = -1;
+    int P, me;
+    MPI_Comm_size(x->comm, &P);
+    MPI_Comm_rank(x->comm, &me);
+    const char *env = getenv("CRPSPMM_EXCHANGE");
+    int want = !(env != NULL && strcmp(env, "host") == 0);
+    // every rank needs a GPU of its own: compare the PCI bus ids
+    char mine[64] = {0};
+    if (crp_hip_device_bus_id(mine, sizeof(mine)) != 0) want = 0;
+    std::vector<char> all((size_t) P * 64, 0);
+    MPI_Allgather(mine, 64, MPI_CHAR, all.data(), 64, MPI_CHAR, x->comm);
+    for (int a = 0; a < P && want; a++)
+        for (int b = a + 1; b < P; b++)
+            if (strncmp(&all[(size_t) a * 64], &all[(size_t) b * 64], 64) == 0) want = 0;
+    int all_want = 0;
+    MPI_Allreduce(&want, &all_want, 1, MPI_INT, MPI_MIN, x->comm);
+    if (!all_want) return false;
+    ncclUniqueId id;
+    memset(&id, 0, sizeof(id));
+    int ok = 1;
+    if (me == 0) ok = (ncclGetUniqueId(&id) == ncclSuccess);
+    MPI_Bcast(&ok, 1, MPI_INT, 0, x->comm);
+    if (!ok) return false;
+    MPI_Bcast(&id, (int) sizeof(id), MPI_BYTE, 0, x->comm);
+    ok = (ncclCommInitRank(&x->nccl, P, id, me) == ncclSuccess);
+    int all_ok = 0;
+    MPI_Allreduce(&ok, &all_ok, 1, MPI_INT, MPI_MIN, x->comm);
+    if (!all_ok)
+    {
+        if (ok && x->nccl) ncclCommDestroy(x->nccl);
+        x->nccl = nullptr;
+        return false;
+    }
+    x->nccl_state = 1;
+    return true;
+}
 
 void m_alltoall(void *c, const int *s, int *r, int count)
 {
@@ -71,6 +118,20 @@ void m_alltoallv_dev(void *c, const double *send_dev, const long long *sc, const
     int P, me;
     MPI_Comm_size(x->comm, &P);
     MPI_Comm_rank(x->comm, &me);
+    if (rccl_ready(x))
+    {
+        ncclResult_t r = ncclGroupStart();
+        for (int i = 0; i < P && r == ncclSuccess; i++)
+        {
+            const int q = (me + i) % P;
+            if (rc[q] > 0) r = ncclRecv(recv_dev + rd[q], (size_t) rc[q], ncclDouble, q, x->nccl, (hipStream_t) stream);
+            if (r == ncclSuccess && sc[q] > 0)
+                r = ncclSend(send_dev + sd[q], (size_t) sc[q], ncclDouble, q, x->nccl, (hipStream_t) stream);
+        }
+        if (r == ncclSuccess) r = ncclGroupEnd();
+        ASSERT_PRINTF(r == ncclSuccess, "RCCL exchange failed: %s\n", ncclGetErrorString(r));
+        return;
+    }
     const long long ns = sd[P], nr = rd[P];
     if ((long long) x->hsend.size() < ns) x->hsend.resize((size_t) ns);
     if ((long long) x->hrecv.size() < nr) x->hrecv.resize((size_t) nr);
@@ -103,6 +164,7 @@ void m_alltoallv_dev(void *c, const double *send_dev, const long long *sc, const
             MPI_Isend(x->hsend.data() + sd[dst] + off, cnt, MPI_DOUBLE, dst, me, x->comm, &reqs.back());
         }
     }
+    if (sc[me] > 0) memcpy(x->hrecv.data() + rd[me], x->hsend.data() + sd[me], sizeof(double) * (size_t) sc[me]);   // own block
     MPI_Waitall((int) reqs.size(), reqs.data(), MPI_STATUSES_IGNORE);
     if (nr > 0)
     {
@@ -139,6 +201,7 @@ crp_comm_t *m_split(void *c, int color, int key)
 void m_free(crp_comm_t *self)
 {
     MpiCtx *x = (MpiCtx *) self->ctx;
+    if (x->nccl) ncclCommDestroy(x->nccl);
     if (x->owned) MPI_Comm_free(&x->comm);
     delete x;
     free(self);
@@ -336,6 +399,17 @@ void crpspmm_engine_clear_stat(crpspmm_engine_p s)
     if (s == NULL) return;
     crp_crpspmm_clear_stat(((CeGlue *) s->impl)->eng);
     ce_sync_public(s);
+}
+
+crp_comm_t *crp_mpi_comm_wrap(MPI_Comm comm)
+{
+    select_device_once();
+    return wrap(comm, false);
+}
+
+int crp_mpi_comm_uses_rccl(crp_comm_t *c)
+{
+    return (c != NULL && rccl_ready((MpiCtx *) c->ctx)) ? 1 : 0;
 }
 
 void rp_spmm_init(const int A_srow, const int A_nrow, const int *A_rowptr, const int *A_colidx, const double *A_val,

@@ -48,6 +48,9 @@ int crp_hip_get_device(int *dev);
 /* name must hold >= 256 bytes; cu_count / hbm_bytes may be NULL. */
 int crp_hip_device_info(int dev, char *name, int *cu_count, size_t *hbm_bytes);
 
+/* PCI bus id of the current device ("0000:c1:00.0"): tells whether two ranks share a GPU. len >= 16. */
+int crp_hip_device_bus_id(char *out, size_t len);
+
 int crp_dev_malloc(void **ptr, size_t bytes);
 int crp_dev_free(void *ptr);
 int crp_dev_memset(void *ptr, int value, size_t bytes, void *stream);

@@ -65,3 +65,18 @@ def test_crpspmm_engine_driver(np_):
 def test_crpspmm_engine_driver_env_knob():
     out = _run("test_crpspmm.exe", 2, "g_symm.mtx", 16, {"A2A_B_FINEGRAIN": "1"}, tail=("1", "1"))
     assert "Overriding parameter a2a_B_finegrain: 0 (default) --> 1 (runtime)" in out
+
+
+@pytest.mark.parametrize("np_", [1, 2, 3])
+def test_mpi_backend_device_exchange(np_):
+    """include/crp_mpi.h: the device all-to-all of the MPI communicator back end on its own.  One rank
+    has the GPU to itself and goes through RCCL (grouped ncclSend / ncclRecv); several ranks on the one
+    GPU of the test box fall back to host staging -- both must deliver every block."""
+    path = os.path.join(ROOT, "examples", "rccl_probe.exe")
+    if not os.path.exists(path) or not os.path.exists(MPIEXEC):
+        pytest.skip("no MPI launcher / example programs not built on this machine")
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    env["PATH"] = os.path.dirname(MPIEXEC) + ":" + env["PATH"]
+    r = subprocess.run([MPIEXEC, "-np", str(np_), path], capture_output=True, text=True, env=env, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert ("transport rccl, ok" if np_ == 1 else "transport host-staged, ok") in r.stdout, r.stdout[-500:]

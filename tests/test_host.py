@@ -57,7 +57,9 @@ def test_mpi_facade_exports_reference_api(crp):
                "mat_redist_engine_exec", "mat_redist_engine_free",
                # deprecated/src/crpspmm.h:89-130
                "crpspmm_engine_init", "crpspmm_engine_attach_workbuf", "crpspmm_engine_exec", "crpspmm_engine_free",
-               "crpspmm_engine_print_stat", "crpspmm_engine_clear_stat"):
+               "crpspmm_engine_print_stat", "crpspmm_engine_clear_stat",
+               # include/crp_mpi.h
+               "crp_mpi_comm_wrap", "crp_mpi_comm_uses_rccl"):
         assert fn in exported, fn
 
 
