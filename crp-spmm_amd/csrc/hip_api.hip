@@ -38,6 +38,19 @@ struct TeamDev
     bool lattice = false;
 };
 
+struct Team2Dev
+{
+    bool built = false;
+    int  nteam = 0;
+    int *torder = nullptr, *tpanel = nullptr, *tinfo = nullptr, *tcol0 = nullptr;
+    uint32_t *trec = nullptr;
+    long long *tvoff = nullptr;
+    double   *tval = nullptr;
+    uint32_t *tmap = nullptr;      // per CSR nonzero: its slot in tval (value updates)
+    long long entries = 0, value_entries = 0;
+    bool lattice = false;
+};
+
 struct crp_csr_dev
 {
     int       nrow = 0;
@@ -51,6 +64,7 @@ struct crp_csr_dev
     std::vector<double> h_val;
     PanelDev pan[2];          // [0]: R = 4, [1]: R = 8
     TeamDev  team;            // teams of four R = 8 panels (variant 4)
+    Team2Dev team2;           // teams of eight R = 8 panels, LDS-shared B rows (variant 5)
     int      auto_variant = 1; // what variant 0 resolves to (1 rowgroup, 2 panel R4, 3 panel R8)
     long long b0_rows = 0, b1_rows = 0;   // 1 + largest local / receive-buffer row a column index addresses
     int      *rowmap = nullptr;           // row-subset matrices: C row of every row (device), else nullptr
@@ -160,6 +174,45 @@ static int ensure_team(crp_csr_dev *A)
     for (size_t pz = 0; pz < h.pmap.size(); pz++) tmap[pz] = (uint32_t) (th.tq[h.pmap[pz] >> 3] * 8 + (h.pmap[pz] & 7));
     if (e == hipSuccess) e = up((void **) &t.tvoff, th.tvoff.data(), sizeof(long long) * th.tvoff.size(), 8);
     if (e == hipSuccess) e = up((void **) &t.tval, tval.data(), sizeof(double) * tval.size(), 1024);
+    if (e == hipSuccess) e = up((void **) &t.tmap, tmap.data(), sizeof(uint32_t) * tmap.size(), 4);
+    if (e != hipSuccess) return (int) e;
+    t.built = true;
+    return 0;
+}
+
+// Build (once) and upload the team2 streams on top of the R = 8 panels (column-ordered entries). Blocking.
+static int ensure_team2(crp_csr_dev *A)
+{
+    Team2Dev &t = A->team2;
+    if (t.built) return 0;
+    crp::PanelHost h;
+    crp::build_panels(A->nrow, A->h_rowptr.data(), A->h_colidx.data(), A->h_val.data(), 8, &h, false);
+    crp::Team2Host th;
+    crp::build_team2(h, A->nrow, A->h_rowptr.data(), A->h_colidx.data(), &th);
+    t.nteam = th.nteam;
+    t.entries = th.real_entries;
+    t.lattice = th.lattice;
+    auto up = [](void **dst, const void *src, size_t bytes, size_t pad) -> hipError_t {
+        hipError_t e = hipMalloc(dst, bytes + pad);
+        if (e == hipSuccess && pad) e = hipMemset((char *) *dst + bytes, 0, pad);
+        if (e == hipSuccess && bytes) e = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+        return e;
+    };
+    hipError_t e = up((void **) &t.torder, th.torder.data(), sizeof(int) * th.torder.size(), 4);
+    if (e == hipSuccess) e = up((void **) &t.tpanel, th.tpanel.data(), sizeof(int) * th.tpanel.size(), 4);
+    if (e == hipSuccess) e = up((void **) &t.tinfo, th.tinfo.data(), sizeof(int) * th.tinfo.size(), 16);
+    if (e == hipSuccess) e = up((void **) &t.tcol0, th.tcol0.data(), sizeof(int) * th.tcol0.size(), 4);
+    if (e == hipSuccess) e = up((void **) &t.trec, th.trec.data(), sizeof(uint32_t) * th.trec.size(), 1024);
+    const long long nent = th.tvoff.back();
+    t.value_entries = nent;
+    std::vector<double> tval((size_t) nent * 8, 0.0);
+    for (size_t q = 0; q < th.tq.size(); q++)
+        if (th.tq[q] >= 0) memcpy(&tval[(size_t) th.tq[q] * 8], &h.pval[q * 8], sizeof(double) * 8);
+    std::vector<uint32_t> tmap(h.pmap.size());
+    for (size_t pz = 0; pz < h.pmap.size(); pz++) tmap[pz] = (uint32_t) (th.tq[h.pmap[pz] >> 3] * 8 + (h.pmap[pz] & 7));
+    if (e == hipSuccess) e = up((void **) &t.tvoff, th.tvoff.data(), sizeof(long long) * th.tvoff.size(), 8);
+    // the kernel requests whole 512-byte chunks up to two chunks past a wave's last entry
+    if (e == hipSuccess) e = up((void **) &t.tval, tval.data(), sizeof(double) * tval.size(), 4096);
     if (e == hipSuccess) e = up((void **) &t.tmap, tmap.data(), sizeof(uint32_t) * tmap.size(), 4);
     if (e != hipSuccess) return (int) e;
     t.built = true;
@@ -413,6 +466,14 @@ int crp_csr_dev_destroy(crp_csr_dev_p *A_)
     if (A->team.tvoff) (void) hipFree(A->team.tvoff);
     if (A->team.tval) (void) hipFree(A->team.tval);
     if (A->team.tmap) (void) hipFree(A->team.tmap);
+    if (A->team2.torder) (void) hipFree(A->team2.torder);
+    if (A->team2.tpanel) (void) hipFree(A->team2.tpanel);
+    if (A->team2.tinfo) (void) hipFree(A->team2.tinfo);
+    if (A->team2.tcol0) (void) hipFree(A->team2.tcol0);
+    if (A->team2.trec) (void) hipFree(A->team2.trec);
+    if (A->team2.tvoff) (void) hipFree(A->team2.tvoff);
+    if (A->team2.tval) (void) hipFree(A->team2.tval);
+    if (A->team2.tmap) (void) hipFree(A->team2.tmap);
     if (A->rowptr) (void) hipFree(A->rowptr);
     if (A->colidx) (void) hipFree(A->colidx);
     if (A->val) (void) hipFree(A->val);
@@ -430,6 +491,7 @@ int crp_csr_dev_update_values(crp_csr_dev_p A, const double *val, void *stream)
     for (int i = 0; i < 2; i++)
         if (A->pan[i].built && A->pan[i].entries * (long long) A->pan[i].R >= (1LL << 32)) return -5;
     if (A->team.built && A->team.entries * 8LL >= (1LL << 32)) return -5;
+    if (A->team2.built && A->team2.value_entries * 8LL >= (1LL << 32)) return -5;
     int is_dev = 0;
     crp_dev_ptr_is_device(val, &is_dev);
     CRP_TRY(hipMemcpyAsync(A->val, val, sizeof(double) * (size_t) A->nnz, is_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
@@ -439,6 +501,7 @@ int crp_csr_dev_update_values(crp_csr_dev_p A, const double *val, void *stream)
         if (A->pan[i].built)
             CRP_TRY(crp::scatter_vals_f64(A->nnz, A->pan[i].pmap, A->val, A->pan[i].pval, (hipStream_t) stream));
     if (A->team.built) CRP_TRY(crp::scatter_vals_f64(A->nnz, A->team.tmap, A->val, A->team.tval, (hipStream_t) stream));
+    if (A->team2.built) CRP_TRY(crp::scatter_vals_f64(A->nnz, A->team2.tmap, A->val, A->team2.tval, (hipStream_t) stream));
     return 0;
 }
 
@@ -460,7 +523,7 @@ int crp_csr_dev_nrow(crp_csr_dev_p A) { return A ? A->nrow : -1; }
 long long crp_csr_dev_nnz(crp_csr_dev_p A) { return A ? A->nnz : -1; }
 long long crp_csr_dev_bytes(crp_csr_dev_p A) { return A ? 12LL * A->nnz + 4LL * ((long long) A->nrow + 1) : -1; }
 
-static const char *k_variant_names[] = {"auto", "csr-rowgroup", "rowpanel-R4", "rowpanel-R8", "team-R8"};
+static const char *k_variant_names[] = {"auto", "csr-rowgroup", "rowpanel-R4", "rowpanel-R8", "team-R8", "team2-R8"};
 int crp_spmm_variant_count(void) { return (int) (sizeof(k_variant_names) / sizeof(k_variant_names[0])); }
 const char *crp_spmm_variant_name(int variant)
 {
@@ -486,6 +549,16 @@ int crp_spmm_csr_f64(crp_csr_dev_p A, int layout, int n, const double *B0, long 
     hipError_t e;
     if (layout == CRP_LAYOUT_COL_MAJOR) return (int) crp::spmm_cm_f64(a, (hipStream_t) stream);
     int v = (variant == 0) ? A->auto_variant : variant;
+    if (v == 5 && (!crp::spmm_team2_applicable(a) || A->nnz == 0 || A->nrow < 8)) v = 3;
+    if (v == 5)
+    {
+        const int rc = ensure_team2(A);
+        if (rc != 0) return rc;
+        crp::Team2Args t;
+        t.nteam = A->team2.nteam; t.torder = A->team2.torder; t.tpanel = A->team2.tpanel; t.tinfo = A->team2.tinfo;
+        t.tcol0 = A->team2.tcol0; t.trec = A->team2.trec; t.tvoff = A->team2.tvoff; t.tval = A->team2.tval;
+        return (int) crp::spmm_rm_f64_team2(t, a, (hipStream_t) stream);
+    }
     if (v == 4 && (!crp::spmm_team_applicable(a) || A->b1_rows > 0)) v = 3;   // team kernel: one B source, 256-column tile
     if (v >= 2 && (!crp::spmm_panel_applicable(a) || A->nnz == 0)) v = 1;   // narrow / unaligned operands
     if (v == 4)
@@ -561,6 +634,41 @@ int crp_team_format_host(int nrow, const int *rowptr, const int *colidx, const d
     *torder = dup_i(th.torder);
     *tmask = (unsigned *) malloc(sizeof(unsigned) * (th.tmask.size() + 1));
     if (!th.tmask.empty()) memcpy(*tmask, th.tmask.data(), sizeof(unsigned) * th.tmask.size());
+    return 0;
+}
+
+int crp_team2_format_host(int nrow, const int *rowptr, const int *colidx, const double *val, int *nteam, int *lattice,
+                          int **tpanel, int **tinfo, int **tcol0, unsigned **trec, long long *nrecwords,
+                          long long **tvoff, double **tval, long long *nvalent, int **torder)
+{
+    if (nrow < 0 || rowptr == NULL || !nteam || !tpanel || !tinfo || !tcol0 || !trec || !nrecwords || !tvoff || !tval ||
+        !nvalent || !torder)
+        return -1;
+    crp::PanelHost h;
+    crp::build_panels(nrow, rowptr, colidx, val, 8, &h, false);
+    crp::Team2Host th;
+    crp::build_team2(h, nrow, rowptr, colidx, &th);
+    *nteam = th.nteam;
+    if (lattice) *lattice = th.lattice ? 1 : 0;
+    auto dup_i = [](const std::vector<int> &v) {
+        int *p = (int *) malloc(sizeof(int) * (v.size() + 1));
+        if (!v.empty()) memcpy(p, v.data(), sizeof(int) * v.size());
+        return p;
+    };
+    *tpanel = dup_i(th.tpanel);
+    *tinfo = dup_i(th.tinfo);
+    *tcol0 = dup_i(th.tcol0);
+    *torder = dup_i(th.torder);
+    *trec = (unsigned *) malloc(sizeof(unsigned) * (th.trec.size() + 1));
+    if (!th.trec.empty()) memcpy(*trec, th.trec.data(), sizeof(unsigned) * th.trec.size());
+    *nrecwords = (long long) th.trec.size();
+    *tvoff = (long long *) malloc(sizeof(long long) * (th.tvoff.size() + 1));
+    memcpy(*tvoff, th.tvoff.data(), sizeof(long long) * th.tvoff.size());
+    const long long nent = th.tvoff.back();
+    *nvalent = nent;
+    *tval = (double *) calloc((size_t) nent * 8 + 1, sizeof(double));
+    for (size_t q = 0; q < th.tq.size(); q++)
+        if (th.tq[q] >= 0) memcpy(*tval + (size_t) th.tq[q] * 8, &h.pval[q * 8], sizeof(double) * 8);
     return 0;
 }
 

@@ -50,6 +50,18 @@ struct TeamArgs
     const double   *tval;      // value streams, 8 values per own entry
 };
 
+struct Team2Args          // panel_format.h, Team2Host
+{
+    int nteam;
+    const int      *torder;
+    const int      *tpanel;    // 8 * nteam
+    const int      *tinfo;     // 4 * nteam: rounds, first record block, union entries, 0
+    const int      *tcol0;     // nteam * TEAM2_D * 8
+    const uint32_t *trec;      // record blocks (1 KiB each)
+    const long long *tvoff;    // 8 * nteam
+    const double   *tval;
+};
+
 // spmm_kernels.hip
 hipError_t spmm_rm_f64_rowgroup(const SpmmArgs &a, hipStream_t s);
 hipError_t spmm_cm_f64(const SpmmArgs &a, hipStream_t s);
@@ -57,6 +69,10 @@ bool spmm_panel_applicable(const SpmmArgs &a);
 hipError_t spmm_rm_f64_panel(const PanelArgs &p, const SpmmArgs &a, hipStream_t s);
 bool spmm_team_applicable(const SpmmArgs &a);
 hipError_t spmm_rm_f64_team(const TeamArgs &t, const SpmmArgs &a, hipStream_t s);
+
+// team2_kernel.hip
+bool spmm_team2_applicable(const SpmmArgs &a);
+hipError_t spmm_rm_f64_team2(const Team2Args &t, const SpmmArgs &a, hipStream_t s);
 
 // row_kernels.hip
 hipError_t gather_rows_f64(int layout, int nidx, int n, const int *ridx, const double *src, int64_t lds,

@@ -412,13 +412,23 @@ void locality_order(const PanelHost &p, int group, std::vector<int> *order)
 void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *colidx, TeamHost *out, int T)
 {
     constexpr int TMAX = 8;
-    if (T != 4 && T != 6) T = 4;
+    if (T != 4 && T != 6 && T != 8) T = 4;
     const int TI = T / 2;                 // lattice teams: TI teeth along i times 2 along j
     out->T = T;
     const int np = p.npanel, R = p.R;
     double D1 = 0, D2 = 0;
     int M = 0;
-    const bool lattice = (np >= 64) && detect_stride_lattice(nrow, rowptr, colidx, R, &D1, &D2, &M);
+    bool lattice = (np >= 64) && detect_stride_lattice(nrow, rowptr, colidx, R, &D1, &D2, &M);
+    // teams of eight (team2): shape of a team in tooth coordinates, si x sj teeth x st consecutive panels along
+    // the teeth (CRPSPMM_TEAM2_SHAPE=si,sj,st with si * sj * st = 8; "0" = eight consecutive panels even on a lattice)
+    int si = TI, sj = 2, st = 1;
+    if (T == 8)
+        if (const char *es = getenv("CRPSPMM_TEAM2_SHAPE"); es != NULL)
+        {
+            int a = 0, b = 0, c = 0;
+            if (sscanf(es, "%d,%d,%d", &a, &b, &c) == 3 && a > 0 && b > 0 && c > 0 && a * b * c == 8) { si = a; sj = b; st = c; }
+            else if (atoi(es) == 0) lattice = false;
+        }
     out->lattice = lattice;
     // membership: (team key, slot)
     struct Mem { long long key; int slot, panel, a, b, t; };
@@ -429,8 +439,8 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
         {
             int i, j, t;
             lattice_coords(q, R, D1, D2, M, &i, &j, &t);
-            const int a = i / TI, b = j >> 1;
-            mem[(size_t) q] = {((long long) a << 40) | ((long long) b << 24) | (long long) t, (i % TI) + TI * (j & 1), q, a, b, t};
+            const int a = i / si, b = j / sj, tt = t / st;
+            mem[(size_t) q] = {((long long) a << 40) | ((long long) b << 24) | (long long) tt, (i % si) + si * ((j % sj) + sj * (t % st)), q, a, b, tt};
         }
         else mem[(size_t) q] = {(long long) (q / T), q % T, q, 0, 0, q / T};
     }
@@ -647,6 +657,69 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
             });
         }
     }
+}
+
+// ---- team2 streams (panel_format.h) ------------------------------------------------------------------
+void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *colidx, Team2Host *out)
+{
+    constexpr int T = TEAM2_T, D = TEAM2_D;
+    TeamHost th;
+    build_teams(p, nrow, rowptr, colidx, &th, T);
+    const int nteam = th.nteam;
+    out->nteam = nteam;
+    out->lattice = th.lattice;
+    out->tpanel = th.tpanel;
+    out->torder = th.torder;
+    out->tvoff = th.tvoff;
+    out->tq = th.tq;
+    out->real_entries = th.real_entries;
+    out->tinfo.assign((size_t) nteam * 4, 0);
+    out->tcol0.assign((size_t) nteam * D * 8, 0);
+    // record blocks per team
+    std::vector<int> blk0((size_t) nteam + 1, 0);
+    for (int g = 0; g < nteam; g++)
+    {
+        const int nr = (th.tptr[(size_t) g + 1] - th.tptr[(size_t) g]) / 8;
+        blk0[(size_t) g + 1] = blk0[(size_t) g] + (nr + 7) / 8;
+        out->tinfo[(size_t) g * 4] = nr;
+        out->tinfo[(size_t) g * 4 + 1] = blk0[(size_t) g];
+    }
+    out->trec.assign((size_t) blk0[(size_t) nteam] * 256 + 256, 0u);
+    auto mask_of = [&](size_t q) { return (p.pmask4[q >> 2] >> (8 * (q & 3))) & 0xFFu; };
+    parallel_chunks(nteam, 64, [&](long long b, long long e, int) {
+        for (long long g = b; g < e; g++)
+        {
+            const int q0 = th.tptr[(size_t) g], nr = out->tinfo[(size_t) g * 4];
+            int real = 0;
+            for (int r = 0; r < nr; r++)
+                for (int w = 0; w < T; w++)
+                {
+                    uint32_t x = 0, y = 0, z = 0;
+                    int c = 0;
+                    for (int e8 = 0; e8 < 8; e8++)
+                    {
+                        const int src = th.tsrc[((size_t) q0 + (size_t) r * 8 + (size_t) e8) * T + (size_t) w];
+                        if (src < 0) continue;
+                        const uint32_t m = mask_of((size_t) src);
+                        x |= (uint32_t) e8 << (4 + 3 * c);
+                        if (c < 4) y |= m << (8 * c); else z |= m << (8 * (c - 4));
+                        c++;
+                    }
+                    x |= (uint32_t) c;
+                    real += c;
+                    // the column this wave fetches D rounds ahead (padding entries repeat a valid column)
+                    const int rd = r + D;
+                    const int dcol = (rd < nr) ? th.tcol[(size_t) q0 + (size_t) rd * 8 + (size_t) w] : th.tcol[(size_t) q0];
+                    uint32_t *rec = &out->trec[((size_t) blk0[(size_t) g] + (size_t) (r >> 3)) * 256 + (size_t) (r & 7) * 32 + (size_t) w * 4];
+                    rec[0] = x; rec[1] = y; rec[2] = z; rec[3] = (uint32_t) dcol;
+                }
+            for (int d = 0; d < D; d++)
+                for (int w = 0; w < T; w++)
+                    out->tcol0[((size_t) g * D + (size_t) d) * 8 + (size_t) w] =
+                        (d < nr) ? th.tcol[(size_t) q0 + (size_t) d * 8 + (size_t) w] : (nr > 0 ? th.tcol[(size_t) q0] : 0);
+            out->tinfo[(size_t) g * 4 + 2] = real;
+        }
+    });
 }
 
 void apply_team_schedule(PanelHost *p, const TeamHost &t)

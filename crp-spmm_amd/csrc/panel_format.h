@@ -97,6 +97,34 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
 // number of own entries, i.e. at nearly the same time, and the later ones find the row in L2.
 void apply_team_schedule(PanelHost *p, const TeamHost &t);
 
+// ---- team2: the streams of the LDS-sharing kernel of csrc/team2_kernel.hip ---------------------------
+// A team is TEAM2_T = 8 panels, one per wave of a 512-thread workgroup.  The union of their columns
+// (TeamHost: merged, in a balanced schedule) is walked in rounds of 8 union entries; wave w fetches entry w
+// of a round (one B row slice) by LDS-DMA into a ring shared by the workgroup, TEAM2_D rounds ahead.
+// Per (round, wave) one 16-byte record tells a wave what it owns in the round:
+//   x : bits 0-3 = number of own entries c (0..8); bits 4+3i .. 6+3i = ring slot (0..7) of own entry i
+//   y : row masks of own entries 0..3 (byte i), z : of own entries 4..7
+//   w : column (two-source encoding) of the union entry this wave fetches for round r + TEAM2_D
+// Records are stored in blocks of 8 rounds x 8 waves (1 KiB, one LDS-DMA instruction); the columns
+// of the first TEAM2_D rounds come from tcol0.  A wave's values (8 per own entry, in the order it
+// meets its entries) are a contiguous stream starting at entry tvoff[8 g + w].
+constexpr int TEAM2_T = 8;
+constexpr int TEAM2_D = 3;
+struct Team2Host
+{
+    int nteam = 0;
+    bool lattice = false;
+    std::vector<int>       tpanel;   // 8 * nteam: panel of wave w, or -1
+    std::vector<int>       torder;   // processing order of the teams
+    std::vector<int>       tinfo;    // 4 * nteam: rounds, first record block, union entries, 0
+    std::vector<int>       tcol0;    // nteam * TEAM2_D * 8: columns fetched for rounds 0 .. TEAM2_D-1
+    std::vector<uint32_t>  trec;     // record blocks: 256 words each
+    std::vector<long long> tvoff;    // 8 * nteam + 1
+    std::vector<long long> tq;       // per panel-format entry: its entry index in the value streams, or -1
+    long long real_entries = 0;      // union entries before padding
+};
+void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *colidx, Team2Host *out);
+
 // Number of panel entries (before padding) a given R would need: cheap pass used
 // to pick R.  colidx may carry the two-source encoding.
 long long count_panel_entries(int nrow, const int *rowptr, const int *colidx, int R);

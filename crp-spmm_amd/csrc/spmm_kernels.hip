@@ -223,6 +223,16 @@ hipError_t spmm_rm_f64_rowgroup(const SpmmArgs &a, hipStream_t s)
 //                        (one s_mul per entry, no per-lane address arithmetic); ADDR64 falls
 //                        back to 64-bit global addresses when a B block exceeds 4 GiB.
 // ---------------------------------------------------------------------------
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (I < N)
+    {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
 constexpr int PANEL_RING  = 8;
 constexpr int PANEL_CHUNK = 32;
 
@@ -365,6 +375,53 @@ __device__ __forceinline__ void fmac_rows(double (&acc)[R][NV][VW], const double
     if constexpr (BIT + 1 < R) fmac_rows<R, NV, VW, BIT + 1>(acc, a, slot, mask);
 }
 
+// DPP delivery of the values: a VGPR pair `vv` holds 16 consecutive values of the panel's value
+// array (lane l has value l & 15: 16 / R entries), read with ONE ds_read_b64 per 16 values; the FMA takes
+// its scalar factor through DPP row_newbcast:LANE (every lane reads lane LANE of its own row of 16), the
+// only DPP control 64-bit operations have on gfx90a+.  This replaces R uniform-address LDS reads per
+// entry.  The DPP source was written by an LDS read (no VALU-write -> DPP-read hazard); s_bitcmp +
+// s_cbranch in front of the first FMA are two wait states in any case.
+template <int NV, int VW, int BIT, int LANE>
+__device__ __forceinline__ void fmac_row_masked_dpp(double (&acc)[NV][VW], const double vv,
+                                                    const typename SlotT<VW>::type (&slot)[NV], const uint32_t mask)
+{
+#define CRP_DPPF(A, B) "v_fmac_f64_dpp " A ", %[vv], " B " row_newbcast:%[ln] row_mask:0xf bank_mask:0xf\n\t"
+    if constexpr (NV == 2 && VW == 2)
+        asm volatile("s_bitcmp0_b32 %[m], %[bit]\n\ts_cbranch_scc1 1f\n\t"
+                     CRP_DPPF("%0", "%4") CRP_DPPF("%1", "%5") CRP_DPPF("%2", "%6") CRP_DPPF("%3", "%7") "1:"
+                     : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1])
+                     : "v"(slot[0].x), "v"(slot[0].y), "v"(slot[1].x), "v"(slot[1].y), [vv] "v"(vv), [m] "s"(mask),
+                       [bit] "n"(BIT), [ln] "n"(LANE)
+                     : "scc");
+    else if constexpr (NV == 1 && VW == 2)
+        asm volatile("s_bitcmp0_b32 %[m], %[bit]\n\ts_cbranch_scc1 1f\n\t" CRP_DPPF("%0", "%2") CRP_DPPF("%1", "%3") "1:"
+                     : "+v"(acc[0][0]), "+v"(acc[0][1])
+                     : "v"(slot[0].x), "v"(slot[0].y), [vv] "v"(vv), [m] "s"(mask), [bit] "n"(BIT), [ln] "n"(LANE)
+                     : "scc");
+    else if constexpr (NV == 2 && VW == 1)
+        asm volatile("s_bitcmp0_b32 %[m], %[bit]\n\ts_cbranch_scc1 1f\n\t" CRP_DPPF("%0", "%2") CRP_DPPF("%1", "%3") "1:"
+                     : "+v"(acc[0][0]), "+v"(acc[1][0])
+                     : "v"(slot[0]), "v"(slot[1]), [vv] "v"(vv), [m] "s"(mask), [bit] "n"(BIT), [ln] "n"(LANE)
+                     : "scc");
+    else
+    {
+        static_assert(NV == 1 && VW == 1, "unsupported tile shape");
+        asm volatile("s_bitcmp0_b32 %[m], %[bit]\n\ts_cbranch_scc1 1f\n\t" CRP_DPPF("%0", "%1") "1:"
+                     : "+v"(acc[0][0])
+                     : "v"(slot[0]), [vv] "v"(vv), [m] "s"(mask), [bit] "n"(BIT), [ln] "n"(LANE)
+                     : "scc");
+    }
+#undef CRP_DPPF
+}
+
+template <int R, int NV, int VW, int LANE0, int BIT = 0>
+__device__ __forceinline__ void fmac_rows_dpp(double (&acc)[R][NV][VW], const double vv,
+                                              const typename SlotT<VW>::type (&slot)[NV], const uint32_t mask)
+{
+    fmac_row_masked_dpp<NV, VW, BIT, LANE0 + BIT>(acc[BIT], vv, slot, mask);
+    if constexpr (BIT + 1 < R) fmac_rows_dpp<R, NV, VW, LANE0, BIT + 1>(acc, vv, slot, mask);
+}
+
 // Narrow tiles (one vector access per lane): the scalar unit, shared by the four SIMDs of a CU, is
 // what bounds them -- s_bitcmp + s_cbranch per row is 16 scalar instructions per entry against 8 FMAs.
 // Here the row mask goes into EXEC instead: one s_bfe_i64 per row writes all-ones or zero, the FMA
@@ -429,7 +486,7 @@ __device__ __forceinline__ void panel_consume1(const typename SlotT<VW>::type (&
 // DEPTH = number of 8-slot ring sets: round r lives in set r % DEPTH and is refilled, slot by
 // slot, with round r + DEPTH while it is consumed, so 8*DEPTH - 1 entries stay in flight.
 // WPW = waves per workgroup: 4, or 6 when the processing order was laid out for teams of six panels
-template <int R, int NV, int VW, int DEPTH, bool ADDR64, bool HAS_B1, int WPW>
+template <int R, int NV, int VW, int DEPTH, bool ADDR64, bool HAS_B1, int WPW, bool DPP>
 __global__ __launch_bounds__(64 * WPW) void spmm_panel_f64_kernel(
     const int norder, const int nrow, const int n, const int *__restrict__ porder,
     const int *__restrict__ pptr, const int *__restrict__ pcol, const uint32_t *__restrict__ pmask4,
@@ -539,6 +596,20 @@ __global__ __launch_bounds__(64 * WPW) void spmm_panel_f64_kernel(
 #pragma unroll
             for (int t = 0; t < NS; t++) *reinterpret_cast<d2 *>(dst + 2 * t) = stage[t];
         }
+        if constexpr (DPP)
+        {
+            // hipcc allocates the loop's ring registers apart from the prologue's in this body and moves
+            // them with v_mov before the loop: the moves must not read registers whose loads are still in
+            // flight, so the prologue's loads are drained here and the ring is pinned behind the wait
+            // (costs one exposed latency per panel; the loop itself never copies a ring register).
+            wait_vmcnt<0>();
+#pragma unroll
+            for (int d = 0; d < DEPTH; d++)
+#pragma unroll
+                for (int k = 0; k < RING; k++)
+#pragma unroll
+                    for (int v = 0; v < NV; v++) asm volatile("" : "+v"(ring[d][k][v]));
+        }
 #pragma unroll
         for (int k = 0; k < RING; k++) cA[k] = pcol[q0 + DEPTH * RING + k];     // (arrays are padded)
 #pragma unroll
@@ -565,16 +636,26 @@ __global__ __launch_bounds__(64 * WPW) void spmm_panel_f64_kernel(
                 for (int t = 0; t < NS; t++) glb_load_asm<2>(stage[t], src + 16 * t);
             }
             const double *lv = myvals + ((r / RPC) & 1) * (CHUNK * R) + (r % RPC) * (RING * R);
-#pragma unroll
-            for (int k = 0; k < RING; k++)
+            // DPP: the round's RING * R values in RING * R / 16 reads, lane l holding value l & 15 of its 16
+            constexpr int NVV = (RING * R) / 16;
+            double vv[NVV];
+            if constexpr (DPP)
             {
+#pragma unroll
+                for (int j = 0; j < NVV; j++) vv[j] = lv[j * 16 + (lane & 15)];
+            }
+            static_for<0, RING>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
                 double a_cur[R];
+                if constexpr (!DPP)
+                {
 #pragma unroll
 #ifdef CRP_ABL_NOVALS      // timing experiment: no LDS broadcast of the values
-                for (int rr = 0; rr < R; rr++) a_cur[rr] = 1.0 + rr;
+                    for (int rr = 0; rr < R; rr++) a_cur[rr] = 1.0 + rr;
 #else
-                for (int rr = 0; rr < R; rr++) a_cur[rr] = lv[k * R + rr];      // uniform-address LDS broadcast
+                    for (int rr = 0; rr < R; rr++) a_cur[rr] = lv[k * R + rr];      // uniform-address LDS broadcast
 #endif
+                }
                 const uint32_t mask = ((k < 4 ? m_lo : m_hi) >> (8 * (k & 3))) & 0xFFu;
                 // younger than slot k of this round: slots k+1..7 of the round, the DEPTH-1 rounds issued
                 // after it, and (refill) the k slots re-issued so far; the staging loads of a chunk's
@@ -595,9 +676,12 @@ __global__ __launch_bounds__(64 * WPW) void spmm_panel_f64_kernel(
                         default: wait_vmcnt<0>(); break;
                     }
                 }
-                panel_consume1<R, NV, VW>(ring[set][k], mask, a_cur, acc);
+                if constexpr (DPP)
+                    fmac_rows_dpp<R, NV, VW, ((k * R) % 16)>(acc, vv[(k * R) / 16], ring[set][k],
+                                                             (uint32_t) __builtin_amdgcn_readfirstlane((int) mask));
+                else panel_consume1<R, NV, VW>(ring[set][k], mask, a_cur, acc);
                 if constexpr (refill) panel_issue1<ADDR64, HAS_B1, NV, VW>(ring[set][k], cA[k], s0, s1, voff);
-            }
+            });
             if (last_of_chunk)
             {
                 // ... and parks it in the other LDS buffer once it has landed: younger than the last
@@ -679,7 +763,20 @@ static hipError_t launch_panel_w(const PanelArgs &p, const SpmmArgs &a, hipStrea
     constexpr int TW = 64 * VW * NV;
     const int nwg = (p.norder + WPW - 1) / WPW;
     dim3 grid((nwg + 7) / 8 * 8, (a.n + TW - 1) / TW);      // multiple of 8 for the XCD remap
-    hipLaunchKernelGGL((spmm_panel_f64_kernel<R, NV, VW, DEPTH, ADDR64, HAS_B1, WPW>), grid, dim3(64 * WPW), 0, s, p.norder, a.nrow,
+    // value delivery: uniform-address LDS broadcast (default) or DPP row_newbcast (CRPSPMM_PANEL_DPP=1: hipcc
+    // needs 216 VGPRs for that body against 160, so it stays an experiment)
+    static const bool dpp = getenv("CRPSPMM_PANEL_DPP") ? atoi(getenv("CRPSPMM_PANEL_DPP")) != 0 : false;
+    if constexpr (DEPTH == 1 && WPW == 4)
+    {
+        if (dpp)
+        {
+            hipLaunchKernelGGL((spmm_panel_f64_kernel<R, NV, VW, DEPTH, ADDR64, HAS_B1, WPW, true>), grid, dim3(64 * WPW), 0, s, p.norder,
+                               a.nrow, a.n, p.porder, p.pptr, p.pcol, p.pmask4, p.pval, a.B0, a.ldB0, a.B1, a.ldB1, a.C, a.ldC, a.rowmap,
+                               p.psync);
+            return hipGetLastError();
+        }
+    }
+    hipLaunchKernelGGL((spmm_panel_f64_kernel<R, NV, VW, DEPTH, ADDR64, HAS_B1, WPW, false>), grid, dim3(64 * WPW), 0, s, p.norder, a.nrow,
                        a.n, p.porder, p.pptr, p.pcol, p.pmask4, p.pval, a.B0, a.ldB0, a.B1, a.ldB1, a.C, a.ldC, a.rowmap, p.psync);
     return hipGetLastError();
 }

@@ -135,3 +135,34 @@ def team_format_host(rowptr, colidx, val):
     tot = int(tptr[-1]) if nt else 0
     return dict(nteam=nt, lattice=bool(lat.value), tpanel=take(tp, 4 * nt, np.int32).reshape(nt, 4), tptr=tptr,
                 tcol=take(tc, tot, np.int32), tmask=take(tm, tot, np.uint32), torder=take(to, nt, np.int32))
+
+
+def team2_format_host(rowptr, colidx, val):
+    """crp_team2_format_host -> dict(nteam, lattice, tpanel[nteam, 8], tinfo[nteam, 4], tcol0[nteam, 3, 8],
+    trec (uint32 words), tvoff, tval[nent, 8], torder)."""
+    lib = L.load()
+    rp = np.ascontiguousarray(rowptr, dtype=np.int32)
+    ci = np.ascontiguousarray(colidx, dtype=np.int32)
+    va = np.ascontiguousarray(val, dtype=np.float64)
+    if ci.size == 0:
+        ci, va = np.zeros(1, np.int32), np.zeros(1)
+    nteam, lat = C.c_int(), C.c_int()
+    tp, ti, tc0, to = L.c_int_p(), L.c_int_p(), L.c_int_p(), L.c_int_p()
+    tr = C.POINTER(C.c_uint)()
+    tv = C.POINTER(C.c_longlong)()
+    tval = L.c_dbl_p()
+    nrw, nve = C.c_longlong(), C.c_longlong()
+    L.check(lib.crp_team2_format_host(rp.size - 1, rp.ctypes.data_as(L.c_int_p), ci.ctypes.data_as(L.c_int_p),
+                                      va.ctypes.data_as(L.c_dbl_p), C.byref(nteam), C.byref(lat), C.byref(tp), C.byref(ti),
+                                      C.byref(tc0), C.byref(tr), C.byref(nrw), C.byref(tv), C.byref(tval), C.byref(nve),
+                                      C.byref(to)), "crp_team2_format_host")
+    nt = nteam.value
+
+    def take(ptr, cnt, dt):
+        out = np.ctypeslib.as_array(ptr, (max(cnt, 1),))[:cnt].astype(dt).copy()
+        L.c_free(C.cast(ptr, C.c_void_p))
+        return out
+    return dict(nteam=nt, lattice=bool(lat.value), tpanel=take(tp, 8 * nt, np.int32).reshape(nt, 8),
+                tinfo=take(ti, 4 * nt, np.int32).reshape(nt, 4), tcol0=take(tc0, 24 * nt, np.int32).reshape(nt, 3, 8),
+                trec=take(tr, nrw.value, np.uint32), tvoff=take(tv, 8 * nt + 1, np.int64),
+                tval=take(tval, 8 * nve.value, np.float64).reshape(-1, 8), torder=take(to, nt, np.int32))

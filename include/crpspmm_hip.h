@@ -131,6 +131,17 @@ int crp_panel_format_host(int nrow, const int *rowptr, const int *colidx, const 
 int crp_team_format_host(int nrow, const int *rowptr, const int *colidx, const double *val, int *nteam, int *lattice,
                          int **tpanel, int **tptr, int **tcol, unsigned **tmask, int **torder);
 
+/* Host-only: the streams variant 5 ("team2-R8", csrc/team2_kernel.hip) consumes: teams of 8 panels of 8 rows
+ * (one per wave of a 512-thread workgroup; tpanel, -1 = none), the union of whose columns is walked in rounds
+ * of 8 entries.  tinfo[4g] = rounds of team g, tinfo[4g+1] = its first record block; trec = record blocks of
+ * 8 rounds x 8 waves x 4 words {count | ring slots, masks of own entries 0-3, masks 4-7, column this wave
+ * fetches 3 rounds ahead}; tcol0[(3g + d) * 8 + w] = column wave w fetches for round d < 3; wave w's values
+ * (8 per own entry, in the order it meets them) start at tval[8 * tvoff[8g + w]].  *nvalent = entries in tval.
+ * malloc'd copies (caller frees).  Used by the CPU tests, which replay the streams in numpy. */
+int crp_team2_format_host(int nrow, const int *rowptr, const int *colidx, const double *val, int *nteam, int *lattice,
+                          int **tpanel, int **tinfo, int **tcol0, unsigned **trec, long long *nrecwords,
+                          long long **tvoff, double **tval, long long *nvalent, int **torder);
+
 /* ---- the hot kernel --------------------------------------------------------
  * C[nrow x n] := A * B (alpha = 1, beta = 0; C is overwritten, never read),
  * the arithmetic of mkl_sparse_d_mm as called at src/rowpara_spmm.c:403-406:

@@ -478,3 +478,74 @@ def test_full_size_properties_pwtk_standin(crp, orc, gpu):
     lin = 2 * CX - 3 * CY
     assert (torch.linalg.norm(CZ - lin) / torch.linalg.norm(lin)).item() <= 1e-12
     A.free()
+
+
+@pytest.mark.parametrize("n", [24, 64, 100, 128, 130, 200, 256, 300, 520])
+def test_team2_kernel_vs_oracle(crp, orc, gpu, n):
+    """Variant 5 (LDS-sharing team kernel, csrc/team2_kernel.hip): random matrix with empty rows (teams of 8
+    consecutive panels, ragged last team), padded leading dimensions, and a stride-lattice matrix (teams of
+    4 x 2 teeth); widths on both tile shapes (128 / 256 columns) and beyond one tile."""
+    from crp_spmm_amd import gen
+    m, k = 777, 1234
+    rp, ci, va = gen.random_csr(m, k, 70, seed=n, empty_every=13)
+    B = np.random.default_rng(n).uniform(-2, 2, size=(k, n))
+    ref = orc.spmm_csr(rp, ci, va, B)
+    for ldpad in (0, 2):
+        got = _spmm(crp, gpu, rp, ci, va, k, B, n, ldpad=ldpad, variant=5)
+        assert orc.rel_fro_err(ref, got) <= FP64_TOL, (n, ldpad)
+        assert not got[::13].any()
+    nx, ny, nz = 300, 6, 5
+    mm = nx * ny * nz
+    rp, ci, va = gen.banded_fem(mm, offsets=(1, 2, 3, 4, 5, nx, nx + 1, nx * ny, nx * ny + 1), seed=4)
+    B = np.random.default_rng(n + 1).uniform(-2, 2, size=(mm, n))
+    got = _spmm(crp, gpu, rp, ci, va, mm, B, n, variant=5)
+    assert orc.rel_fro_err(orc.spmm_csr(rp, ci, va, B), got) <= FP64_TOL, ("lattice", n)
+
+
+def test_team2_two_source_nonfinite_update_rowmap(crp, orc, gpu):
+    """Variant 5: two-source column index (B1 = receive buffer), absent pairs never multiplied (an Inf in a B
+    row that a panel-mate reads must not leak NaNs into rows that do not have that column), value updates,
+    row maps, bit-identical repeats."""
+    import torch
+    from crp_spmm_amd import gen, hip
+    lib = crp.load()
+    m, k = 500, 900
+    rp, ci, va = gen.random_csr(m, k, 30, seed=2)
+    lo, hi = 300, 650
+    remote_rows = np.concatenate([np.arange(0, lo), np.arange(hi, k)])
+    pos = np.full(k, -1)
+    pos[remote_rows] = np.arange(remote_rows.size)
+    c2 = np.where((ci >= lo) & (ci < hi), ci - lo, ~pos[ci]).astype(np.int32)
+    for n_ in (48, 200):
+        B = np.random.default_rng(n_).normal(size=(k, n_))
+        got = _spmm(crp, gpu, rp, c2, va, hi - lo, B[lo:hi], n_, B1=B[remote_rows], variant=5)
+        assert orc.rel_fro_err(orc.spmm_csr(rp, ci, va, B), got) <= FP64_TOL, n_
+    # non-finite B rows
+    n = 136
+    B = np.random.default_rng(5).normal(size=(k, n))
+    used = np.unique(ci)
+    B[used[::17]] = np.inf
+    B[used[5::29]] = np.nan
+    ref = orc.spmm_csr(rp, ci, va, B)
+    got = _spmm(crp, gpu, rp, ci, va, k, B, n, variant=5)
+    assert np.array_equal(np.isnan(ref), np.isnan(got)) and np.array_equal(np.isinf(ref), np.isinf(got))
+    fin = np.isfinite(ref)
+    assert np.abs(ref[fin] - got[fin]).max() <= 1e-12 * np.abs(ref[fin]).max()
+    # value update + repeats + row map
+    A = hip.CsrDev(m, k, rp, ci, va)
+    Bf = np.random.default_rng(6).normal(size=(k, n))
+    Bd = _t(Bf, gpu)
+    Cd = torch.empty((m, n), dtype=torch.float64, device=gpu)
+    hip.spmm_csr(A, Bd, Cd, n=n, variant=5)
+    torch.cuda.synchronize()
+    first = Cd.clone()
+    hip.spmm_csr(A, Bd, Cd, n=n, variant=5)
+    torch.cuda.synchronize()
+    assert torch.equal(first, Cd)
+    assert orc.rel_fro_err(orc.spmm_csr(rp, ci, va, Bf), Cd.cpu().numpy()) <= FP64_TOL
+    v2 = -2.5 * va
+    assert lib.crp_csr_dev_update_values(A.handle, v2.ctypes.data, None) == 0
+    hip.spmm_csr(A, Bd, Cd, n=n, variant=5)
+    torch.cuda.synchronize()
+    assert orc.rel_fro_err(orc.spmm_csr(rp, ci, v2, Bf), Cd.cpu().numpy()) <= FP64_TOL
+    A.free()

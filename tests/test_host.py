@@ -544,3 +544,78 @@ def test_parallel_ingest_and_cache(crp, orc, tmp_path):
     (tmp_path / "junk.crpcsr").write_bytes(b"not a cache file")
     assert mmio.csr_cache_read(tmp_path / "junk.crpcsr") is None
     print("parallel ingest of %d entries: %.3f s" % (r.size, t_par))
+
+
+def _replay_team2(t, m, B):
+    """Replays the team2 streams the way csrc/team2_kernel.hip walks them: per team and wave, round by round;
+    the column behind ring slot e of round r is what wave e fetched for that round (tcol0 for the first 3
+    rounds, the record of round r - 3 afterwards); a wave's k-th own entry takes values tval[tvoff + k]."""
+    C_out = np.zeros((m, B.shape[1]))
+    written = np.zeros(m, dtype=bool)
+    rec = t["trec"].reshape(-1, 8, 8, 4)          # [block][round in block][wave][word]
+    for g in range(t["nteam"]):
+        nr, blk0 = int(t["tinfo"][g, 0]), int(t["tinfo"][g, 1])
+        cols = np.zeros((nr, 8), dtype=np.int64)
+        for r in range(nr):
+            for w in range(8):
+                cols[r, w] = t["tcol0"][g, r, w] if r < 3 else np.int32(rec[blk0 + ((r - 3) >> 3), (r - 3) & 7, w, 3])
+        own_total = 0
+        for w in range(8):
+            panel = int(t["tpanel"][g, w])
+            k = int(t["tvoff"][8 * g + w])
+            acc = np.zeros((8, B.shape[1]))
+            for r in range(nr):
+                x, y, z, _ = (int(v) for v in rec[blk0 + (r >> 3), r & 7, w])
+                cnt = x & 15
+                assert cnt <= 8
+                if panel < 0:
+                    assert cnt == 0
+                for i in range(cnt):
+                    slot = (x >> (4 + 3 * i)) & 7
+                    mask = ((y if i < 4 else z) >> (8 * (i & 3))) & 0xFF
+                    assert mask != 0
+                    c = int(cols[r, slot])
+                    assert 0 <= c < B.shape[0]
+                    for rr in range(8):
+                        if (mask >> rr) & 1:
+                            acc[rr] += t["tval"][k, rr] * B[c]
+                    k += 1
+                own_total += cnt
+            if panel >= 0:
+                assert k == int(t["tvoff"][8 * g + w + 1])
+                lo, hi = panel * 8, min(m, panel * 8 + 8)
+                C_out[lo:hi] = acc[:hi - lo]
+                assert not written[lo:hi].any()
+                written[lo:hi] = True
+        assert own_total == int(t["tinfo"][g, 2])
+    assert written.all()
+    return C_out
+
+
+def test_team2_streams_replay(crp, orc):
+    """The streams of the LDS-sharing kernel (variant 5), replayed in numpy: every row is produced once and
+    equals the oracle's product -- for a stride-lattice matrix (teams of 4 x 2 teeth), a random matrix (8
+    consecutive panels per team; duplicates, empty rows), and sizes that leave ragged last panels / teams."""
+    from crp_spmm_amd import gen, hip
+    rng = np.random.default_rng(2)
+    cases = []
+    nx, ny, nz = 300, 5, 3
+    cases.append(("lattice",) + gen.banded_fem(nx * ny * nz, offsets=(1, 2, 3, nx, nx + 1, nx * ny, nx * ny + 1), seed=3))
+    cases.append(("random",) + gen.random_csr(611, 611, 14, seed=5, empty_every=9))
+    cases.append(("tiny",) + gen.random_csr(13, 40, 5, seed=1))
+    rp, ci, va = gen.random_csr(200, 64, 6, seed=8)
+    ci2 = ci.copy()
+    ci2[1::7] = ci2[0::7][:ci2[1::7].size]             # duplicate columns inside rows (kept, like the reference ingest)
+    cases.append(("dups", rp, ci2, va))
+    for name, rp, ci, va in cases:
+        m = len(rp) - 1
+        k = int(ci.max()) + 1 if ci.size else 1
+        t = hip.team2_format_host(rp, ci, va)
+        assert np.array_equal(np.sort(t["tpanel"][t["tpanel"] >= 0]), np.arange((m + 7) // 8)), name
+        assert np.array_equal(np.sort(t["torder"]), np.arange(t["nteam"])), name
+        if name == "lattice":
+            assert t["lattice"]
+        B = rng.uniform(-1, 1, size=(k, 3))
+        got = _replay_team2(t, m, B)
+        ref = orc.spmm_csr(rp, ci, va, B)
+        assert orc.rel_fro_err(ref, got) <= 1e-13, name

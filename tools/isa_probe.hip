@@ -1,0 +1,140 @@
+// ISA probe for gfx950 (diagnostic, not product): the three hardware behaviours the LDS-sharing SpMM kernel
+// (csrc/team2_kernel.hip) is built on.
+//   1. v_fmac_f64_dpp ... row_newbcast:N  -- every lane reads lane N of its own row of 16 as the scalar factor:
+//      semantics and issue rate against a plain v_fmac_f64;
+//   2. global_load_lds_dwordx4 under a partial EXEC mask (lanes 0..31): only the active lanes' 16-byte pieces
+//      are written, at M0 base + lane * 16;
+//   3. the values -> LDS -> ds_read_b64 (address (lane & 7) * 8) -> DPP chain.
+// build: hipcc --offload-arch=gfx950 -O3 -o tools/isa_probe tools/isa_probe.hip
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+
+#define GPTR(p) ((const __attribute__((address_space(1))) void *) (p))
+#define LPTR(p) ((__attribute__((address_space(3))) void *) (p))
+
+__global__ void dpp_sem(const double *vals, const double *b, double *out)
+{
+    const int lane = threadIdx.x;
+    double vv = vals[lane];                     // lane l holds vals[l]
+    double bb = b[lane];
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    asm volatile("s_nop 4\n\t"
+                 "v_fmac_f64_dpp %0, %4, %5 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %4, %5 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %2, %4, %5 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %3, %4, %5 row_newbcast:15 row_mask:0xf bank_mask:0xf"
+                 : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])
+                 : "v"(vv), "v"(bb));
+    for (int i = 0; i < 4; i++) out[i * 64 + lane] = acc[i];
+}
+
+template <bool DPP>
+__global__ void rate(double *out, int iters, double a, double b)
+{
+    double acc[16];
+    for (int i = 0; i < 16; i++) acc[i] = threadIdx.x * 1e-3 + i;
+    double va = a + (threadIdx.x & 15) * 1e-9, vb = b;
+    for (int it = 0; it < iters; it++)
+    {
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+        {
+            if constexpr (DPP)
+                asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:5 row_mask:0xf bank_mask:0xf" : "+v"(acc[i]) : "v"(va), "v"(vb));
+            else
+                asm volatile("v_fmac_f64 %0, %1, %2" : "+v"(acc[i]) : "v"(va), "v"(vb));
+        }
+    }
+    double s = 0;
+    for (int i = 0; i < 16; i++) s += acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+__global__ __launch_bounds__(64) void masked_dma(const double *src, double *out)
+{
+    __shared__ __attribute__((aligned(16))) double buf[256];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < 256; i += 64) buf[i] = -1.0;
+    __syncthreads();
+    if (lane < 32) __builtin_amdgcn_global_load_lds(GPTR(reinterpret_cast<const char *>(src) + lane * 16), LPTR(&buf[0]), 16, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int i = lane; i < 256; i += 64) out[i] = buf[i];
+    // values chain: entry e = 8 doubles at buf[8 e ..]; lane reads (lane & 7), DPP row r multiplies by value r
+    const double vv = buf[8 * 3 + (lane & 7)];           // entry 3
+    double acc = 0.0, one = 1.0 + lane;
+    asm volatile("s_nop 4\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:6 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(vv), "v"(one));
+    out[256 + lane] = acc;                              // expect buf[8*3+6] * (1 + lane)
+}
+
+int main()
+{
+    int rc = 0;
+    // ---- 1. semantics
+    {
+        std::vector<double> hv(64), hb(64), ho(256);
+        for (int i = 0; i < 64; i++) { hv[i] = 100.0 + i; hb[i] = 1.0 + 0.5 * i; }
+        double *dv, *db, *dout;
+        hipMalloc(&dv, 512); hipMalloc(&db, 512); hipMalloc(&dout, 2048);
+        hipMemcpy(dv, hv.data(), 512, hipMemcpyHostToDevice);
+        hipMemcpy(db, hb.data(), 512, hipMemcpyHostToDevice);
+        dpp_sem<<<1, 64>>>(dv, db, dout);
+        hipMemcpy(ho.data(), dout, 2048, hipMemcpyDeviceToHost);
+        const int sel[4] = {0, 3, 7, 15};
+        long bad = 0;
+        for (int i = 0; i < 4; i++)
+            for (int l = 0; l < 64; l++)
+            {
+                const double expect = hv[(l & ~15) + sel[i]] * hb[l];
+                if (ho[i * 64 + l] != expect) { if (bad < 4) printf("  dpp lane %d sel %d: got %g expect %g\n", l, sel[i], ho[i * 64 + l], expect); bad++; }
+            }
+        printf("dpp row_newbcast semantics: %ld mismatches of 256\n", bad);
+        if (bad) rc = 1;
+    }
+    // ---- 2. rate
+    {
+        double *d;
+        hipMalloc(&d, 8 * 2000000);
+        for (int dpp = 0; dpp < 2; dpp++)
+            for (int wps = 1; wps <= 4; wps *= 2)
+            {
+                const int threads = 256 * wps, blocks = 256, iters = 20000;
+                hipEvent_t e0, e1;
+                hipEventCreate(&e0); hipEventCreate(&e1);
+                for (int rep = 0; rep < 2; rep++)
+                {
+                    hipEventRecord(e0);
+                    if (dpp) rate<true><<<blocks, threads>>>(d, iters, 1.000001, 1e-9);
+                    else rate<false><<<blocks, threads>>>(d, iters, 1.000001, 1e-9);
+                    hipEventRecord(e1);
+                    hipEventSynchronize(e1);
+                }
+                float ms; hipEventElapsedTime(&ms, e0, e1);
+                printf("%s waves/SIMD %d: %.3f ms, %.2f ns per wave-FMA per SIMD, %.1f TFLOP/s\n", dpp ? "fmac_f64_dpp" : "fmac_f64    ", wps, ms,
+                       ms * 1e6 / ((double) iters * 16 * wps), 2.0 * 64 * iters * 16 * wps * 4 * 256 / (ms * 1e-3) / 1e12);
+            }
+    }
+    // ---- 3. masked LDS-DMA + value chain
+    {
+        std::vector<double> hs(256), ho(320);
+        for (int i = 0; i < 256; i++) hs[i] = 7.0 + i;
+        double *ds, *dout;
+        hipMalloc(&ds, 2048); hipMalloc(&dout, 320 * 8);
+        hipMemcpy(ds, hs.data(), 2048, hipMemcpyHostToDevice);
+        masked_dma<<<1, 64>>>(ds, dout);
+        hipMemcpy(ho.data(), dout, 320 * 8, hipMemcpyDeviceToHost);
+        long bad = 0;
+        for (int i = 0; i < 256; i++)
+        {
+            const double expect = i < 64 ? hs[i] : -1.0;       // 32 lanes x 16 B = 64 doubles
+            if (ho[i] != expect) { if (bad < 4) printf("  masked dma [%d]: got %g expect %g\n", i, ho[i], expect); bad++; }
+        }
+        for (int l = 0; l < 64; l++)
+            if (ho[256 + l] != hs[8 * 3 + 6] * (1.0 + l)) { if (bad < 8) printf("  value chain lane %d: got %g\n", l, ho[256 + l]); bad++; }
+        printf("masked LDS-DMA (32 lanes) + value chain: %ld mismatches\n", bad);
+        if (bad) rc = 1;
+    }
+    return rc;
+}
