@@ -37,6 +37,33 @@ def build_matrix(name):
     if name == "pwtk":
         rp, ci, va = gen.banded_fem(217918)
         return "pwtk-standin banded_fem(217918, seed 20261004)", 217918, 217918, rp, ci, va
+    if name == "pwtk_shell":
+        # irregular pwtk-class stand-in: jittered shell mesh, 6 unknowns per node, far seam band (gen.shell_fem)
+        rp, ci, va = gen.shell_fem()
+        return "pwtk-class shell_fem(160 x 227 nodes x 6 dof, jittered; seed 20261005)", 217918, 217918, rp, ci, va
+    if name == "pwtk_shell_rcm":
+        # diagnostic: the same matrix with its rows permuted on the host by reverse Cuthill-McKee on the graph of
+        # row groups with identical column sets (what the locality reordering at create does on the device side)
+        import scipy.sparse as sp
+        from scipy.sparse.csgraph import reverse_cuthill_mckee
+        rp, ci, va = gen.shell_fem()
+        m = len(rp) - 1
+        rows = np.repeat(np.arange(m), np.diff(rp))
+        h = np.zeros(m, dtype=np.uint64)
+        np.add.at(h, rows, ci.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15))
+        new = np.ones(m, dtype=bool)
+        new[1:] = (h[1:] != h[:-1]) | (np.diff(rp)[1:] != np.diff(rp)[:-1])
+        sn = np.cumsum(new) - 1
+        ns = int(sn[-1]) + 1
+        S = sp.csr_matrix((np.ones(m), (np.arange(m), sn)), shape=(m, ns))
+        A = sp.csr_matrix((np.ones(len(ci), dtype=np.int8), ci, rp), shape=(m, m))
+        Q = (S.T @ A @ S)
+        Q = ((Q + Q.T) != 0).astype(np.int8).tocsr()
+        perm = np.asarray(reverse_cuthill_mckee(Q, symmetric_mode=True))
+        order = np.argsort(np.argsort(perm)[sn], kind="stable")          # rows grouped by supernode in perm order
+        Ap = sp.csr_matrix((va, ci, rp), shape=(m, m))[order]
+        Ap.sort_indices()
+        return "pwtk-class shell_fem, rows RCM-ordered on the host (diagnostic)", m, m, Ap.indptr.astype(np.int32), Ap.indices.astype(np.int32), Ap.data
     if name == "pwtk_l2":
         # diagnostic only: same row structure, every column folded into the first 1024 rows of B
         # (2 MiB at n = 256) so that B is always L2-resident

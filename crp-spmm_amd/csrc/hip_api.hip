@@ -10,6 +10,7 @@
 #include "crpspmm_hip.h"
 #include "kernels.h"
 #include "panel_format.h"
+#include "locality.h"
 
 // device copy of one row-panel format (panel_format.h)
 struct PanelDev
@@ -68,8 +69,28 @@ struct crp_csr_dev
     int      auto_variant = 1; // what variant 0 resolves to (1 rowgroup, 2 panel R4, 3 panel R8)
     long long b0_rows = 0, b1_rows = 0;   // 1 + largest local / receive-buffer row a column index addresses
     int      *rowmap = nullptr;           // row-subset matrices: C row of every row (device), else nullptr
+    // locality order (locality.h): the derived formats (panels, teams) are built on the rows in processing order
+    // perm[i] = original row at position i; f_* = that CSR, f_nz[p'] = original position of its nonzero p';
+    // rowmap_fmt = C row of every position (the caller's row map composed with perm).  Empty perm = natural order.
+    std::vector<int>      perm, f_rowptr, f_colidx;
+    std::vector<double>   f_val;
+    std::vector<uint32_t> f_nz;
+    std::vector<int>      h_rowmap;       // host copy of the caller's row map (empty: none)
+    int      *rowmap_fmt = nullptr;
     int       c_nrow = 0;                 // rows of C the product writes into (nrow without a rowmap)
 };
+
+static const int *fmt_rowptr(const crp_csr_dev *A) { return A->perm.empty() ? A->h_rowptr.data() : A->f_rowptr.data(); }
+static const int *fmt_colidx(const crp_csr_dev *A) { return A->perm.empty() ? A->h_colidx.data() : A->f_colidx.data(); }
+static const double *fmt_val(const crp_csr_dev *A) { return A->perm.empty() ? A->h_val.data() : A->f_val.data(); }
+// slot map of a derived format, built on the processing order, re-indexed by the caller's nonzero positions
+static void fmt_slotmap_to_caller(const crp_csr_dev *A, std::vector<uint32_t> *pmap)
+{
+    if (A->perm.empty()) return;
+    std::vector<uint32_t> out(pmap->size());
+    for (size_t pz = 0; pz < pmap->size(); pz++) out[(size_t) A->f_nz[pz]] = (*pmap)[pz];
+    pmap->swap(out);
+}
 
 #define CRP_TRY(expr)                                 \
     do                                                \
@@ -84,7 +105,8 @@ static int ensure_panel(crp_csr_dev *A, int idx)
     PanelDev &d = A->pan[idx];
     if (d.built) return 0;
     crp::PanelHost h;
-    crp::build_panels(A->nrow, A->h_rowptr.data(), A->h_colidx.data(), A->h_val.data(), idx == 0 ? 4 : 8, &h);
+    crp::build_panels(A->nrow, fmt_rowptr(A), fmt_colidx(A), fmt_val(A), idx == 0 ? 4 : 8, &h);
+    fmt_slotmap_to_caller(A, &h.pmap);
     d.R = h.R;
     d.npanel = h.npanel;
     d.norder = (int) h.porder.size();
@@ -148,9 +170,10 @@ static int ensure_team(crp_csr_dev *A)
     const int rc = ensure_panel(A, 1);
     if (rc != 0) return rc;
     crp::PanelHost h;
-    crp::build_panels(A->nrow, A->h_rowptr.data(), A->h_colidx.data(), A->h_val.data(), 8, &h, false);
+    crp::build_panels(A->nrow, fmt_rowptr(A), fmt_colidx(A), fmt_val(A), 8, &h, false);
+    fmt_slotmap_to_caller(A, &h.pmap);
     crp::TeamHost th;
-    crp::build_teams(h, A->nrow, A->h_rowptr.data(), A->h_colidx.data(), &th);
+    crp::build_teams(h, A->nrow, fmt_rowptr(A), fmt_colidx(A), &th);
     t.nteam = th.nteam;
     t.entries = (long long) th.tcol.size();
     t.lattice = th.lattice;
@@ -186,9 +209,10 @@ static int ensure_team2(crp_csr_dev *A)
     Team2Dev &t = A->team2;
     if (t.built) return 0;
     crp::PanelHost h;
-    crp::build_panels(A->nrow, A->h_rowptr.data(), A->h_colidx.data(), A->h_val.data(), 8, &h, false);
+    crp::build_panels(A->nrow, fmt_rowptr(A), fmt_colidx(A), fmt_val(A), 8, &h, false);
+    fmt_slotmap_to_caller(A, &h.pmap);
     crp::Team2Host th;
-    crp::build_team2(h, A->nrow, A->h_rowptr.data(), A->h_colidx.data(), &th);
+    crp::build_team2(h, A->nrow, fmt_rowptr(A), fmt_colidx(A), &th);
     t.nteam = th.nteam;
     t.entries = th.real_entries;
     t.lattice = th.lattice;
@@ -417,14 +441,62 @@ int crp_csr_dev_create(int nrow, int ncol, const int *rowptr, const int *colidx,
         A->h_colidx.assign(colidx, colidx + nnz);
         A->h_val.assign(val, val + nnz);
     }
+    // Locality order of the rows (locality.h) for the derived formats: taken when it lets rows of a panel share
+    // more columns than the caller's order does (fewer R = 8 panel entries).  A mesh numbered along its own lines
+    // (the stride-lattice matrices) keeps the caller's order -- consecutive rows there are neighbours already and
+    // the lattice schedules build on that.  CRPSPMM_REORDER=0 never, =1 whenever the matrix qualifies.
+    if (nnz > 0 && nrow >= 2048 && nrow == ncol && A->b1_rows == 0)
+    {
+        const char *er = getenv("CRPSPMM_REORDER");
+        const int mode = er ? atoi(er) : -1;
+        std::vector<int> perm;
+        if (mode != 0 && crp::locality_reorder(nrow, ncol, rowptr, colidx, 8, &perm))
+        {
+            A->f_rowptr.assign((size_t) nrow + 1, 0);
+            for (int i = 0; i < nrow; i++) A->f_rowptr[(size_t) i + 1] = A->f_rowptr[(size_t) i] + (rowptr[perm[(size_t) i] + 1] - rowptr[perm[(size_t) i]]);
+            A->f_colidx.resize((size_t) nnz);
+            A->f_nz.resize((size_t) nnz);
+            for (int i = 0; i < nrow; i++)
+            {
+                const int r = perm[(size_t) i];
+                int q = A->f_rowptr[(size_t) i];
+                for (int pz = rowptr[r]; pz < rowptr[r + 1]; pz++, q++)
+                {
+                    A->f_colidx[(size_t) q] = colidx[pz];
+                    A->f_nz[(size_t) q] = (uint32_t) pz;
+                }
+            }
+            const long long e_nat = crp::count_panel_entries(nrow, rowptr, colidx, 8);
+            const long long e_loc = crp::count_panel_entries(nrow, A->f_rowptr.data(), A->f_colidx.data(), 8);
+            if (mode == 1 || (double) e_loc < 0.9 * (double) e_nat)
+            {
+                A->perm.swap(perm);
+                A->f_val.resize((size_t) nnz);
+                for (long long q = 0; q < nnz; q++) A->f_val[(size_t) q] = val[A->f_nz[(size_t) q]];
+                hipError_t e2 = hipMalloc((void **) &A->rowmap_fmt, sizeof(int) * (size_t) nrow);
+                if (e2 == hipSuccess) e2 = hipMemcpy(A->rowmap_fmt, A->perm.data(), sizeof(int) * (size_t) nrow, hipMemcpyHostToDevice);
+                if (e2 != hipSuccess)
+                {
+                    crp_csr_dev_p tmp = A;
+                    crp_csr_dev_destroy(&tmp);
+                    return (int) e2;
+                }
+            }
+            else
+            {
+                A->f_rowptr.clear(); A->f_colidx.clear(); A->f_nz.clear();
+                A->f_rowptr.shrink_to_fit(); A->f_colidx.shrink_to_fit(); A->f_nz.shrink_to_fit();
+            }
+        }
+    }
     // Pick the kernel family variant 0 resolves to.  The panel kernels pay off when rows of a
     // panel share columns (banded / FEM / block structure); with no sharing (fill -> 1/R) the
     // plain CSR kernel moves fewer bytes.  CRPSPMM_SPMM_VARIANT overrides (1, 2 or 3).
     A->auto_variant = 1;
     if (nnz > 0 && nrow >= 8)
     {
-        const long long e4 = crp::count_panel_entries(nrow, rowptr, colidx, 4);
-        const long long e8 = crp::count_panel_entries(nrow, rowptr, colidx, 8);
+        const long long e4 = crp::count_panel_entries(nrow, fmt_rowptr(A), fmt_colidx(A), 4);
+        const long long e8 = crp::count_panel_entries(nrow, fmt_rowptr(A), fmt_colidx(A), 8);
         const double fill4 = (double) nnz / (4.0 * (double) e4);
         if (fill4 >= 0.45) A->auto_variant = ((double) e8 <= 0.72 * (double) e4) ? 3 : 2;
     }
@@ -478,6 +550,7 @@ int crp_csr_dev_destroy(crp_csr_dev_p *A_)
     if (A->colidx) (void) hipFree(A->colidx);
     if (A->val) (void) hipFree(A->val);
     if (A->rowmap) (void) hipFree(A->rowmap);
+    if (A->rowmap_fmt) (void) hipFree(A->rowmap_fmt);
     delete A;
     *A_ = NULL;
     return 0;
@@ -496,7 +569,11 @@ int crp_csr_dev_update_values(crp_csr_dev_p A, const double *val, void *stream)
     crp_dev_ptr_is_device(val, &is_dev);
     CRP_TRY(hipMemcpyAsync(A->val, val, sizeof(double) * (size_t) A->nnz, is_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
                            (hipStream_t) stream));
-    if (!is_dev) memcpy(A->h_val.data(), val, sizeof(double) * (size_t) A->nnz);   // formats built later see the new values
+    if (!is_dev)
+    {
+        memcpy(A->h_val.data(), val, sizeof(double) * (size_t) A->nnz);   // formats built later see the new values
+        for (size_t q = 0; q < A->f_val.size(); q++) A->f_val[q] = val[A->f_nz[q]];
+    }
     for (int i = 0; i < 2; i++)
         if (A->pan[i].built)
             CRP_TRY(crp::scatter_vals_f64(A->nnz, A->pan[i].pmap, A->val, A->pan[i].pval, (hipStream_t) stream));
@@ -510,11 +587,25 @@ int crp_csr_dev_set_rowmap(crp_csr_dev_p A, const int *rowmap, int c_nrow)
     if (A == NULL || (rowmap != NULL && c_nrow < 0)) return -1;
     if (A->rowmap) { CRP_TRY(hipFree(A->rowmap)); A->rowmap = nullptr; }
     A->c_nrow = A->nrow;
+    A->h_rowmap.clear();
+    if (!A->perm.empty())        // formats in processing order: C row of position i = map[perm[i]]
+    {
+        std::vector<int> comp(A->perm);
+        if (rowmap != NULL)
+            for (int i = 0; i < A->nrow; i++)
+            {
+                const int r = rowmap[A->perm[(size_t) i]];
+                if (r < 0 || r >= c_nrow) return -2;
+                comp[(size_t) i] = r;
+            }
+        CRP_TRY(hipMemcpy(A->rowmap_fmt, comp.data(), sizeof(int) * (size_t) A->nrow, hipMemcpyHostToDevice));
+    }
     if (rowmap == NULL || A->nrow == 0) return 0;
     for (int i = 0; i < A->nrow; i++)
         if (rowmap[i] < 0 || rowmap[i] >= c_nrow) return -2;
     CRP_TRY(hipMalloc((void **) &A->rowmap, sizeof(int) * (size_t) A->nrow));
     CRP_TRY(hipMemcpy(A->rowmap, rowmap, sizeof(int) * (size_t) A->nrow, hipMemcpyHostToDevice));
+    A->h_rowmap.assign(rowmap, rowmap + A->nrow);
     A->c_nrow = c_nrow;
     return 0;
 }
@@ -550,6 +641,7 @@ int crp_spmm_csr_f64(crp_csr_dev_p A, int layout, int n, const double *B0, long 
     if (layout == CRP_LAYOUT_COL_MAJOR) return (int) crp::spmm_cm_f64(a, (hipStream_t) stream);
     int v = (variant == 0) ? A->auto_variant : variant;
     if (v == 5 && (!crp::spmm_team2_applicable(a) || A->nnz == 0 || A->nrow < 8)) v = 3;
+    if (v >= 2 && A->rowmap_fmt != nullptr) a.rowmap = A->rowmap_fmt;      // derived formats hold the rows in processing order
     if (v == 5)
     {
         const int rc = ensure_team2(A);
@@ -586,6 +678,7 @@ int crp_spmm_csr_f64(crp_csr_dev_p A, int layout, int n, const double *B0, long 
 }
 
 int crp_csr_dev_auto_variant(crp_csr_dev_p A) { return A ? A->auto_variant : -1; }
+int crp_csr_dev_reordered(crp_csr_dev_p A) { return A ? (A->perm.empty() ? 0 : 1) : -1; }
 
 int crp_panel_format_host(int nrow, const int *rowptr, const int *colidx, const double *val, int R, int *npanel,
                           int **pptr, int **pcol, unsigned **pmask4, double **pval, long long *real_entries,
@@ -669,6 +762,22 @@ int crp_team2_format_host(int nrow, const int *rowptr, const int *colidx, const 
     *tval = (double *) calloc((size_t) nent * 8 + 1, sizeof(double));
     for (size_t q = 0; q < th.tq.size(); q++)
         if (th.tq[q] >= 0) memcpy(*tval + (size_t) th.tq[q] * 8, &h.pval[q * 8], sizeof(double) * 8);
+    return 0;
+}
+
+int crp_locality_order_host(int nrow, int ncol, const int *rowptr, const int *colidx, int nparts, int *perm, double *info)
+{
+    if (nrow < 0 || rowptr == NULL || perm == NULL || nparts < 1) return -1;
+    std::vector<int> pv;
+    crp::LocalityInfo li;
+    const bool ok = crp::locality_reorder(nrow, ncol, rowptr, colidx, nparts, &pv, &li);
+    if (!ok)
+    {
+        for (int i = 0; i < nrow; i++) perm[i] = i;
+        return 1;
+    }
+    memcpy(perm, pv.data(), sizeof(int) * (size_t) nrow);
+    if (info) { info[0] = li.groups; info[1] = li.parts; info[2] = li.mean_dist_before; info[3] = li.mean_dist_after; }
     return 0;
 }
 

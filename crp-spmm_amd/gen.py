@@ -132,3 +132,69 @@ def random_csr(m, k, max_deg, seed=7, empty_every=0):
 def alg_bytes(m, k, n, nnz, vb=8):
     """compulsory HBM bytes of one SpMM: A once, B once, C written once."""
     return (vb + 4) * nnz + 4 * (m + 1) + vb * k * n + vb * m * n
+
+
+def shell_fem(nc=160, nl=227, dof=6, m=217918, seed=20261005, jitter=64, p_drop=0.12, p_extra=0.05, seam=3, seam_to=197):
+    """Irregular pwtk-class stand-in (the real pwtk, /root/reference/README.md:62-63, is a shell-element model of a
+    pressurised wind tunnel: 217,918 rows, ~53 nnz/row, bandwidth 189,331): a closed tube surface of nc x nl
+    quadrilateral shell elements' nodes, `dof` unknowns per node, every node coupled to its (up to) 8 surface
+    neighbours through dense dof x dof blocks.  Nothing is Toeplitz: node numbers are shuffled inside windows of
+    `jitter` nodes of the ring-by-ring order, a fraction p_drop of the diagonal couplings is missing (triangulated
+    patches), a fraction p_extra of the nodes has a stiffener coupling two nodes along the ring, and the first
+    `seam` rings are tied to rings seam_to.. (the far band that gives pwtk its bandwidth: 197 rings = 189,1xx rows).  Rows beyond m are cut (the
+    last node keeps fewer unknowns).  Symmetric pattern and values, diagonal blocks boosted; columns ascending.
+    -> (rowptr int32, colidx int32, val float64)"""
+    import scipy.sparse as sp
+    nn = nc * nl
+    node = np.arange(nn, dtype=np.int64)
+    c, l = node % nc, node // nc
+    # window-local shuffle of the numbering (deterministic: sort by hash inside each window)
+    win = node // jitter
+    key = win.astype(np.float64) + 0.999 * _u01(node + np.int64(7919), seed)
+    perm = np.empty(nn, dtype=np.int64)
+    perm[np.argsort(key, kind="stable")] = node          # perm[old] = new number
+    edges_a, edges_b = [], []
+
+    def add(a, b, keep):
+        edges_a.append(a[keep])
+        edges_b.append(b[keep])
+    for dc, dl in ((1, 0), (0, 1), (1, 1), (-1, 1)):
+        ok = (l + dl < nl)
+        nb = ((c + dc) % nc) + (l + dl) * nc
+        if dc != 0 and dl != 0:
+            ok = ok & (_u01(node * np.int64(4) + np.int64(dc + 2), seed + 1) >= p_drop)
+        add(node, np.where(ok, nb, 0), ok)
+    ex = _u01(node + np.int64(1 << 30), seed + 2) < p_extra
+    add(node, ((c + 2) % nc) + l * nc, ex)
+    if seam > 0:
+        s = l < seam
+        add(node, c + (np.minimum(seam_to + l, nl - 1)) * nc, s & (nl > 2 * seam))
+    a = np.concatenate(edges_a)
+    b = np.concatenate(edges_b)
+    a, b = perm[a], perm[b]
+    lo, hi = np.minimum(a, b), np.maximum(a, b)
+    und = np.unique(lo * np.int64(nn) + hi)
+    lo, hi = und // nn, und % nn
+    nr = np.concatenate([lo, hi, np.arange(nn, dtype=np.int64)])       # node-level pattern, both triangles + diagonal
+    ncol = np.concatenate([hi, lo, np.arange(nn, dtype=np.int64)])
+    P = sp.csr_matrix((np.ones(nr.size, dtype=np.int8), (nr, ncol)), shape=(nn, nn))
+    P.sort_indices()
+    # expand every node entry to a dof x dof block
+    deg = np.diff(P.indptr).astype(np.int64)
+    row_node = np.repeat(np.arange(nn, dtype=np.int64), deg)
+    nnz_n = P.indices.size
+    rows = (row_node[:, None, None] * dof + np.arange(dof)[None, :, None]) + np.zeros((1, 1, dof), dtype=np.int64)
+    cols = (P.indices.astype(np.int64)[:, None, None] * dof + np.arange(dof)[None, None, :]) + np.zeros((1, dof, 1), dtype=np.int64)
+    rows, cols = rows.reshape(-1), cols.reshape(-1)
+    keep = (rows < m) & (cols < m)
+    rows, cols = rows[keep], cols[keep]
+    order = np.lexsort((cols, rows))
+    rows, cols = rows[order], cols[order]
+    rowptr = np.zeros(m + 1, dtype=np.int64)
+    np.add.at(rowptr, rows + 1, 1)
+    rowptr = np.cumsum(rowptr)
+    lo, hi = np.minimum(rows, cols), np.maximum(rows, cols)
+    u = _u01(lo * np.int64(1 << 20) + (hi - lo) + (hi % 97) * np.int64(1 << 40), seed + 3)
+    vals = np.where(rows == cols, 40.0 + u, 2.0 * u - 1.0)
+    del nnz_n
+    return rowptr.astype(np.int32), cols.astype(np.int32), vals

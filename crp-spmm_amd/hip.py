@@ -166,3 +166,22 @@ def team2_format_host(rowptr, colidx, val):
                 tinfo=take(ti, 4 * nt, np.int32).reshape(nt, 4), tcol0=take(tc0, 24 * nt, np.int32).reshape(nt, 3, 8),
                 trec=take(tr, nrw.value, np.uint32), tvoff=take(tv, 8 * nt + 1, np.int64),
                 tval=take(tval, 8 * nve.value, np.float64).reshape(-1, 8), torder=take(to, nt, np.int32))
+
+
+def locality_order_host(rowptr, colidx, ncol=None, nparts=8):
+    """crp_locality_order_host -> (perm, info dict or None when the matrix does not qualify)."""
+    lib = L.load()
+    rp = np.ascontiguousarray(rowptr, dtype=np.int32)
+    ci = np.ascontiguousarray(colidx, dtype=np.int32)
+    if ci.size == 0:
+        ci = np.zeros(1, np.int32)
+    m = rp.size - 1
+    perm = np.zeros(max(m, 1), dtype=np.int32)
+    info = np.zeros(4)
+    rc = lib.crp_locality_order_host(m, m if ncol is None else int(ncol), rp.ctypes.data_as(L.c_int_p), ci.ctypes.data_as(L.c_int_p),
+                                     int(nparts), perm.ctypes.data_as(L.c_int_p), info.ctypes.data_as(L.c_dbl_p))
+    if rc < 0:
+        raise RuntimeError("crp_locality_order_host failed: %d" % rc)
+    if rc == 1:
+        return perm[:m], None
+    return perm[:m], dict(groups=int(info[0]), parts=int(info[1]), mean_dist_before=info[2], mean_dist_after=info[3])

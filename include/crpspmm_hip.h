@@ -100,6 +100,11 @@ long long crp_csr_dev_bytes(crp_csr_dev_p A);
  * (chosen at create time from how many columns the rows of a panel share;
  * CRPSPMM_SPMM_VARIANT=1|2|3 overrides). */
 int crp_csr_dev_auto_variant(crp_csr_dev_p A);
+/* 1 when the derived formats (row panels, teams) hold the rows in the locality order of csrc/locality.cpp
+ * instead of the caller's order (taken at create time when it lets the rows of a panel share more columns;
+ * CRPSPMM_REORDER=0|1 overrides).  Results do not depend on it: C rows are written through a row map and
+ * every row's products are still summed in the kernel variant's own order. */
+int crp_csr_dev_reordered(crp_csr_dev_p A);
 /* Host-only: build the row-panel format the rowpanel kernels consume (R = 4 or 8)
  * and return malloc'd copies (caller frees).  Panel p owns entries pptr[p] .. pptr[p+1]
  * (padded to multiples of 8 with mask-0 entries); entry q has column pcol[q] (two-source
@@ -141,6 +146,13 @@ int crp_team_format_host(int nrow, const int *rowptr, const int *colidx, const d
 int crp_team2_format_host(int nrow, const int *rowptr, const int *colidx, const double *val, int *nteam, int *lattice,
                           int **tpanel, int **tinfo, int **tcol0, unsigned **trec, long long *nrecwords,
                           long long **tvoff, double **tval, long long *nvalent, int **torder);
+
+/* Host-only: the processing order of the rows of a square A that crp_csr_dev_create() applies for B-row
+ * locality (csrc/locality.cpp: row groups with identical column lists, `nparts` slabs by breadth-first
+ * bisection, reverse Cuthill-McKee inside every slab).  perm[i] = row processed at position i (caller provides
+ * nrow ints).  Returns 0, or 1 when the matrix does not qualify (not square, two-source indices, too small):
+ * perm is then the identity.  info (4 doubles, may be NULL): row groups, parts, mean |pos(col) - pos(row)| before, after. */
+int crp_locality_order_host(int nrow, int ncol, const int *rowptr, const int *colidx, int nparts, int *perm, double *info);
 
 /* ---- the hot kernel --------------------------------------------------------
  * C[nrow x n] := A * B (alpha = 1, beta = 0; C is overwritten, never read),

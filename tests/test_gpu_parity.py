@@ -549,3 +549,52 @@ def test_team2_two_source_nonfinite_update_rowmap(crp, orc, gpu):
     torch.cuda.synchronize()
     assert orc.rel_fro_err(orc.spmm_csr(rp, ci, v2, Bf), Cd.cpu().numpy()) <= FP64_TOL
     A.free()
+
+
+def test_locality_order_all_variants(crp, orc, gpu, monkeypatch):
+    """Formats built on the locality order of the rows (csrc/locality.cpp; forced with CRPSPMM_REORDER=1): every
+    panel / team variant still writes every C row where the caller expects it, with and without a caller row map,
+    and value updates reach the re-ordered slots."""
+    import ctypes as C
+    import torch
+    from crp_spmm_amd import gen, hip
+    lib = crp.load()
+    _IP = C.POINTER(C.c_int)
+    rp, ci, va = gen.shell_fem(nc=24, nl=40, m=24 * 40 * 6 - 3, seam_to=30)
+    m = len(rp) - 1
+    n = 136
+    B = np.random.default_rng(9).normal(size=(m, n))
+    ref = orc.spmm_csr(rp, ci, va, B)
+    monkeypatch.setenv("CRPSPMM_REORDER", "1")
+    A = hip.CsrDev(m, m, rp, ci, va)
+    assert lib.crp_csr_dev_reordered(A.handle) == 1
+    Bd = _t(B, gpu)
+    for variant in (0, 1, 2, 3, 4, 5):
+        Cd = torch.full((m, n), float("nan"), dtype=torch.float64, device=gpu)
+        hip.spmm_csr(A, Bd, Cd, n=n, variant=variant)
+        torch.cuda.synchronize()
+        assert orc.rel_fro_err(ref, Cd.cpu().numpy()) <= FP64_TOL, variant
+    # caller row map on top (rows scattered into a taller C), then new values
+    rowmap = (np.arange(m, dtype=np.int32) * 2 + 1)
+    assert lib.crp_csr_dev_set_rowmap(A.handle, rowmap.ctypes.data_as(_IP), 2 * m + 1) == 0
+    v2 = 0.5 * va + 1.0
+    assert lib.crp_csr_dev_update_values(A.handle, v2.ctypes.data, None) == 0
+    ref2 = orc.spmm_csr(rp, ci, v2, B)
+    for variant in (1, 3, 5):
+        Cd = torch.full((2 * m + 1, n), 7.0, dtype=torch.float64, device=gpu)
+        hip.spmm_csr(A, Bd, Cd, n=n, variant=variant)
+        torch.cuda.synchronize()
+        out = Cd.cpu().numpy()
+        assert orc.rel_fro_err(ref2, out[1::2]) <= FP64_TOL, variant
+        assert (out[0::2] == 7.0).all()
+    A.free()
+    # auto: a jittered shell mesh of 100 rings takes the locality order, the stride-lattice matrix keeps the caller's
+    monkeypatch.delenv("CRPSPMM_REORDER")
+    rp2, ci2, va2 = gen.shell_fem(nc=100, nl=100, m=60000, seam_to=80)
+    A = hip.CsrDev(60000, 60000, rp2, ci2, va2)
+    assert lib.crp_csr_dev_reordered(A.handle) == 1
+    A.free()
+    rp3, ci3, va3 = gen.banded_fem(6000, offsets=(1, 2, 3, 300, 301, 1800, 1801), seed=2)
+    A = hip.CsrDev(6000, 6000, rp3, ci3, va3)
+    assert lib.crp_csr_dev_reordered(A.handle) == 0
+    A.free()
