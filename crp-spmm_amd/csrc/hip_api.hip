@@ -43,7 +43,7 @@ struct Team2Dev
 {
     bool built = false;
     int  nteam = 0;
-    int *torder = nullptr, *tpanel = nullptr, *tinfo = nullptr, *tcol0 = nullptr;
+    int *torder = nullptr, *tpanel = nullptr, *tinfo = nullptr, *tpro = nullptr;
     uint32_t *trec = nullptr;
     long long *tvoff = nullptr;
     double   *tval = nullptr;
@@ -225,19 +225,13 @@ static int ensure_team2(crp_csr_dev *A)
     hipError_t e = up((void **) &t.torder, th.torder.data(), sizeof(int) * th.torder.size(), 4);
     if (e == hipSuccess) e = up((void **) &t.tpanel, th.tpanel.data(), sizeof(int) * th.tpanel.size(), 4);
     if (e == hipSuccess) e = up((void **) &t.tinfo, th.tinfo.data(), sizeof(int) * th.tinfo.size(), 16);
-    if (e == hipSuccess) e = up((void **) &t.tcol0, th.tcol0.data(), sizeof(int) * th.tcol0.size(), 4);
+    if (e == hipSuccess) e = up((void **) &t.tpro, th.tpro.data(), sizeof(int) * th.tpro.size(), 8);
     if (e == hipSuccess) e = up((void **) &t.trec, th.trec.data(), sizeof(uint32_t) * th.trec.size(), 1024);
-    const long long nent = th.tvoff.back();
-    t.value_entries = nent;
-    std::vector<double> tval((size_t) nent * 8, 0.0);
-    for (size_t q = 0; q < th.tq.size(); q++)
-        if (th.tq[q] >= 0) memcpy(&tval[(size_t) th.tq[q] * 8], &h.pval[q * 8], sizeof(double) * 8);
-    std::vector<uint32_t> tmap(h.pmap.size());
-    for (size_t pz = 0; pz < h.pmap.size(); pz++) tmap[pz] = (uint32_t) (th.tq[h.pmap[pz] >> 3] * 8 + (h.pmap[pz] & 7));
+    t.value_entries = th.tvoff.back();
     if (e == hipSuccess) e = up((void **) &t.tvoff, th.tvoff.data(), sizeof(long long) * th.tvoff.size(), 8);
-    // the kernel requests whole 512-byte chunks up to two chunks past a wave's last entry
-    if (e == hipSuccess) e = up((void **) &t.tval, tval.data(), sizeof(double) * tval.size(), 4096);
-    if (e == hipSuccess) e = up((void **) &t.tmap, tmap.data(), sizeof(uint32_t) * tmap.size(), 4);
+    // the kernel requests 256 bytes per wave and round: up to four groups past a wave's last part
+    if (e == hipSuccess) e = up((void **) &t.tval, th.tval.data(), sizeof(double) * th.tval.size(), 4096);
+    if (e == hipSuccess) e = up((void **) &t.tmap, th.vmap.data(), sizeof(uint32_t) * th.vmap.size(), 4);
     if (e != hipSuccess) return (int) e;
     t.built = true;
     return 0;
@@ -541,7 +535,7 @@ int crp_csr_dev_destroy(crp_csr_dev_p *A_)
     if (A->team2.torder) (void) hipFree(A->team2.torder);
     if (A->team2.tpanel) (void) hipFree(A->team2.tpanel);
     if (A->team2.tinfo) (void) hipFree(A->team2.tinfo);
-    if (A->team2.tcol0) (void) hipFree(A->team2.tcol0);
+    if (A->team2.tpro) (void) hipFree(A->team2.tpro);
     if (A->team2.trec) (void) hipFree(A->team2.trec);
     if (A->team2.tvoff) (void) hipFree(A->team2.tvoff);
     if (A->team2.tval) (void) hipFree(A->team2.tval);
@@ -648,7 +642,7 @@ int crp_spmm_csr_f64(crp_csr_dev_p A, int layout, int n, const double *B0, long 
         if (rc != 0) return rc;
         crp::Team2Args t;
         t.nteam = A->team2.nteam; t.torder = A->team2.torder; t.tpanel = A->team2.tpanel; t.tinfo = A->team2.tinfo;
-        t.tcol0 = A->team2.tcol0; t.trec = A->team2.trec; t.tvoff = A->team2.tvoff; t.tval = A->team2.tval;
+        t.tpro = A->team2.tpro; t.trec = A->team2.trec; t.tvoff = A->team2.tvoff; t.tval = A->team2.tval;
         return (int) crp::spmm_rm_f64_team2(t, a, (hipStream_t) stream);
     }
     if (v == 4 && (!crp::spmm_team_applicable(a) || A->b1_rows > 0)) v = 3;   // team kernel: one B source, 256-column tile
@@ -731,10 +725,10 @@ int crp_team_format_host(int nrow, const int *rowptr, const int *colidx, const d
 }
 
 int crp_team2_format_host(int nrow, const int *rowptr, const int *colidx, const double *val, int *nteam, int *lattice,
-                          int **tpanel, int **tinfo, int **tcol0, unsigned **trec, long long *nrecwords,
-                          long long **tvoff, double **tval, long long *nvalent, int **torder)
+                          int **tpanel, int **tinfo, int **tpro, unsigned **trec, long long *nrecwords,
+                          long long **tvoff, double **tval, long long *nvalent, int **torder, unsigned **vmap)
 {
-    if (nrow < 0 || rowptr == NULL || !nteam || !tpanel || !tinfo || !tcol0 || !trec || !nrecwords || !tvoff || !tval ||
+    if (nrow < 0 || rowptr == NULL || !nteam || !tpanel || !tinfo || !tpro || !trec || !nrecwords || !tvoff || !tval ||
         !nvalent || !torder)
         return -1;
     crp::PanelHost h;
@@ -750,18 +744,21 @@ int crp_team2_format_host(int nrow, const int *rowptr, const int *colidx, const 
     };
     *tpanel = dup_i(th.tpanel);
     *tinfo = dup_i(th.tinfo);
-    *tcol0 = dup_i(th.tcol0);
+    *tpro = dup_i(th.tpro);
     *torder = dup_i(th.torder);
     *trec = (unsigned *) malloc(sizeof(unsigned) * (th.trec.size() + 1));
     if (!th.trec.empty()) memcpy(*trec, th.trec.data(), sizeof(unsigned) * th.trec.size());
     *nrecwords = (long long) th.trec.size();
     *tvoff = (long long *) malloc(sizeof(long long) * (th.tvoff.size() + 1));
     memcpy(*tvoff, th.tvoff.data(), sizeof(long long) * th.tvoff.size());
-    const long long nent = th.tvoff.back();
-    *nvalent = nent;
-    *tval = (double *) calloc((size_t) nent * 8 + 1, sizeof(double));
-    for (size_t q = 0; q < th.tq.size(); q++)
-        if (th.tq[q] >= 0) memcpy(*tval + (size_t) th.tq[q] * 8, &h.pval[q * 8], sizeof(double) * 8);
+    *nvalent = th.tvoff.back();
+    *tval = (double *) calloc(th.tval.size() + 1, sizeof(double));
+    if (!th.tval.empty()) memcpy(*tval, th.tval.data(), sizeof(double) * th.tval.size());
+    if (vmap)
+    {
+        *vmap = (unsigned *) malloc(sizeof(unsigned) * (th.vmap.size() + 1));
+        if (!th.vmap.empty()) memcpy(*vmap, th.vmap.data(), sizeof(unsigned) * th.vmap.size());
+    }
     return 0;
 }
 

@@ -56,7 +56,7 @@ struct Team2Args          // panel_format.h, Team2Host
     const int      *torder;
     const int      *tpanel;    // 8 * nteam
     const int      *tinfo;     // 4 * nteam: rounds, first record block, union entries, 0
-    const int      *tcol0;     // nteam * TEAM2_D * 8
+    const int      *tpro;      // nteam * TEAM2_D * 8 * 2: {column, value offset}
     const uint32_t *trec;      // record blocks (1 KiB each)
     const long long *tvoff;    // 8 * nteam
     const double   *tval;

@@ -662,7 +662,7 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
 // ---- team2 streams (panel_format.h) ------------------------------------------------------------------
 void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *colidx, Team2Host *out)
 {
-    constexpr int T = TEAM2_T, D = TEAM2_D;
+    constexpr int T = TEAM2_T, D = TEAM2_D, CAP = TEAM2_CAP;
     TeamHost th;
     build_teams(p, nrow, rowptr, colidx, &th, T);
     const int nteam = th.nteam;
@@ -670,56 +670,174 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
     out->lattice = th.lattice;
     out->tpanel = th.tpanel;
     out->torder = th.torder;
-    out->tvoff = th.tvoff;
-    out->tq = th.tq;
-    out->real_entries = th.real_entries;
-    out->tinfo.assign((size_t) nteam * 4, 0);
-    out->tcol0.assign((size_t) nteam * D * 8, 0);
-    // record blocks per team
-    std::vector<int> blk0((size_t) nteam + 1, 0);
-    for (int g = 0; g < nteam; g++)
-    {
-        const int nr = (th.tptr[(size_t) g + 1] - th.tptr[(size_t) g]) / 8;
-        blk0[(size_t) g + 1] = blk0[(size_t) g] + (nr + 7) / 8;
-        out->tinfo[(size_t) g * 4] = nr;
-        out->tinfo[(size_t) g * 4 + 1] = blk0[(size_t) g];
-    }
-    out->trec.assign((size_t) blk0[(size_t) nteam] * 256 + 256, 0u);
     auto mask_of = [&](size_t q) { return (p.pmask4[q >> 2] >> (8 * (q & 3))) & 0xFFu; };
-    parallel_chunks(nteam, 64, [&](long long b, long long e, int) {
+
+    struct Part { int slot, first, len, src; };
+    struct TeamOut
+    {
+        int nr = 0, filled = 0, nparts = 0;
+        std::vector<int> col;                       // nr * 8 slot columns
+        std::vector<std::vector<Part>> own;         // nr * 8: parts of wave w in round r
+    };
+    std::vector<TeamOut> res((size_t) nteam);
+    parallel_chunks(nteam, 32, [&](long long b, long long e, int) {
+        std::vector<int> k8;
         for (long long g = b; g < e; g++)
         {
-            const int q0 = th.tptr[(size_t) g], nr = out->tinfo[(size_t) g * 4];
-            int real = 0;
-            for (int r = 0; r < nr; r++)
-                for (int w = 0; w < T; w++)
+            TeamOut &to = res[(size_t) g];
+            // real union entries of the team, in the team's schedule order
+            std::vector<int> nodes;
+            for (int q = th.tptr[(size_t) g]; q < th.tptr[(size_t) g + 1]; q++)
+            {
+                bool used = false;
+                for (int w = 0; w < T; w++) used = used || th.tsrc[(size_t) q * T + (size_t) w] >= 0;
+                if (used) nodes.push_back(q);
+            }
+            // contiguous row ranges of every (node, wave)
+            auto ranges = [&](unsigned m, Part *dst) {
+                int n = 0;
+                for (int r = 0; r < 8;)
                 {
-                    uint32_t x = 0, y = 0, z = 0;
-                    int c = 0;
-                    for (int e8 = 0; e8 < 8; e8++)
-                    {
-                        const int src = th.tsrc[((size_t) q0 + (size_t) r * 8 + (size_t) e8) * T + (size_t) w];
-                        if (src < 0) continue;
-                        const uint32_t m = mask_of((size_t) src);
-                        x |= (uint32_t) e8 << (4 + 3 * c);
-                        if (c < 4) y |= m << (8 * c); else z |= m << (8 * (c - 4));
-                        c++;
-                    }
-                    x |= (uint32_t) c;
-                    real += c;
-                    // the column this wave fetches D rounds ahead (padding entries repeat a valid column)
-                    const int rd = r + D;
-                    const int dcol = (rd < nr) ? th.tcol[(size_t) q0 + (size_t) rd * 8 + (size_t) w] : th.tcol[(size_t) q0];
-                    uint32_t *rec = &out->trec[((size_t) blk0[(size_t) g] + (size_t) (r >> 3)) * 256 + (size_t) (r & 7) * 32 + (size_t) w * 4];
-                    rec[0] = x; rec[1] = y; rec[2] = z; rec[3] = (uint32_t) dcol;
+                    if (!((m >> r) & 1u)) { r++; continue; }
+                    int l = 1;
+                    while (r + l < 8 && ((m >> (r + l)) & 1u)) l++;
+                    dst[n].first = r; dst[n].len = l; n++;
+                    r += l;
                 }
-            for (int d = 0; d < D; d++)
-                for (int w = 0; w < T; w++)
-                    out->tcol0[((size_t) g * D + (size_t) d) * 8 + (size_t) w] =
-                        (d < nr) ? th.tcol[(size_t) q0 + (size_t) d * 8 + (size_t) w] : (nr > 0 ? th.tcol[(size_t) q0] : 0);
-            out->tinfo[(size_t) g * 4 + 2] = real;
+                return n;
+            };
+            std::vector<char> taken(nodes.size(), 0);
+            size_t head = 0, left = nodes.size();
+            const int last_col = nodes.empty() ? 0 : th.tcol[(size_t) nodes[0]];
+            while (left > 0)
+            {
+                int cnt[T] = {0, 0, 0, 0, 0, 0, 0, 0};
+                int nslot = 0;
+                const size_t base_col = to.col.size();
+                to.col.resize(base_col + 8, last_col);
+                to.own.resize(to.own.size() + 8);
+                while (head < nodes.size() && taken[head]) head++;
+                int seen = 0;
+                for (size_t t = head; t < nodes.size() && nslot < 8 && seen < 32; t++)
+                {
+                    if (taken[t]) continue;
+                    seen++;
+                    const int q = nodes[t];
+                    Part tmp[T][4];
+                    int kk[T];
+                    bool fits = true;
+                    for (int w = 0; w < T; w++)
+                    {
+                        const int src = th.tsrc[(size_t) q * T + (size_t) w];
+                        kk[w] = src >= 0 ? ranges(mask_of((size_t) src), tmp[w]) : 0;
+                        if (cnt[w] + kk[w] > CAP) fits = false;
+                    }
+                    if (!fits) continue;
+                    for (int w = 0; w < T; w++)
+                        for (int i = 0; i < kk[w]; i++)
+                        {
+                            Part pt = tmp[w][i];
+                            pt.slot = nslot;
+                            pt.src = th.tsrc[(size_t) q * T + (size_t) w];
+                            to.own[(size_t) to.nr * 8 + (size_t) w].push_back(pt);
+                            cnt[w]++;
+                            to.nparts++;
+                        }
+                    to.col[base_col + (size_t) nslot] = th.tcol[(size_t) q];
+                    nslot++;
+                    taken[t] = 1;
+                    left--;
+                }
+                to.filled += nslot;
+                to.nr++;
+            }
         }
     });
+
+    // ---- layout: record blocks, value streams
+    out->tinfo.assign((size_t) nteam * 4, 0);
+    out->tpro.assign((size_t) nteam * D * 8 * 2, 0);
+    out->tvoff.assign((size_t) nteam * T + 1, 0);
+    std::vector<int> blk0((size_t) nteam + 1, 0);
+    long long run = 0;
+    out->real_entries = out->slots = out->parts = 0;
+    for (int g = 0; g < nteam; g++)
+    {
+        const TeamOut &to = res[(size_t) g];
+        blk0[(size_t) g + 1] = blk0[(size_t) g] + (to.nr + 7) / 8;
+        out->tinfo[(size_t) g * 4] = to.nr;
+        out->tinfo[(size_t) g * 4 + 1] = blk0[(size_t) g];
+        out->tinfo[(size_t) g * 4 + 2] = to.nparts;
+        out->tinfo[(size_t) g * 4 + 3] = to.filled;
+        out->real_entries += to.filled;
+        out->slots += (long long) to.nr * 8;
+        out->parts += to.nparts;
+        for (int w = 0; w < T; w++)
+        {
+            out->tvoff[(size_t) g * T + (size_t) w] = run;
+            for (int r = 0; r < to.nr; r++) run += (long long) to.own[(size_t) r * 8 + (size_t) w].size();
+        }
+    }
+    out->tvoff[(size_t) nteam * T] = run;
+    out->trec.assign((size_t) blk0[(size_t) nteam] * 256 + 256, 0u);
+    out->tval.assign((size_t) run * 8, 0.0);
+    // vmap through the panel format's slot map: pmap[nz] = q * 8 + row of the panel format
+    std::vector<uint32_t> slot_of(p.pcol.size() * 8, 0xFFFFFFFFu);       // panel-format value slot -> tval slot
+    parallel_chunks(nteam, 32, [&](long long b, long long e, int) {
+        for (long long g = b; g < e; g++)
+        {
+            const TeamOut &to = res[(size_t) g];
+            for (int w = 0; w < T; w++)
+            {
+                long long k = out->tvoff[(size_t) g * T + (size_t) w];
+                const long long k0 = k;
+                for (int r = 0; r < to.nr; r++)
+                {
+                    const std::vector<Part> &ow = to.own[(size_t) r * 8 + (size_t) w];
+                    uint32_t x = (uint32_t) ow.size(), y = 0;
+                    for (size_t i = 0; i < ow.size(); i++)
+                    {
+                        const Part &pt = ow[i];
+                        x |= (uint32_t) pt.slot << (4 + 3 * i);
+                        y |= (uint32_t) (pt.first * 8 - pt.first * (pt.first - 1) / 2 + pt.len - 1) << (6 * i);
+                        for (int rr = pt.first; rr < pt.first + pt.len; rr++)
+                        {
+                            out->tval[(size_t) k * 8 + (size_t) rr] = p.pval[(size_t) pt.src * 8 + (size_t) rr];
+                            slot_of[(size_t) pt.src * 8 + (size_t) rr] = (uint32_t) (k * 8 + rr);
+                        }
+                        k++;
+                    }
+                    uint32_t *rec = &out->trec[((size_t) blk0[(size_t) g] + (size_t) (r >> 3)) * 256 + (size_t) (r & 7) * 32 + (size_t) w * 4];
+                    rec[0] = x;
+                    rec[1] = y;
+                }
+                // value offsets and columns fetched D rounds ahead
+                std::vector<long long> voff((size_t) to.nr + 1, 0);
+                for (int r = 0; r < to.nr; r++) voff[(size_t) r + 1] = voff[(size_t) r] + (long long) to.own[(size_t) r * 8 + (size_t) w].size();
+                (void) k0;
+                for (int r = 0; r < to.nr; r++)
+                {
+                    const int rd = r + D;
+                    uint32_t *rec = &out->trec[((size_t) blk0[(size_t) g] + (size_t) (r >> 3)) * 256 + (size_t) (r & 7) * 32 + (size_t) w * 4];
+                    rec[2] = (uint32_t) (rd < to.nr ? voff[(size_t) rd] : voff[(size_t) to.nr]);
+                    rec[3] = (uint32_t) (rd < to.nr ? to.col[(size_t) rd * 8 + (size_t) w] : to.col[0]);
+                    // flags that steer the kernel's round (tools/gen_team2_asm.py)
+                    if (rd < to.nr) rec[0] |= 1u << 16;                                   // ISSUE: fetch for round r + D
+                    if (r + D - 1 >= to.nr) rec[0] |= 1u << 17;                           // TAIL: fewer than D-1 younger rounds in flight
+                    if (r == to.nr - 1) rec[0] |= 1u << 18;                               // LAST
+                    if (w == 0 && (r & 7) == 0 && (r >> 3) + 1 < (to.nr + 7) / 8) rec[0] |= 1u << 19;   // RECS: fetch the next record block
+                }
+                for (int d = 0; d < D; d++)
+                {
+                    int *pr = &out->tpro[(((size_t) g * D + (size_t) d) * 8 + (size_t) w) * 2];
+                    pr[0] = (d < to.nr) ? to.col[(size_t) d * 8 + (size_t) w] : (to.nr > 0 ? to.col[0] : 0);
+                    pr[1] = (int) ((d < to.nr) ? voff[(size_t) d] : voff[(size_t) to.nr]);
+                }
+            }
+        }
+    });
+    out->vmap.assign(p.pmap.size(), 0u);
+    for (size_t nz = 0; nz < p.pmap.size(); nz++) out->vmap[nz] = slot_of[(size_t) p.pmap[nz]];
 }
 
 void apply_team_schedule(PanelHost *p, const TeamHost &t)

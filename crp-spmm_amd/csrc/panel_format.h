@@ -99,30 +99,44 @@ void apply_team_schedule(PanelHost *p, const TeamHost &t);
 
 // ---- team2: the streams of the LDS-sharing kernel of csrc/team2_kernel.hip ---------------------------
 // A team is TEAM2_T = 8 panels, one per wave of a 512-thread workgroup.  The union of their columns
-// (TeamHost: merged, in a balanced schedule) is walked in rounds of 8 union entries; wave w fetches entry w
-// of a round (one B row slice) by LDS-DMA into a ring shared by the workgroup, TEAM2_D rounds ahead.
-// Per (round, wave) one 16-byte record tells a wave what it owns in the round:
-//   x : bits 0-3 = number of own entries c (0..8); bits 4+3i .. 6+3i = ring slot (0..7) of own entry i
-//   y : row masks of own entries 0..3 (byte i), z : of own entries 4..7
-//   w : column (two-source encoding) of the union entry this wave fetches for round r + TEAM2_D
-// Records are stored in blocks of 8 rounds x 8 waves (1 KiB, one LDS-DMA instruction); the columns
-// of the first TEAM2_D rounds come from tcol0.  A wave's values (8 per own entry, in the order it
-// meets its entries) are a contiguous stream starting at entry tvoff[8 g + w].
+// (TeamHost: merged, in a balanced schedule) is walked in rounds of up to 8 union entries ("slots"); wave w
+// fetches slot w of a round (one B row slice) by LDS-DMA into a ring shared by the workgroup, TEAM2_D rounds
+// ahead.  What a wave owns of a round is a list of at most TEAM2_CAP PARTS: a part is one slot together with a
+// CONTIGUOUS range of the panel's rows that have the column (an entry whose rows are not contiguous is split
+// into several parts), so that the kernel can jump to straight-line code for the range instead of testing a
+// mask bit per row.  Per (round, wave) one 16-byte record:
+//   word 0 : bits 0-2 = number of parts c (0..4); bits 4+3i .. 6+3i = ring slot (0..7) of part i; flags: bit 16
+//            ISSUE (r + D < rounds), 17 TAIL (r + D - 1 >= rounds), 18 LAST round, 19 RECS (wave 0, r % 8 == 0 and
+//            a further record block exists: fetch it now)
+//   word 1 : bits 6i .. 6i+5 = range code of part i: code(first, len) = first * 8 - first * (first - 1) / 2 + len - 1
+//            (0..35; first = first row, len = rows)
+//   word 2 : entry offset, inside the wave's value stream, of the parts of round r + TEAM2_D
+//   word 3 : column (two-source encoding) of the union entry this wave fetches for round r + TEAM2_D
+// Records are stored in blocks of 8 rounds x 8 waves (1 KiB, one LDS-DMA instruction); for the first TEAM2_D
+// rounds the (column, value offset) pairs come from tpro.  A wave's values are a stream of 8-double groups, one
+// per part in the order the wave meets them (rows outside the part's range hold 0 and are never read), starting
+// at entry tvoff[8 g + w]; round r's parts are contiguous in it.
 constexpr int TEAM2_T = 8;
 constexpr int TEAM2_D = 3;
+constexpr int TEAM2_CAP = 4;
 struct Team2Host
 {
     int nteam = 0;
     bool lattice = false;
     std::vector<int>       tpanel;   // 8 * nteam: panel of wave w, or -1
     std::vector<int>       torder;   // processing order of the teams
-    std::vector<int>       tinfo;    // 4 * nteam: rounds, first record block, union entries, 0
-    std::vector<int>       tcol0;    // nteam * TEAM2_D * 8: columns fetched for rounds 0 .. TEAM2_D-1
+    std::vector<int>       tinfo;    // 4 * nteam: rounds, first record block, parts of all waves, filled slots
+    std::vector<int>       tpro;     // nteam * TEAM2_D * 8 * 2: {column, value offset} wave w fetches for round d < TEAM2_D
     std::vector<uint32_t>  trec;     // record blocks: 256 words each
-    std::vector<long long> tvoff;    // 8 * nteam + 1
-    std::vector<long long> tq;       // per panel-format entry: its entry index in the value streams, or -1
-    long long real_entries = 0;      // union entries before padding
+    std::vector<long long> tvoff;    // 8 * nteam + 1: first value group of wave w's stream
+    std::vector<double>    tval;     // value groups (8 doubles each)
+    std::vector<uint32_t>  vmap;     // per CSR nonzero (panel format's own order of pmap): its slot in tval
+    long long real_entries = 0;      // union entries (filled slots)
+    long long slots = 0;             // slots including the empty ones of partly filled rounds
+    long long parts = 0;
 };
+// p must hold its entries in column order (build_panels(..., team_schedule = false)); p.pmap is consumed to
+// build vmap (indexed like p.pmap: by the CSR nonzero position the panels were built from).
 void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *colidx, Team2Host *out);
 
 // Number of panel entries (before padding) a given R would need: cheap pass used

@@ -138,24 +138,25 @@ def team_format_host(rowptr, colidx, val):
 
 
 def team2_format_host(rowptr, colidx, val):
-    """crp_team2_format_host -> dict(nteam, lattice, tpanel[nteam, 8], tinfo[nteam, 4], tcol0[nteam, 3, 8],
-    trec (uint32 words), tvoff, tval[nent, 8], torder)."""
+    """crp_team2_format_host -> dict(nteam, lattice, tpanel[nteam, 8], tinfo[nteam, 4], tpro[nteam, 3, 8, 2],
+    trec (uint32 words), tvoff, tval[groups, 8], torder, vmap)."""
     lib = L.load()
     rp = np.ascontiguousarray(rowptr, dtype=np.int32)
     ci = np.ascontiguousarray(colidx, dtype=np.int32)
     va = np.ascontiguousarray(val, dtype=np.float64)
+    nnz = int(rp[-1])
     if ci.size == 0:
         ci, va = np.zeros(1, np.int32), np.zeros(1)
     nteam, lat = C.c_int(), C.c_int()
-    tp, ti, tc0, to = L.c_int_p(), L.c_int_p(), L.c_int_p(), L.c_int_p()
-    tr = C.POINTER(C.c_uint)()
+    tp, ti, tpr, to = L.c_int_p(), L.c_int_p(), L.c_int_p(), L.c_int_p()
+    tr, vm = C.POINTER(C.c_uint)(), C.POINTER(C.c_uint)()
     tv = C.POINTER(C.c_longlong)()
     tval = L.c_dbl_p()
     nrw, nve = C.c_longlong(), C.c_longlong()
     L.check(lib.crp_team2_format_host(rp.size - 1, rp.ctypes.data_as(L.c_int_p), ci.ctypes.data_as(L.c_int_p),
                                       va.ctypes.data_as(L.c_dbl_p), C.byref(nteam), C.byref(lat), C.byref(tp), C.byref(ti),
-                                      C.byref(tc0), C.byref(tr), C.byref(nrw), C.byref(tv), C.byref(tval), C.byref(nve),
-                                      C.byref(to)), "crp_team2_format_host")
+                                      C.byref(tpr), C.byref(tr), C.byref(nrw), C.byref(tv), C.byref(tval), C.byref(nve),
+                                      C.byref(to), C.byref(vm)), "crp_team2_format_host")
     nt = nteam.value
 
     def take(ptr, cnt, dt):
@@ -163,9 +164,10 @@ def team2_format_host(rowptr, colidx, val):
         L.c_free(C.cast(ptr, C.c_void_p))
         return out
     return dict(nteam=nt, lattice=bool(lat.value), tpanel=take(tp, 8 * nt, np.int32).reshape(nt, 8),
-                tinfo=take(ti, 4 * nt, np.int32).reshape(nt, 4), tcol0=take(tc0, 24 * nt, np.int32).reshape(nt, 3, 8),
+                tinfo=take(ti, 4 * nt, np.int32).reshape(nt, 4), tpro=take(tpr, 48 * nt, np.int32).reshape(nt, 3, 8, 2),
                 trec=take(tr, nrw.value, np.uint32), tvoff=take(tv, 8 * nt + 1, np.int64),
-                tval=take(tval, 8 * nve.value, np.float64).reshape(-1, 8), torder=take(to, nt, np.int32))
+                tval=take(tval, 8 * nve.value, np.float64).reshape(-1, 8), torder=take(to, nt, np.int32),
+                vmap=take(vm, nnz, np.uint32))
 
 
 def locality_order_host(rowptr, colidx, ncol=None, nparts=8):

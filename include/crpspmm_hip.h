@@ -138,14 +138,16 @@ int crp_team_format_host(int nrow, const int *rowptr, const int *colidx, const d
 
 /* Host-only: the streams variant 5 ("team2-R8", csrc/team2_kernel.hip) consumes: teams of 8 panels of 8 rows
  * (one per wave of a 512-thread workgroup; tpanel, -1 = none), the union of whose columns is walked in rounds
- * of 8 entries.  tinfo[4g] = rounds of team g, tinfo[4g+1] = its first record block; trec = record blocks of
- * 8 rounds x 8 waves x 4 words {count | ring slots, masks of own entries 0-3, masks 4-7, column this wave
- * fetches 3 rounds ahead}; tcol0[(3g + d) * 8 + w] = column wave w fetches for round d < 3; wave w's values
- * (8 per own entry, in the order it meets them) start at tval[8 * tvoff[8g + w]].  *nvalent = entries in tval.
- * malloc'd copies (caller frees).  Used by the CPU tests, which replay the streams in numpy. */
+ * of up to 8 slots.  tinfo[4g] = rounds of team g, [4g+1] = its first record block, [4g+2] = parts of all its
+ * waves, [4g+3] = filled slots.  trec = record blocks of 8 rounds x 8 waves x 4 words: {part count | ring
+ * slots, range codes (6 bits per part: code(first, len) = first*8 - first*(first-1)/2 + len - 1), value offset
+ * of round r+3's parts in the wave's stream, column this wave fetches for round r+3}; tpro[((3g + d)*8 + w)*2 ..]
+ * = {column, value offset} of round d < 3; wave w's value groups (8 doubles per part, rows outside the part's
+ * range 0) start at tval[8 * tvoff[8g + w]]; vmap[nz] = slot in tval of CSR nonzero nz.  *nvalent = groups in
+ * tval.  malloc'd copies (caller frees).  Used by the CPU tests, which replay the streams in numpy. */
 int crp_team2_format_host(int nrow, const int *rowptr, const int *colidx, const double *val, int *nteam, int *lattice,
-                          int **tpanel, int **tinfo, int **tcol0, unsigned **trec, long long *nrecwords,
-                          long long **tvoff, double **tval, long long *nvalent, int **torder);
+                          int **tpanel, int **tinfo, int **tpro, unsigned **trec, long long *nrecwords,
+                          long long **tvoff, double **tval, long long *nvalent, int **torder, unsigned **vmap);
 
 /* Host-only: the processing order of the rows of a square A that crp_csr_dev_create() applies for B-row
  * locality (csrc/locality.cpp: row groups with identical column lists, `nparts` slabs by breadth-first

@@ -546,49 +546,66 @@ def test_parallel_ingest_and_cache(crp, orc, tmp_path):
     print("parallel ingest of %d entries: %.3f s" % (r.size, t_par))
 
 
-def _replay_team2(t, m, B):
+def _range_of_code(code):
+    for first in range(8):
+        base = first * 8 - first * (first - 1) // 2
+        if base <= code < base + (8 - first):
+            return first, code - base + 1
+    raise AssertionError("bad range code %d" % code)
+
+
+def _replay_team2(t, m, B, va=None):
     """Replays the team2 streams the way csrc/team2_kernel.hip walks them: per team and wave, round by round;
-    the column behind ring slot e of round r is what wave e fetched for that round (tcol0 for the first 3
-    rounds, the record of round r - 3 afterwards); a wave's k-th own entry takes values tval[tvoff + k]."""
+    the column behind ring slot e of round r is what wave e fetched for that round (tpro for the first 3
+    rounds, the record of round r - 3 afterwards); the parts of round r take their values from the wave's stream
+    at the offset the record of round r - 3 (or tpro) announced."""
     C_out = np.zeros((m, B.shape[1]))
     written = np.zeros(m, dtype=bool)
     rec = t["trec"].reshape(-1, 8, 8, 4)          # [block][round in block][wave][word]
     for g in range(t["nteam"]):
         nr, blk0 = int(t["tinfo"][g, 0]), int(t["tinfo"][g, 1])
         cols = np.zeros((nr, 8), dtype=np.int64)
+        voffs = np.zeros((nr, 8), dtype=np.int64)
         for r in range(nr):
             for w in range(8):
-                cols[r, w] = t["tcol0"][g, r, w] if r < 3 else np.int32(rec[blk0 + ((r - 3) >> 3), (r - 3) & 7, w, 3])
-        own_total = 0
+                if r < 3:
+                    cols[r, w], voffs[r, w] = t["tpro"][g, r, w]
+                else:
+                    cols[r, w] = np.int32(rec[blk0 + ((r - 3) >> 3), (r - 3) & 7, w, 3])
+                    voffs[r, w] = rec[blk0 + ((r - 3) >> 3), (r - 3) & 7, w, 2]
+        parts_total = 0
         for w in range(8):
             panel = int(t["tpanel"][g, w])
-            k = int(t["tvoff"][8 * g + w])
+            k0 = int(t["tvoff"][8 * g + w])
+            k = 0
             acc = np.zeros((8, B.shape[1]))
             for r in range(nr):
-                x, y, z, _ = (int(v) for v in rec[blk0 + (r >> 3), r & 7, w])
-                cnt = x & 15
-                assert cnt <= 8
+                x, y = int(rec[blk0 + (r >> 3), r & 7, w, 0]), int(rec[blk0 + (r >> 3), r & 7, w, 1])
+                cnt = x & 7
+                assert cnt <= 4 and (x & 8) == 0
                 if panel < 0:
                     assert cnt == 0
+                if cnt:
+                    assert voffs[r, w] == k, (g, w, r)         # the announced offset is where the stream stands
                 for i in range(cnt):
                     slot = (x >> (4 + 3 * i)) & 7
-                    mask = ((y if i < 4 else z) >> (8 * (i & 3))) & 0xFF
-                    assert mask != 0
+                    first, ln = _range_of_code((y >> (6 * i)) & 63)
                     c = int(cols[r, slot])
                     assert 0 <= c < B.shape[0]
-                    for rr in range(8):
-                        if (mask >> rr) & 1:
-                            acc[rr] += t["tval"][k, rr] * B[c]
+                    for rr in range(first, first + ln):
+                        acc[rr] += t["tval"][k0 + k, rr] * B[c]
                     k += 1
-                own_total += cnt
+                parts_total += cnt
             if panel >= 0:
-                assert k == int(t["tvoff"][8 * g + w + 1])
+                assert k0 + k == int(t["tvoff"][8 * g + w + 1])
                 lo, hi = panel * 8, min(m, panel * 8 + 8)
                 C_out[lo:hi] = acc[:hi - lo]
                 assert not written[lo:hi].any()
                 written[lo:hi] = True
-        assert own_total == int(t["tinfo"][g, 2])
+        assert parts_total == int(t["tinfo"][g, 2])
     assert written.all()
+    if va is not None:                             # the value-update map names every nonzero's slot
+        assert np.array_equal(t["tval"].reshape(-1)[t["vmap"]], va)
     return C_out
 
 
@@ -616,6 +633,6 @@ def test_team2_streams_replay(crp, orc):
         if name == "lattice":
             assert t["lattice"]
         B = rng.uniform(-1, 1, size=(k, 3))
-        got = _replay_team2(t, m, B)
+        got = _replay_team2(t, m, B, va)
         ref = orc.spmm_csr(rp, ci, va, B)
         assert orc.rel_fro_err(ref, got) <= 1e-13, name

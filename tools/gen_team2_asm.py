@@ -1,105 +1,226 @@
 #!/usr/bin/env python3
-"""Generates crp-spmm_amd/csrc/team2_consume.inc: the hand-scheduled gfx950 instruction stream with which
-one wave of the LDS-sharing SpMM kernel (csrc/team2_kernel.hip) consumes its own entries of one round.
+"""Generates crp-spmm_amd/csrc/team2_consume.inc: the hand-scheduled gfx950 instruction stream of the round loop of
+the LDS-sharing SpMM kernel (csrc/team2_kernel.hip).
 
-Why a generated asm text: the stream keeps up to two entries' LDS reads in flight under counted
-s_waitcnt lgkmcnt(N) while the FMAs of the previous entry issue, and every register whose load is in
-flight must stay out of the compiler's hands (hipcc treats an asm load's destination as written when
-the statement ends and may copy it before the data has landed).  So one round is ONE asm statement:
-the staging registers are fixed VGPRs named in the clobber list, the accumulators are "+v" operands.
+Why a generated asm text, and why the whole loop
+  * up to two parts' LDS reads are in flight under counted s_waitcnt lgkmcnt(N) while the FMAs of the part before
+    issue, and a register whose load is in flight must stay out of the compiler's hands (hipcc treats an asm
+    load's destination as written when the statement ends and may copy it before the data has landed); the
+    straight-line FMA sequences (below) are shared by all rounds, so the accumulators must sit in the same physical
+    registers whenever one is called.  Both hold only inside ONE asm statement: the loop over the rounds of a team is
+    that statement, its staging registers are fixed VGPRs / SGPRs named in the clobber list, the accumulators and
+    everything the compiler prepared are operands;
+  * the scalar unit is the scarce resource of this kernel (one SALU issue per cycle and CU, shared by 16 waves).
+    The first version tested one mask bit per row and let the compiler write the round's bookkeeping: 119 M
+    scalar instructions per launch on the pwtk stand-in, and the kernel was bound by them.  Now
+      - a part names a CONTIGUOUS row range; its FMAs are straight-line code reached by one computed call: 36
+        sequences per staging buffer, each aligned to 2^SEQ bytes, entered with s_swappc_b64, left with s_setpc_b64
+        (per part: 2 x s_bfe, s_lshl, s_add, s_addc + call / return; nothing per row);
+      - the loop is unrolled over the NSET = 4 ring sets, so every LDS offset of a round (ring set, value slot,
+        record) is an immediate; what a round does is steered by flag bits of its record.
 
-Per own entry i (static stage i = 0..7, left through a forward branch when i reaches the count):
-    ring slot  = ctl[4+3i .. 6+3i]           -> B row slice by ds_read_b128 (one per 16-byte piece)
-    values     = ds_read_b64 at value-ring offset kp + (lane & 7) * 8 (lane l holds value l & 7)
-    row mask   = byte i of (mlo, mhi)
-    row r      : s_bitcmp0 / s_cbranch skip, else v_fmac_f64_dpp acc, values, slice row_newbcast:r
-Reads of entry i + 1 are issued before the wait for entry i.
+Record of (round r, wave w), 4 words (panel_format.h, Team2Host):
+    w0 : bits 0-2 part count c (0..4) | bits 4+3i.. ring slot of part i | bit 16 ISSUE (fetch for round r + D)
+         | bit 17 TAIL (fewer than D-1 younger rounds in flight at the top of round r: wait vmcnt(0))
+         | bit 18 LAST round of the team | bit 19 RECS (this wave fetches the next record block now)
+    w1 : bits 6i.. range code of part i        w2 : value-stream offset of round r + D        w3 : column of round r + D
+Per round: [wait own DMAs of the round; s_barrier] -> issue (values: 16-lane LDS-DMA of 256 bytes; row: NV DMAs of 1
+KiB) -> read the next record -> parts: B row slice by ds_read_b128 per 16-byte piece, the part's 8 values by ONE
+ds_read_b64 (lane l holds value l & 7), call of sequence code_i: rows first..first+len-1, per row
+    v_fmac_f64_dpp acc, values, slice row_newbcast:row   (NV * 2 of them)
+The reads of part i + 1 are issued before the wait for part i.
 
 usage: tools/gen_team2_asm.py > crp-spmm_amd/csrc/team2_consume.inc
 """
 import sys
 
-VBASE = 100          # first fixed staging VGPR (even): A0 A1 AV B0 B1 BV TA TB
-VAL_RING_BYTES = 3 * 512
+D = 3
+NSET = 4
+VSLOT = 256
+VBASE = 100          # fixed VGPRs: A0(4) A1(4) AV(2) B0(4) B1(4) BV(2) TA TV REC(4)
+SBASE = 84           # fixed SGPRs: pc(2) ret(2) tblA(2) tblB(2) t cnt rowbase(2) recsrc(2)
+NCODE = 36
+NVREG = 26
+NSREG = 14
 
 
-def regs(nv):
+def gen(nv, has_b1):
     b = VBASE
     A = {"s0": b, "s1": b + 4, "v": b + 8}
     B = {"s0": b + 10, "s1": b + 14, "v": b + 18}
-    return A, B, b + 20, b + 21
-
-
-def gen(nv):
-    A, B, TA, TB = regs(nv)
+    TA, TV, REC = b + 20, b + 21, b + 22
+    PC, RET, TBA, TBB, T, CNT, RB, RS = SBASE, SBASE + 2, SBASE + 4, SBASE + 6, SBASE + 8, SBASE + 9, SBASE + 10, SBASE + 12
+    slotb = 1024 * nv
+    setb = 8 * slotb
     slot_shift = 11 if nv == 2 else 10
+    seq_align = 9 if nv == 2 else 8                 # 2^9 >= 8 rows x 4 FMAs x 8 bytes + return
+    opr = nv + 1                                    # DMAs a wave issues per round
+    tag = "%d%d_%%=" % (nv, 1 if has_b1 else 0)
     L = []
     emit = L.append
 
-    def rd(i, X):
-        emit("s_bfe_u32 %%[st], %%[ctl], 0x%x" % ((3 << 16) | (4 + 3 * i)))
-        emit("s_lshl_b32 %%[st], %%[st], %d" % slot_shift)
-        emit("v_add_u32 v%d, %%[st], %%[seta]" % TA)
-        emit("ds_read_b128 v[%d:%d], v%d" % (X["s0"], X["s0"] + 3, TA))
+    def rd(k, i, X):
+        emit("s_bfe_u32 s%d, %%[w0], 0x%x" % (T, (3 << 16) | (4 + 3 * i)))
+        emit("v_lshl_add_u32 v%d, s%d, %d, %%[seta]" % (TA, T, slot_shift))
+        emit("ds_read_b128 v[%d:%d], v%d offset:%d" % (X["s0"], X["s0"] + 3, TA, k * setb))
         if nv == 2:
-            emit("ds_read_b128 v[%d:%d], v%d offset:1024" % (X["s1"], X["s1"] + 3, TA))
-        emit("v_add_u32 v%d, %%[kp], %%[vln]" % TB)
-        emit("ds_read_b64 v[%d:%d], v%d" % (X["v"], X["v"] + 1, TB))
-        emit("s_add_u32 %[kp], %[kp], 64")
-        emit("s_cmp_eq_u32 %%[kp], %d" % VAL_RING_BYTES)
-        emit("s_cselect_b32 %[kp], 0, %[kp]")
+            emit("ds_read_b128 v[%d:%d], v%d offset:%d" % (X["s1"], X["s1"] + 3, TA, k * setb + 1024))
+        emit("ds_read_b64 v[%d:%d], %%[vsl] offset:%d" % (X["v"], X["v"] + 1, k * VSLOT + 64 * i))
 
-    def rows(i, X):
-        emit("s_bfe_u32 %%[sm], %%[%s], 0x%x" % ("mlo" if i < 4 else "mhi", (8 << 16) | (8 * (i & 3))))
-        for r in range(8):
-            emit("s_bitcmp0_b32 %%[sm], %d" % r)
-            emit("s_cbranch_scc1 .Lt2r%d_%d_%%=" % (i, r))
-            for v in range(nv):
-                base = X["s0"] if v == 0 else X["s1"]
-                for w in range(2):
-                    emit("v_fmac_f64_dpp %%[a%d], v[%d:%d], v[%d:%d] row_newbcast:%d row_mask:0xf bank_mask:0xf"
-                         % ((r * nv + v) * 2 + w, X["v"], X["v"] + 1, base + 2 * w, base + 2 * w + 1, r))
-            emit(".Lt2r%d_%d_%%=:" % (i, r))
+    def call(i, tb):
+        emit("s_bfe_u32 s%d, %%[w1], 0x%x" % (T, (6 << 16) | (6 * i)))
+        emit("s_lshl_b32 s%d, s%d, %d" % (T, T, seq_align))
+        emit("s_add_u32 s%d, s%d, s%d" % (PC, tb, T))
+        emit("s_addc_u32 s%d, s%d, 0" % (PC + 1, tb + 1))
+        emit("s_swappc_b64 s[%d:%d], s[%d:%d]" % (RET, RET + 1, PC, PC + 1))
 
-    nrd = nv + 1                       # LDS reads per entry
-    emit("s_and_b32 %[cnt], %[ctl], 15")
-    emit("s_cmp_eq_u32 %[cnt], 0")
-    emit("s_cbranch_scc1 .Lt2end_%=")
-    rd(0, A)
-    for i in range(8):
-        cur, nxt = (A, B) if i % 2 == 0 else (B, A)
-        if i < 7:
-            emit("s_cmp_gt_u32 %%[cnt], %d" % (i + 1))
-            emit("s_cbranch_scc0 .Lt2w%d_%%=" % i)
-            rd(i + 1, nxt)
-            emit("s_waitcnt lgkmcnt(%d)" % nrd)
-            emit("s_branch .Lt2f%d_%%=" % i)
-            emit(".Lt2w%d_%%=:" % i)
-            emit("s_waitcnt lgkmcnt(0)")
-            emit(".Lt2f%d_%%=:" % i)
+    # ---- once: table bases, fixed copies of what is advanced in the loop
+    emit("s_getpc_b64 s[%d:%d]" % (TBA, TBA + 1))
+    emit(".Lt2pc%s:" % tag)
+    emit("s_add_u32 s%d, s%d, .Lt2tabA%s-.Lt2pc%s" % (TBA, TBA, tag, tag))
+    emit("s_addc_u32 s%d, s%d, 0" % (TBA + 1, TBA + 1))
+    emit("s_add_u32 s%d, s%d, %d" % (TBB, TBA, NCODE << seq_align))
+    emit("s_addc_u32 s%d, s%d, 0" % (TBB + 1, TBA + 1))
+    emit("s_mov_b32 s%d, %%[rslo]" % RS)
+    emit("s_mov_b32 s%d, %%[rshi]" % (RS + 1))
+    emit("s_branch .Lt2body0%s" % tag)               # round 0: the compiler's code has waited, synchronised and read the record
+
+    for k in range(NSET):
+        kd = (k + D) % NSET                          # set of round r + D
+        emit(".Lt2round%d%s:" % (k, tag))
+        emit("s_bitcmp1_b32 %[w0], 17")
+        emit("s_cbranch_scc1 .Lt2tw%d%s" % (k, tag))
+        emit("s_waitcnt vmcnt(%d)" % ((D - 1) * opr))
+        emit("s_barrier")
+        emit("s_branch .Lt2body%d%s" % (k, tag))
+        emit(".Lt2tw%d%s:" % (k, tag))
+        emit("s_waitcnt vmcnt(0)")
+        emit("s_barrier")
+        emit(".Lt2body%d%s:" % (k, tag))
+        # -- issue for round r + D
+        emit("s_bitcmp1_b32 %[w0], 16")
+        emit("s_cbranch_scc0 .Lt2ni%d%s" % (k, tag))
+        emit("v_lshl_add_u32 v%d, %%[w2], 6, %%[lane16]" % TV)
+        emit("s_mov_b64 exec, 0xffff")
+        emit("s_add_u32 m0, %%[vringw], %d" % (kd * VSLOT))
+        emit("s_nop 0")
+        emit("global_load_lds_dwordx4 v%d, %%[vbase]" % TV)
+        emit("s_mov_b64 exec, -1")
+        if has_b1:
+            # c < 0: row ~c of B1
+            emit("s_cmp_lt_i32 %[w3], 0")
+            emit("s_cbranch_scc1 .Lt2b1%d%s" % (k, tag))
+        emit("s_mul_hi_u32 s%d, %%[w3], %%[ld0]" % (RB + 1))
+        emit("s_mul_i32 s%d, %%[w3], %%[ld0]" % RB)
+        emit("s_add_u32 s%d, s%d, %%[b0lo]" % (RB, RB))
+        emit("s_addc_u32 s%d, s%d, %%[b0hi]" % (RB + 1, RB + 1))
+        if has_b1:
+            emit("s_branch .Lt2bj%d%s" % (k, tag))
+            emit(".Lt2b1%d%s:" % (k, tag))
+            emit("s_not_b32 s%d, %%[w3]" % T)
+            emit("s_mul_hi_u32 s%d, s%d, %%[ld1]" % (RB + 1, T))
+            emit("s_mul_i32 s%d, s%d, %%[ld1]" % (RB, T))
+            emit("s_add_u32 s%d, s%d, %%[b1lo]" % (RB, RB))
+            emit("s_addc_u32 s%d, s%d, %%[b1hi]" % (RB + 1, RB + 1))
+            emit(".Lt2bj%d%s:" % (k, tag))
+        emit("s_add_u32 m0, %%[wslot], %d" % (kd * setb))
+        emit("s_nop 0")
+        emit("global_load_lds_dwordx4 %%[voffa], s[%d:%d]" % (RB, RB + 1))
+        if nv == 2:
+            emit("global_load_lds_dwordx4 %%[voffb], s[%d:%d] offset:1024" % (RB, RB + 1))
+        emit(".Lt2ni%d%s:" % (k, tag))
+        # -- next record block (one wave, every 8 rounds)
+        emit("s_bitcmp1_b32 %[w0], 19")
+        emit("s_cbranch_scc0 .Lt2nr%d%s" % (k, tag))
+        emit("s_add_u32 s%d, s%d, 1024" % (RS, RS))
+        emit("s_addc_u32 s%d, s%d, 0" % (RS + 1, RS + 1))
+        emit("s_xor_b32 %[recdst], %[recdst], 1024")
+        emit("s_mov_b32 m0, %[recdst]")
+        emit("s_nop 0")
+        emit("global_load_lds_dwordx4 %%[lane16], s[%d:%d]" % (RS, RS + 1))
+        emit(".Lt2nr%d%s:" % (k, tag))
+        # -- record of the next round (LDS reads return in order: it is there when the parts are done)
+        if k < NSET - 1:
+            emit("ds_read_b128 v[%d:%d], %%[recaddr] offset:%d" % (REC, REC + 3, (k + 1) * 128))
         else:
-            emit("s_waitcnt lgkmcnt(0)")
-        rows(i, cur)
-        if i < 7:
-            emit("s_cmp_le_u32 %%[cnt], %d" % (i + 1))
-            emit("s_cbranch_scc1 .Lt2end_%=")
-    emit(".Lt2end_%=:")
+            emit("v_add_u32 %[recoff], 512, %[recoff]")
+            emit("v_and_b32 %[recoff], 0x7ff, %[recoff]")
+            emit("v_add_u32 %[recaddr], %[recbase], %[recoff]")
+            emit("ds_read_b128 v[%d:%d], %%[recaddr]" % (REC, REC + 3))
+        # -- parts
+        emit("s_and_b32 s%d, %%[w0], 7" % CNT)
+        emit("s_cmp_eq_u32 s%d, 0" % CNT)
+        emit("s_cbranch_scc1 .Lt2pe%d%s" % (k, tag))
+        emit("s_cmp_eq_u32 s%d, 1" % CNT)
+        emit("s_cbranch_scc1 .Lt2v%d_1%s" % (k, tag))
+        emit("s_cmp_eq_u32 s%d, 2" % CNT)
+        emit("s_cbranch_scc1 .Lt2v%d_2%s" % (k, tag))
+        emit("s_cmp_eq_u32 s%d, 3" % CNT)
+        emit("s_cbranch_scc1 .Lt2v%d_3%s" % (k, tag))
+        nrd = nv + 1
+        for c in (4, 3, 2, 1):
+            if c != 4:
+                emit(".Lt2v%d_%d%s:" % (k, c, tag))
+            bufs = [(A, TBA), (B, TBB)]
+            rd(k, 0, A)
+            for i in range(c):
+                cur, tb = bufs[i % 2]
+                if i + 1 < c:
+                    rd(k, i + 1, bufs[(i + 1) % 2][0])
+                    emit("s_waitcnt lgkmcnt(%d)" % nrd)
+                else:
+                    emit("s_waitcnt lgkmcnt(0)")
+                call(i, tb)
+            if c != 1:
+                emit("s_branch .Lt2pe%d%s" % (k, tag))
+        emit(".Lt2pe%d%s:" % (k, tag))
+        emit("s_bitcmp1_b32 %[w0], 18")
+        emit("s_cbranch_scc1 .Lt2done%s" % tag)
+        emit("s_waitcnt lgkmcnt(0)")
+        emit("v_readfirstlane_b32 %%[w0], v%d" % REC)
+        emit("v_readfirstlane_b32 %%[w1], v%d" % (REC + 1))
+        emit("v_readfirstlane_b32 %%[w2], v%d" % (REC + 2))
+        emit("v_readfirstlane_b32 %%[w3], v%d" % (REC + 3))
+        if k == NSET - 1:
+            emit("s_branch .Lt2round0%s" % tag)
+    # ---- the sequences
+    for name, X in (("A", A), ("B", B)):
+        code = 0
+        for first in range(8):
+            for ln in range(1, 9 - first):
+                emit(".p2align %d" % seq_align)
+                if code == 0:
+                    emit(".Lt2tab%s%s:" % (name, tag))
+                for r in range(first, first + ln):
+                    for v in range(nv):
+                        base = X["s0"] if v == 0 else X["s1"]
+                        for w in range(2):
+                            emit("v_fmac_f64_dpp %%[a%d], v[%d:%d], v[%d:%d] row_newbcast:%d row_mask:0xf bank_mask:0xf"
+                                 % ((r * nv + v) * 2 + w, X["v"], X["v"] + 1, base + 2 * w, base + 2 * w + 1, r))
+                emit("s_setpc_b64 s[%d:%d]" % (RET, RET + 1))
+                code += 1
+        assert code == NCODE
+    emit(".Lt2done%s:" % tag)
+    emit("s_waitcnt lgkmcnt(0)")                     # the record read of the round after the last one
     return L
 
 
 def main():
     out = sys.stdout
     out.write("// GENERATED by tools/gen_team2_asm.py -- do not edit; see that script for the design.\n")
-    out.write("// Staging VGPRs v%d..v%d are fixed and must be in the clobber list of the statement.\n" % (VBASE, VBASE + 21))
-    out.write("#define CRP_TEAM2_VCLOBBERS %s\n" % ", ".join('"v%d"' % r for r in range(VBASE, VBASE + 22)))
+    out.write("// Fixed registers v%d..v%d and s%d..s%d (and m0) must be in the clobber list of the statement.\n"
+              % (VBASE, VBASE + NVREG - 1, SBASE, SBASE + NSREG - 1))
+    out.write("#define CRP_TEAM2_CLOBBERS %s, %s\n" % (", ".join('"v%d"' % r for r in range(VBASE, VBASE + NVREG)),
+                                                      ", ".join('"s%d"' % r for r in range(SBASE, SBASE + NSREG))))
     for nv in (1, 2):
-        out.write("#define CRP_TEAM2_CONSUME_NV%d \\\n" % nv)
-        lines = gen(nv)
-        for k, l in enumerate(lines):
-            sep = "\\n\\t" if not l.endswith(":") else "\\n"
-            last = k == len(lines) - 1
-            out.write('    "%s%s"%s\n' % (l, "" if last else sep, "" if last else " \\"))
-        out.write("\n")
+        for hb in (0, 1):
+            out.write("#define CRP_TEAM2_LOOP_NV%d_B%d \\\n" % (nv, hb))
+            lines = gen(nv, bool(hb))
+            for k, l in enumerate(lines):
+                sep = "\\n\\t" if not l.endswith(":") else "\\n"
+                last = k == len(lines) - 1
+                out.write('    "%s%s"%s\n' % (l, "" if last else sep, "" if last else " \\"))
+            out.write("\n")
 
 
 if __name__ == "__main__":
