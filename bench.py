@@ -4,24 +4,27 @@
 One "step" = one C := A * B of the hot path (rp_spmm_exec / para2d_spmm_exec,
 /root/reference/src/rowpara_spmm.c:212-422) with A, B and C resident in HBM.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--n 256] [--matrix pwtk]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--n 256] [--matrix pwtk | --mtx FILE]
 
-N = 1 : BASELINE configs[1] -- pwtk (seeded stand-in, gen.banded_fem(217918): no
-        SuiteSparse files and no network in the containers) x n = 256, fp64,
-        1 MI355X, rp_spmm HIP kernel.
-N > 1 : the same matrix and n, 2D grid chosen by the planner for an A that is
-        multiplied (steps + warmup) times -- crp_spmm_part2d_amortized, the
-        reference's cost terms with its "rA = times A is reused" applied
-        consistently (--grid reference: the reference rule with rA = 1) --, one
-        rank per GPU over torch.distributed (control plane gloo, B exchange
-        nccl == RCCL); strong scaling (total work fixed).
+N = 1 : BASELINE configs[1] -- pwtk x n = 256, fp64, 1 MI355X, rp_spmm HIP kernel.  The matrix is the real
+        pwtk.mtx when --mtx names it or $CRPSPMM_MTX_DIR holds it (read through the library's own Matrix-Market
+        ingest, examples/mmio_utils.c:11-190 restated in csrc/mmio_utils.cpp); otherwise -- no SuiteSparse files
+        and no network in the containers -- the seeded stand-in gen.banded_fem(217918), and the JSON says so.
+        The default run also times the IRREGULAR pwtk-class stand-in (gen.shell_fem: jittered shell mesh, 6
+        unknowns per node) with the same protocol and reports it under config.also (--no-also skips it).
+N > 1 : the same matrix and n, 2D grid chosen by the planner for an A that is multiplied (steps + warmup)
+        times -- crp_spmm_part2d_amortized, the reference's cost terms with its "rA = times A is reused"
+        applied consistently (--grid reference: the reference rule with rA = 1) --, one rank per GPU over
+        torch.distributed (control plane gloo, device payloads over RCCL); strong scaling (total work fixed).
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -31,70 +34,109 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
 
+# kernel symbol behind every variant name (what rocprofv3 --kernel-trace shows for it)
+KERNEL_SYMBOL = {"csr-rowgroup": "crp::spmm_rm_f64_kernel<LPR,VW,NV>", "rowpanel-R4": "crp::spmm_panel_f64_kernel<4,...>",
+                 "rowpanel-R8": "crp::spmm_panel_f64_kernel<8,...>", "team-R8": "crp::spmm_team_f64_kernel",
+                 "team2-R8": "crp::spmm_team2_f64_kernel<NV,HAS_B1>"}
 
-def build_matrix(name):
+
+def find_mtx(args):
+    """--mtx FILE, else $CRPSPMM_MTX_DIR/{pwtk.mtx,pwtk/pwtk.mtx} for --matrix pwtk; None when there is no file."""
+    if args.mtx:
+        return args.mtx
+    d = os.environ.get("CRPSPMM_MTX_DIR")
+    if d and args.matrix == "pwtk":
+        for cand in (os.path.join(d, "pwtk.mtx"), os.path.join(d, "pwtk", "pwtk.mtx")):
+            if os.path.exists(cand):
+                return cand
+    return None
+
+
+def build_matrix(name, mtx=None):
+    """-> (label, data, m, k, rowptr, colidx, val); data = "real" for a Matrix-Market file, else "synthetic"."""
     from crp_spmm_amd import gen
+    if mtx is not None:
+        from crp_spmm_amd import mmio
+        t0 = time.time()
+        m, k, rp, ci, va = mmio.read_mtx_csr(mtx, verbose=False)
+        dt = time.time() - t0
+        rows = np.repeat(np.arange(m, dtype=np.int64), np.diff(rp))
+        bw = int(np.abs(ci.astype(np.int64) - rows).max()) if ci.size else 0
+        # (the line examples/test_utils.c:43-47 prints)
+        print("A size = %d * %d, nnz = %d, nnz/row = %d, bandwidth = %d" % (m, k, rp[-1], rp[-1] // max(m, 1), bw), file=sys.stderr)
+        return ("%s (Matrix-Market file, ingest %.2f s, bandwidth %d)" % (os.path.basename(mtx), dt, bw), "real", m, k, rp, ci, va)
     if name == "pwtk":
         rp, ci, va = gen.banded_fem(217918)
-        return "pwtk-standin banded_fem(217918, seed 20261004)", 217918, 217918, rp, ci, va
+        return "pwtk stand-in banded_fem(217918, seed 20261004)", "synthetic", 217918, 217918, rp, ci, va
     if name == "pwtk_shell":
         # irregular pwtk-class stand-in: jittered shell mesh, 6 unknowns per node, far seam band (gen.shell_fem)
         rp, ci, va = gen.shell_fem()
-        return "pwtk-class shell_fem(160 x 227 nodes x 6 dof, jittered; seed 20261005)", 217918, 217918, rp, ci, va
-    if name == "pwtk_shell_rcm":
-        # diagnostic: the same matrix with its rows permuted on the host by reverse Cuthill-McKee on the graph of
-        # row groups with identical column sets (what the locality reordering at create does on the device side)
-        import scipy.sparse as sp
-        from scipy.sparse.csgraph import reverse_cuthill_mckee
-        rp, ci, va = gen.shell_fem()
-        m = len(rp) - 1
-        rows = np.repeat(np.arange(m), np.diff(rp))
-        h = np.zeros(m, dtype=np.uint64)
-        np.add.at(h, rows, ci.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15))
-        new = np.ones(m, dtype=bool)
-        new[1:] = (h[1:] != h[:-1]) | (np.diff(rp)[1:] != np.diff(rp)[:-1])
-        sn = np.cumsum(new) - 1
-        ns = int(sn[-1]) + 1
-        S = sp.csr_matrix((np.ones(m), (np.arange(m), sn)), shape=(m, ns))
-        A = sp.csr_matrix((np.ones(len(ci), dtype=np.int8), ci, rp), shape=(m, m))
-        Q = (S.T @ A @ S)
-        Q = ((Q + Q.T) != 0).astype(np.int8).tocsr()
-        perm = np.asarray(reverse_cuthill_mckee(Q, symmetric_mode=True))
-        order = np.argsort(np.argsort(perm)[sn], kind="stable")          # rows grouped by supernode in perm order
-        Ap = sp.csr_matrix((va, ci, rp), shape=(m, m))[order]
-        Ap.sort_indices()
-        return "pwtk-class shell_fem, rows RCM-ordered on the host (diagnostic)", m, m, Ap.indptr.astype(np.int32), Ap.indices.astype(np.int32), Ap.data
+        return "pwtk-class stand-in shell_fem(160 x 227 nodes x 6 dof, jittered; seed 20261005)", "synthetic", 217918, 217918, rp, ci, va
     if name == "pwtk_l2":
         # diagnostic only: same row structure, every column folded into the first 1024 rows of B
         # (2 MiB at n = 256) so that B is always L2-resident
         rp, ci, va = gen.banded_fem(217918)
-        return "pwtk-standin with columns mod 1024 (L2-resident B; diagnostic)", 217918, 217918, rp, (ci % 1024).astype(np.int32), va
+        return "pwtk stand-in with columns mod 1024 (L2-resident B; diagnostic)", "synthetic", 217918, 217918, rp, (ci % 1024).astype(np.int32), va
     if name == "small":
         rp, ci, va = gen.banded_fem(20000, offsets=(1, 2, 3, 4, 5, 6, 100, 101, 3000))
-        return "banded_fem(20000) smoke-size", 20000, 20000, rp, ci, va
-    # stand-ins for the other BASELINE configs at sizes one GPU builds in seconds (parity / side numbers only;
-    # the bench line of record is pwtk n=256)
+        return "banded_fem(20000) smoke-size", "synthetic", 20000, 20000, rp, ci, va
+    # stand-ins for the other BASELINE configs (parity / side numbers; the bench line of record is pwtk n=256)
     if name == "kkt":
         rp, ci, va = gen.kkt3d(96)
         m = len(rp) - 1
-        return "nlpkkt-standin kkt3d(96)", m, m, rp, ci, va
+        return "nlpkkt stand-in kkt3d(96)", "synthetic", m, m, rp, ci, va
+    if name == "kkt240":
+        rp, ci, va = kkt240_cached()
+        m = len(rp) - 1
+        return "nlpkkt240-size stand-in kkt3d(241): %d rows" % m, "synthetic", m, m, rp, ci, va
     if name == "fem3d":
         rp, ci, va = gen.fem3d(56)
         m = len(rp) - 1
-        return "Queen-standin fem3d(56, dof 3)", m, m, rp, ci, va
+        return "Queen stand-in fem3d(56, dof 3)", "synthetic", m, m, rp, ci, va
     if name == "er":
         rp, ci, va = gen.erdos_renyi(1 << 20, 1 << 20, 32, seed=1)
-        return "Erdos-Renyi 2^20 x 2^20, 32 nnz/row", 1 << 20, 1 << 20, rp, ci, va
+        return "Erdos-Renyi 2^20 x 2^20, 32 nnz/row", "synthetic", 1 << 20, 1 << 20, rp, ci, va
     raise SystemExit("unknown --matrix %s" % name)
 
 
+def kkt240_cached():
+    """nlpkkt240-size stand-in (kkt3d(241): 27,995,042 rows) through the library's binary CSR cache: generated once
+    per box (minutes of numpy), afterwards read back in seconds."""
+    from crp_spmm_amd import gen, mmio
+    path = os.path.join(os.environ.get("CRPSPMM_CACHE_DIR", tempfile.gettempdir()), "crpspmm_kkt3d_241.csrbin")
+    got = mmio.csr_cache_read(path)
+    if got is not None:
+        return got[2], got[3], got[4]
+    rp, ci, va = gen.kkt3d(241)
+    m = len(rp) - 1
+    mmio.csr_cache_write(path, m, m, rp, ci, va)
+    return rp, ci, va
+
+
 def cpu_baseline(rp, ci, va, k, n, budget_s=12.0):
-    """The oracle's OpenMP restatement (kind 'port') timed on this box's host cores."""
+    """The reference's CPU path on this box's host cores: mkl_sparse_d_create_csr + mkl_sparse_d_mm +
+    mkl_sparse_destroy PER CALL, as /root/reference/src/rowpara_spmm.c:398-408 does (kind "mkl"; run in a fresh
+    process with MKL_THREADING_LAYER=GNU and all cores, oracle/mkl_baseline.py).  When libmkl_rt does not load:
+    the oracle's OpenMP restatement (kind "port")."""
+    cores = os.cpu_count() or 1
+    m = len(rp) - 1
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "a.npz")
+        np.savez(path, rp=rp, ci=ci, va=va, k=k, n=n)
+        env = dict(os.environ, MKL_THREADING_LAYER="GNU", OMP_NUM_THREADS=str(cores), MKL_NUM_THREADS=str(cores),
+                   OMP_PLACES="cores", OMP_PROC_BIND="close")
+        try:
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "mkl_baseline.py"), path, str(budget_s)],
+                               capture_output=True, text=True, env=env, timeout=240)
+            if r.returncode == 0 and r.stdout.strip():
+                res = json.loads(r.stdout.strip().splitlines()[-1])
+                res["cores"] = cores
+                return res
+        except Exception:
+            pass
     import oracle
     oracle.lib()
     B = oracle.fill_B(0, k, 0, n)
-    m = len(rp) - 1
-    cores = os.cpu_count() or 1
     os.environ["OMP_NUM_THREADS"] = str(cores)
     oracle.spmm_csr(rp, ci, va, B, fast=True)            # warm-up
     reps, t0 = 0, time.time()
@@ -109,58 +151,25 @@ def cpu_baseline(rp, ci, va, k, n, budget_s=12.0):
                       % (m, len(ci), n, reps, dt)}
 
 
-def measured_traffic(args, world):
-    """HBM bytes per launch from the committed rocprofv3 PMC pass (profiles/r01_traffic.json:
-    2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction applied) -- only for the configuration it was
-    measured on; null otherwise."""
+def measured_traffic(matrix, data, n, world, kernel_name):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r02_traffic.json: 2 x FETCH_SIZE +
+    WRITE_SIZE, gfx950 correction applied; tools/prof_pmc.sh) -- a pointer to that run, not a measurement of this one:
+    returned only for the configuration and kernel it was taken on, with its source; (None, None) otherwise."""
     try:
-        if world != 1 or args.matrix != "pwtk" or args.n != 256 or args.variant != 0:
-            return None
-        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
-            return json.load(f)["traffic_bytes_per_launch"] / 1e9 * 1e9
+        with open(os.path.join(ROOT, "profiles", "r02_traffic.json")) as f:
+            t = json.load(f)
+        for e in t["entries"]:
+            if world == 1 and data == "synthetic" and e["matrix"] == matrix and e["n"] == n and e["kernel"] == kernel_name:
+                return float(e["traffic_bytes_per_launch"]), "profiles/r02_traffic.json: %s" % e["source"]
     except Exception:
-        return None
+        pass
+    return None, None
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--n", type=int, default=256)
-    ap.add_argument("--matrix", default="pwtk")
-    ap.add_argument("--variant", type=int, default=0)
-    ap.add_argument("--grid", default="amortized", choices=("amortized", "reference"),
-                    help="N > 1: planner rule for the process grid (see module docstring)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--check", type=int, default=1)
-    ap.add_argument("--sweep-variants", action="store_true", help="also time kernel variants 1..3 (stderr)")
-    args = ap.parse_args()
-
-    import torch
-    import torch.distributed as dist
-    import crp_spmm_amd
-    from crp_spmm_amd import comm as crp_comm, engine, planner
-    lib = crp_spmm_amd.load()            # fails loudly when the HIP library is missing
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node N)"
-                         % (args.gpus, world))
-    torch.cuda.set_device(local_rank % torch.cuda.device_count())
-    dev = torch.device("cuda", torch.cuda.current_device())
+def measure(args, matrix, mtx, steps, lib, torch, dist, comm, dev, world, rank, with_cpu):
+    from crp_spmm_amd import engine, planner
     distributed = world > 1
-    if distributed:
-        crp_comm.init_process_group(device=dev.index)
-        comm = crp_comm.TorchComm()
-    else:
-        comm = crp_comm.SelfComm()
-
-    label, m, k, rp, ci, va = build_matrix(args.matrix)
+    label, data, m, k, rp, ci, va = build_matrix(matrix, mtx)
     n, nnz = args.n, int(rp[-1])
     flops = 2.0 * nnz * n
 
@@ -170,7 +179,7 @@ def main():
         if args.grid == "reference":
             pl = planner.calc_spmm_part2d_from_1d(world, m, n, k, rb, rp, ci, rA=1)
         else:
-            pl = planner.spmm_part2d_amortized(world, m, n, k, rb, rp, ci, max(1, args.steps + args.warmup))
+            pl = planner.spmm_part2d_amortized(world, m, n, k, rb, rp, ci, max(1, steps + args.warmup))
         pm, pn = pl["pm"], pl["pn"]
         a0, br, ac, bc = pl["A0_rowptr"], pl["B_rowptr"], pl["AC_rowptr"], pl["BC_colptr"]
         s, e_ = int(a0[rank]), int(a0[rank + 1])
@@ -192,26 +201,41 @@ def main():
     ii = torch.arange(b_r0, b_r1, dtype=torch.float64, device=dev)[:, None]
     jj = torch.arange(col0, col1, dtype=torch.float64, device=dev)[None, :]
     B = (ii * 0.19 + jj * 0.24).contiguous()
+    del ii, jj
     Cmat = torch.empty((c_r1 - c_r0, n_loc), dtype=torch.float64, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
         eng.exec(0, B, Cmat, stream=stream)
 
+    t_first = time.perf_counter()
+    step()                                   # (builds the kernel's formats on first use)
+    torch.cuda.synchronize()
+    t_first = time.perf_counter() - t_first
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
 
-    # ---- correctness guard on the local block (closed form for fill_B); not timed
+    # ---- correctness guard on the local block (closed form for fill_B); not timed.  Above 2^28 result elements
+    #      only sampled rows are compared (the reference's own check gives up at 2^31: examples/test_utils.c:3-19)
+    err = None
     if args.check:
         rows = np.repeat(np.arange(m), np.diff(rp))
         s1 = np.bincount(rows, weights=va * ci, minlength=m)[c_r0:c_r1]
         s0 = np.bincount(rows, weights=va, minlength=m)[c_r0:c_r1]
-        expect = 0.19 * s1[:, None] + 0.24 * np.arange(col0, col1)[None, :] * s0[:, None]
+        del rows
         step()
         torch.cuda.synchronize()
-        got = Cmat.cpu().numpy()
-        err = np.linalg.norm(got - expect) / max(np.linalg.norm(expect), 1e-300)
+        if (c_r1 - c_r0) * n_loc <= (1 << 28):
+            sel = np.arange(c_r1 - c_r0)
+            got = Cmat.cpu().numpy()
+        else:
+            sel = np.unique(np.concatenate([np.arange(0, c_r1 - c_r0, 1009), np.arange(min(4096, c_r1 - c_r0)),
+                                            np.arange(max(0, c_r1 - c_r0 - 4096), c_r1 - c_r0)]))
+            got = Cmat[torch.from_numpy(sel).to(dev)].cpu().numpy()
+        expect = 0.19 * s1[sel, None] + 0.24 * np.arange(col0, col1)[None, :] * s0[sel, None]
+        err = float(np.linalg.norm(got - expect) / max(np.linalg.norm(expect), 1e-300))
+        del got, expect
         if not err <= 1e-12:
             raise SystemExit("rank %d: result check failed, rel. Frobenius error %.3e" % (rank, err))
 
@@ -246,7 +270,7 @@ def main():
             torch.cuda.synchronize()
 
     # ---- timed region: K steps between barrier + synchronize; HIP events per step on the launch stream
-    ev = [(C.c_void_p(), C.c_void_p()) for _ in range(args.steps)]
+    ev = [(C.c_void_p(), C.c_void_p()) for _ in range(steps)]
     for a, b in ev:
         lib.crp_event_create(C.byref(a))
         lib.crp_event_create(C.byref(b))
@@ -275,31 +299,105 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
 
-    ms_per_step = elapsed / args.steps * 1e3
-    value = flops * args.steps / elapsed / 1e9
+    ms_per_step = elapsed / steps * 1e3
     kern_ms = float(np.mean(per_step))
     alg_bytes = rp_eng.alg_bytes()            # this rank's compulsory bytes per launch (DESIGN.md "bytes per unit")
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-    out = {
-        "metric": "SpMM GFLOP/s (pwtk n=%d, fp64)" % n if args.matrix == "pwtk" else "SpMM GFLOP/s (%s n=%d)" % (args.matrix, n),
-        "value": value, "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "%s x n=%d, rp_spmm/para2d_spmm exec, operands resident in HBM" % (label, n),
-                   "rows": m, "nnz": nnz, "n": n, "grid": "%dx%d" % (pm, pn), "kernel_variant": args.variant,
-                   "achieved_hbm_GBs_alg": alg_bytes * (world if distributed else 1) / (ms_per_step * 1e-3) / 1e9
-                   if not distributed else None},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args, world),
-                     "kernel": "spmm_rm_f64 (rank 0 launch: %d algorithmic bytes, %.4f ms avg by HIP events)"
-                               % (alg_bytes, kern_ms)},
+    ki = rp_eng.kernel_info()
+    kname = KERNEL_SYMBOL.get(ki["variant_name"], str(ki["variant_name"]))
+    traffic, tsrc = measured_traffic(matrix, data, n, world, ki["variant_name"])
+    res = {
+        "label": label, "data": data, "rows": m, "nnz": nnz, "n": n, "grid": "%dx%d" % (pm, pn),
+        "value": flops * steps / elapsed / 1e9, "ms_per_step": ms_per_step, "kern_ms": kern_ms, "alg_bytes": alg_bytes,
+        "achieved": achieved, "kernel_info": ki, "kernel": kname, "traffic": traffic, "traffic_source": tsrc,
+        "first_exec_s": t_first, "check_rel_err": err,
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(rp, ci, va, k, n)
+    if with_cpu:
+        res["cpu_baseline"] = cpu_baseline(rp, ci, va, k, n)
+    eng.free()
+    del B, Cmat
+    torch.cuda.empty_cache()
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--n", type=int, default=256)
+    ap.add_argument("--matrix", default="pwtk")
+    ap.add_argument("--mtx", default=None, help="Matrix-Market file to multiply instead of a generated matrix")
+    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--grid", default="amortized", choices=("amortized", "reference"),
+                    help="N > 1: planner rule for the process grid (see module docstring)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the irregular pwtk-class stand-in of the default run")
+    ap.add_argument("--check", type=int, default=1)
+    ap.add_argument("--sweep-variants", action="store_true", help="also time the other kernel variants (stderr)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import crp_spmm_amd
+    from crp_spmm_amd import comm as crp_comm
+    lib = crp_spmm_amd.load()            # fails loudly when the HIP library is missing
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node N)"
+                         % (args.gpus, world))
+    torch.cuda.set_device(local_rank % torch.cuda.device_count())
+    dev = torch.device("cuda", torch.cuda.current_device())
+    distributed = world > 1
+    rccl_ranks = None
+    if distributed:
+        crp_comm.init_process_group(device=dev.index)
+        comm = crp_comm.TorchComm()
+        rccl_ranks = getattr(comm, "device_ranks", lambda: None)()
+    else:
+        comm = crp_comm.SelfComm()
+
+    mtx = find_mtx(args)
+    main_res = measure(args, args.matrix, mtx, args.steps, lib, torch, dist, comm, dev, world, rank,
+                       with_cpu=(rank == 0 and world == 1 and not args.no_cpu_baseline))
+    also = None
+    if world == 1 and mtx is None and args.matrix == "pwtk" and args.variant == 0 and not args.no_also:
+        r2 = measure(args, "pwtk_shell", None, min(args.steps, 100), lib, torch, dist, comm, dev, world, rank, with_cpu=False)
+        also = {"workload": "%s x n=%d" % (r2["label"], r2["n"]), "nnz": r2["nnz"], "ms_per_step": r2["ms_per_step"],
+                "GFLOP/s": r2["value"], "kernel": r2["kernel"], "roofline_frac": r2["achieved"] / HBM_PEAK_GBS,
+                "kernel_ms": r2["kern_ms"], "alg_bytes": r2["alg_bytes"], "locality_order": r2["kernel_info"]["reordered"],
+                "lattice_detected": r2["kernel_info"]["lattice"], "traffic": r2["traffic"], "traffic_source": r2["traffic_source"]}
+
+    r = main_res
+    what = "pwtk" if (args.matrix == "pwtk" and r["data"] == "real") else \
+           ("pwtk stand-in" if args.matrix == "pwtk" else (os.path.basename(mtx) if mtx else args.matrix))
+    out = {
+        "metric": "SpMM GFLOP/s (%s n=%d, fp64)" % (what, r["n"]),
+        "value": r["value"], "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f64", "data": r["data"],
+        "config": {"workload": "%s x n=%d, rp_spmm/para2d_spmm exec, operands resident in HBM" % (r["label"], r["n"]),
+                   "rows": r["rows"], "nnz": r["nnz"], "n": r["n"], "grid": r["grid"], "kernel_variant": args.variant,
+                   "kernel_variant_resolved": r["kernel_info"]["variant_name"],
+                   "locality_order": r["kernel_info"]["reordered"], "lattice_detected": r["kernel_info"]["lattice"],
+                   "rccl_ranks": rccl_ranks, "first_exec_s": r["first_exec_s"], "check_rel_err": r["check_rel_err"],
+                   "achieved_hbm_GBs_alg": r["alg_bytes"] / (r["ms_per_step"] * 1e-3) / 1e9 if not distributed else None,
+                   "also": also},
+        "roofline": {"bound": "hbm", "achieved": r["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": r["achieved"] / HBM_PEAK_GBS, "traffic": r["traffic"], "traffic_source": r["traffic_source"],
+                     "kernel": "%s (rank 0 launch: %d algorithmic bytes, %.4f ms avg by HIP events)"
+                               % (r["kernel"], r["alg_bytes"], r["kern_ms"])},
+    }
+    if "cpu_baseline" in r:
+        out["cpu_baseline"] = r["cpu_baseline"]
     if rank == 0:
         print(json.dumps(out))
         sys.stdout.flush()
-    eng.free()
     if distributed:
         dist.destroy_process_group()
 

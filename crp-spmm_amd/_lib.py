@@ -129,6 +129,8 @@ SIGNATURES = {
     "crp_csr_dev_bytes": (_LL, [_V]),
     "crp_csr_dev_auto_variant": (_I, [_V]),
     "crp_csr_dev_reordered": (_I, [_V]),
+    "crp_csr_dev_resolved_variant": (_I, [_V, _I]),
+    "crp_csr_dev_lattice": (_I, [_V]),
     "crp_panel_format_host": (_I, [_I, c_int_p, c_int_p, c_dbl_p, _I, c_int_p, C.POINTER(c_int_p), C.POINTER(c_int_p),
                                    C.POINTER(C.POINTER(C.c_uint)), C.POINTER(c_dbl_p), C.POINTER(_LL),
                                    C.POINTER(c_int_p), c_int_p]),
@@ -160,6 +162,7 @@ SIGNATURES = {
     "crp_rp_spmm_overlap_rows": (None, [_V, c_int_p, c_int_p]),
     "crp_rp_spmm_set_timing": (None, [_V, _I]),
     "crp_rp_spmm_set_variant": (None, [_V, _I]),
+    "crp_rp_spmm_kernel_info": (None, [_V, c_int_p, c_int_p, c_int_p]),
     "crp_rp_spmm_alg_bytes": (_LL, [_V]),
     "crp_rp_spmm_update_values": (None, [_V, c_dbl_p]),
     "crp_rp_spmm_nnz": (_LL, [_V]),

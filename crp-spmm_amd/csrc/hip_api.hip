@@ -634,6 +634,10 @@ int crp_spmm_csr_f64(crp_csr_dev_p A, int layout, int n, const double *B0, long 
     hipError_t e;
     if (layout == CRP_LAYOUT_COL_MAJOR) return (int) crp::spmm_cm_f64(a, (hipStream_t) stream);
     int v = (variant == 0) ? A->auto_variant : variant;
+    // auto: from 96 columns on the LDS-sharing team kernel replaces the row-panel kernels wherever those were
+    // chosen (measured on the pwtk, shell, kkt and fem3d stand-ins at n = 128 / 256 / 1024: 0.97 / 0.91 / 0.93,
+    // 0.83 / 0.73 / 0.68, 0.65 / 0.70 / 0.67, 0.87 / 0.93 / 0.88 of the row-panel time; at n = 32 it needs 1.7 x)
+    if (variant == 0 && v >= 2 && n >= 96 && A->nrow >= 64 && crp::spmm_team2_applicable(a)) v = 5;
     if (v == 5 && (!crp::spmm_team2_applicable(a) || A->nnz == 0 || A->nrow < 8)) v = 3;
     if (v >= 2 && A->rowmap_fmt != nullptr) a.rowmap = A->rowmap_fmt;      // derived formats hold the rows in processing order
     if (v == 5)
@@ -673,6 +677,15 @@ int crp_spmm_csr_f64(crp_csr_dev_p A, int layout, int n, const double *B0, long 
 
 int crp_csr_dev_auto_variant(crp_csr_dev_p A) { return A ? A->auto_variant : -1; }
 int crp_csr_dev_reordered(crp_csr_dev_p A) { return A ? (A->perm.empty() ? 0 : 1) : -1; }
+int crp_csr_dev_resolved_variant(crp_csr_dev_p A, int n)
+{
+    if (A == NULL) return -1;
+    int v = A->auto_variant;
+    if (v >= 2 && n < 24) v = 1;
+    if (v >= 2 && n >= 96 && A->nrow >= 64 && (n % 2 == 0)) v = 5;
+    return v;
+}
+int crp_csr_dev_lattice(crp_csr_dev_p A) { return A ? ((A->team2.built && A->team2.lattice) || (A->team.built && A->team.lattice) ? 1 : 0) : -1; }
 
 int crp_panel_format_host(int nrow, const int *rowptr, const int *colidx, const double *val, int R, int *npanel,
                           int **pptr, int **pcol, unsigned **pmask4, double **pval, long long *real_entries,

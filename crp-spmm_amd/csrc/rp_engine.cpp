@@ -592,6 +592,22 @@ long long crp_rp_spmm_alg_bytes(crp_rp_spmm_p e)
            8LL * e->glb_n * (long long) e->A_nrow;
 }
 
+// what the local kernel is for this engine's width: variant the auto choice resolves to (of the main device
+// matrix, or of the interior part when the rows are split), whether its formats hold the rows in locality
+// order, whether a stride lattice was found
+void crp_rp_spmm_kernel_info(crp_rp_spmm_p e, int *variant, int *reordered, int *lattice)
+{
+    if (variant) *variant = -1;
+    if (reordered) *reordered = 0;
+    if (lattice) *lattice = 0;
+    if (e == NULL) return;
+    crp_csr_dev_p A = e->A_dev ? e->A_dev : e->A_int;
+    if (A == NULL) return;
+    if (variant) *variant = e->variant != 0 ? e->variant : crp_csr_dev_resolved_variant(A, e->glb_n);
+    if (reordered) *reordered = crp_csr_dev_reordered(A);
+    if (lattice) *lattice = crp_csr_dev_lattice(A);
+}
+
 const int *crp_rp_spmm_dev_colidx_host(crp_rp_spmm_p e) { return e ? e->dev_colidx_host.data() : NULL; }
 
 // ---------------------------------------------------------------------------

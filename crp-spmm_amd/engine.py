@@ -106,6 +106,13 @@ class RpSpmm:
     def set_timing(self, on):
         self._lib.crp_rp_spmm_set_timing(self.handle, int(bool(on)))
 
+    def kernel_info(self):
+        """-> dict(variant, variant_name, reordered, lattice) of the local SpMM (crp_rp_spmm_kernel_info)."""
+        v, ro, la = C.c_int(), C.c_int(), C.c_int()
+        self._lib.crp_rp_spmm_kernel_info(self.handle, C.byref(v), C.byref(ro), C.byref(la))
+        name = self._lib.crp_spmm_variant_name(v.value)
+        return dict(variant=v.value, variant_name=name.decode() if name else None, reordered=bool(ro.value), lattice=bool(la.value))
+
     def set_variant(self, variant):
         self._lib.crp_rp_spmm_set_variant(self.handle, int(variant))
 

@@ -101,6 +101,10 @@ void crp_rp_spmm_set_variant(crp_rp_spmm_p rp_spmm, int variant);
  * this rank): 12*nnz + 4*(A_nrow+1) + 8*n*(distinct B rows) + 8*n*A_nrow. */
 long long crp_rp_spmm_alg_bytes(crp_rp_spmm_p rp_spmm);
 long long crp_rp_spmm_nnz(crp_rp_spmm_p rp_spmm);
+/* What the local SpMM of this engine is (for reports): the kernel variant in use (crp_spmm_variant_name; the auto
+ * choice resolved for the engine's glb_n), 1 if its formats hold the rows in the locality order of
+ * csrc/locality.cpp, 1 if a stride lattice was found.  Any pointer may be NULL. */
+void crp_rp_spmm_kernel_info(crp_rp_spmm_p rp_spmm, int *variant, int *reordered, int *lattice);
 /* New values for the same sparsity pattern, in the order of the A_val given to init (the
  * deprecated crpspmm_engine passes A's values on every exec: deprecated/src/crpspmm.h:108-117). */
 void crp_rp_spmm_update_values(crp_rp_spmm_p rp_spmm, const double *A_val);

@@ -105,6 +105,13 @@ int crp_csr_dev_auto_variant(crp_csr_dev_p A);
  * CRPSPMM_REORDER=0|1 overrides).  Results do not depend on it: C rows are written through a row map and
  * every row's products are still summed in the kernel variant's own order. */
 int crp_csr_dev_reordered(crp_csr_dev_p A);
+/* the variant `variant = 0` (auto) runs for a row-major product of n columns with aligned, even operands: the
+ * create-time choice (crp_csr_dev_auto_variant), replaced by 5 (team2-R8) from 96 columns on when that choice is a
+ * row-panel kernel, and by 1 below 24 columns. */
+int crp_csr_dev_resolved_variant(crp_csr_dev_p A, int n);
+/* 1 when the team formats built so far found the two nested strides of a mesh numbered along its lines (their
+ * teams are then blocks of neighbouring mesh lines), 0 otherwise / not built yet. */
+int crp_csr_dev_lattice(crp_csr_dev_p A);
 /* Host-only: build the row-panel format the rowpanel kernels consume (R = 4 or 8)
  * and return malloc'd copies (caller frees).  Panel p owns entries pptr[p] .. pptr[p+1]
  * (padded to multiples of 8 with mask-0 entries); entry q has column pcol[q] (two-source
