@@ -40,6 +40,8 @@ class CrpComm(C.Structure):
     pass
 
 
+AGV_DEV_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t),
+                         C.c_void_p)
 SPLIT_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int, C.c_int)   # returns crp_comm_t*
 FREE_FN = C.CFUNCTYPE(None, C.POINTER(CrpComm))
 CrpComm._fields_ = [
@@ -47,6 +49,7 @@ CrpComm._fields_ = [
     ("alltoall_i32", A2A_FN), ("alltoallv_i32", A2AV_FN), ("allgatherv_bytes", AGV_FN),
     ("barrier", BARRIER_FN), ("reduce_f64", RED_F64_FN), ("reduce_u64", RED_U64_FN),
     ("alltoallv_dev_f64", A2AV_DEV_FN), ("alltoallv_bytes", A2AV_BYTES_FN), ("split", SPLIT_FN), ("free", FREE_FN),
+    ("allgatherv_dev", AGV_DEV_FN),
 ]
 
 
@@ -94,7 +97,8 @@ _LL = C.c_longlong
 
 # name -> (restype, argtypes); every symbol declared in include/crpspmm_hip.h,
 # include/crp_comm.h, include/crp_engine.h, include/utils.h, include/spmat_part.h,
-# include/mmio_utils.h.  tests/test_abi.py checks this table against the headers.
+# include/mmio_utils.h, include/crp_rccl.h.  tests/test_host.py (the ABI test there) checks that the library
+# exports every function the headers declare.
 SIGNATURES = {
     # crpspmm_hip.h
     "crp_hip_version": (C.c_char_p, []),
@@ -161,6 +165,19 @@ SIGNATURES = {
     "crp_rp_spmm_get_plan": (None, [_V, C.POINTER(RpPlanView)]),
     "crp_rp_spmm_overlap_rows": (None, [_V, c_int_p, c_int_p]),
     "crp_rp_spmm_set_timing": (None, [_V, _I]),
+    # crp_rccl.h
+    "crp_rccl_get_unique_id": (_I, [_V]),
+    "crp_rccl_create": (_I, [_V, _I, _I, C.POINTER(_V)]),
+    "crp_rccl_destroy": (_I, [C.POINTER(_V)]),
+    "crp_rccl_nranks": (_I, [_V]),
+    "crp_rccl_rank": (_I, [_V]),
+    "crp_rccl_alltoallv_f64": (_I, [_V, _V, c_ll_p, c_ll_p, _V, c_ll_p, c_ll_p, _V]),
+    "crp_rccl_allgatherv": (_I, [_V, _V, C.c_size_t, _V, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), _V]),
+    "crp_rccl_alltoallv_bytes": (_I, [_V, _V, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), _V, C.POINTER(C.c_size_t),
+                                      C.POINTER(C.c_size_t), _V]),
+    "crp_rccl_comm_alltoallv_dev_f64": (None, [_V, _V, c_ll_p, c_ll_p, _V, c_ll_p, c_ll_p, _V]),
+    "crp_rccl_comm_allgatherv_dev": (None, [_V, _V, C.c_size_t, _V, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), _V]),
+    "crp_para2d_spmm_replicated_on_device": (_I, [_V]),
     "crp_rp_spmm_set_variant": (None, [_V, _I]),
     "crp_rp_spmm_kernel_info": (None, [_V, c_int_p, c_int_p, c_int_p]),
     "crp_rp_spmm_alg_bytes": (_LL, [_V]),
@@ -242,6 +259,14 @@ def load():
         raise CrpLibraryError(
             "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C crp-spmm_amd/csrc`). There is no CPU fallback." % LIB_PATH)
+    # torch ships its own copies of the ROCm runtime libraries (torch/lib/libamdhip64.so, librccl.so, ...).  Whoever
+    # is loaded first decides which copy the process uses; when this library came first and torch second, the process
+    # ended up with two HIP runtimes and aborted in their exit handlers ("free(): invalid pointer").  torch is this
+    # package's plumbing anyway (device memory, streams, process groups), so it goes first.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     try:
         lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
     except OSError as e:  # e.g. libamdhip64 missing

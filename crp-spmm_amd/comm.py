@@ -4,13 +4,20 @@ from Python.
 ``TorchComm`` maps the table onto ``torch.distributed``: host control-plane
 collectives (the MPI_Alltoall / Alltoallv / Allgatherv / Reduce calls of
 /root/reference/src/rowpara_spmm.c:154-162,439-442 and src/para2d_spmm.c:41-83)
-run on CPU tensors (gloo), the per-multiply B exchange
-(src/rowpara_spmm.c:275-309) runs on device tensors over the ``nccl`` backend,
-which is RCCL over xGMI on MI355X.  Initialise the default group with
-``backend="cpu:gloo,cuda:nccl"`` (``init_process_group`` below does).
+run on CPU tensors (gloo).  Device payloads -- the per-multiply B exchange
+(src/rowpara_spmm.c:275-309) and the replication of an A row panel
+(src/para2d_spmm.c:56-86) -- do not pass through Python at all when every rank
+has a GPU of its own: the communicator then carries a native RCCL handle
+(include/crp_rccl.h, unique id broadcast over gloo) and its device members point
+at the library's own functions.  The Python implementations of the device
+members below serve the CPU tests (gloo on host buffers) and the "host"
+rehearsal mode (several ranks on one GPU: device -> host -> gloo -> device).
 """
 import ctypes as C
+import functools
 import os
+import sys
+import traceback
 
 import numpy as np
 import torch
@@ -52,20 +59,28 @@ def init_process_group(device=None):
         dist.init_process_group(backend="gloo")
 
 
+def _fatal_on_error(fn):
+    """ctypes swallows an exception raised inside a callback ("Exception ignored on calling ctypes callback") and
+    the C caller carries on with whatever its buffers held: a failed collective would become a silently wrong
+    product.  Every callback of the communicator table is wrapped with this: print, then abort the process."""
+    @functools.wraps(fn)
+    def wrapper(*a, **k):
+        try:
+            return fn(*a, **k)
+        except BaseException:          # noqa: B902 -- nothing may escape into ctypes
+            traceback.print_exc()
+            sys.stderr.write("[FATAL] communicator callback %s failed: aborting\n" % fn.__name__)
+            sys.stderr.flush()
+            os.abort()
+    return wrapper
+
+
 def _np_from_ptr(ptr, count, dtype):
     if count == 0:
         return np.zeros(0, dtype=dtype)
     ctype = {np.int32: C.c_int, np.float64: C.c_double, np.int64: C.c_longlong, np.uint64: C.c_uint64,
              np.uint8: C.c_ubyte}[dtype]
     return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=(count,))
-
-
-class _CudaView:
-    """Expose a raw device pointer to torch through __cuda_array_interface__."""
-
-    def __init__(self, ptr, nelem):
-        self.__cuda_array_interface__ = {"shape": (nelem,), "typestr": "<f8", "data": (int(ptr), False),
-                                         "version": 2, "strides": None}
 
 
 class TorchComm:
@@ -89,11 +104,59 @@ class TorchComm:
                      L.SPLIT_FN(self._split), L.FREE_FN(self._free))
         (s.alltoall_i32, s.alltoallv_i32, s.allgatherv_bytes, s.barrier, s.reduce_f64, s.reduce_u64,
          s.alltoallv_dev_f64, s.alltoallv_bytes, s.split, s.free) = self._cbs
+        # device payloads: a native RCCL communicator (include/crp_rccl.h) when every rank has a GPU of its own --
+        # the engines then call straight into the library for the per-multiply B exchange and the replication of A,
+        # no Python in the hot loop.  Its unique id travels over this group's gloo side.
+        self._rccl = None
+        if torch.cuda.is_available() and exchange_mode() == "nccl":
+            lib = L.load()
+            idbuf = torch.zeros(128, dtype=torch.uint8)
+            if self.rank == 0:
+                raw = (C.c_ubyte * 128)()
+                L.check(lib.crp_rccl_get_unique_id(raw), "crp_rccl_get_unique_id")
+                idbuf = torch.tensor(list(raw), dtype=torch.uint8)
+            dist.broadcast(idbuf, src=self._glb_ranks[0], group=self.group)
+            raw = (C.c_ubyte * 128)(*[int(v) for v in idbuf])
+            h = C.c_void_p()
+            L.check(lib.crp_rccl_create(raw, self.nproc, self.rank, C.byref(h)), "crp_rccl_create")
+            self._rccl = h
+            s.ctx = h
+            s.alltoallv_dev_f64 = C.cast(lib.crp_rccl_comm_alltoallv_dev_f64, L.A2AV_DEV_FN)
+            s.allgatherv_dev = C.cast(lib.crp_rccl_comm_allgatherv_dev, L.AGV_DEV_FN)
+        elif torch.cuda.is_available():
+            # rehearsal mode (several ranks on one GPU): the device all-gather staged through the host, so that the
+            # engines' device-replication branch runs on a 1-GPU box as well
+            self._agv_dev_cb = L.AGV_DEV_FN(self._allgatherv_dev_staged)
+            s.allgatherv_dev = self._agv_dev_cb
         self.struct = s
         self.ptr = C.pointer(s)
         _live[C.addressof(s)] = self
 
+    @_fatal_on_error
+    def _allgatherv_dev_staged(self, ctx, send, sbytes, recv, rbytes, rdispls, stream):
+        P = self.nproc
+        lib = L.load()
+        rb = [int(rbytes[i]) for i in range(P)]
+        rd = [int(rdispls[i]) for i in range(P)]
+        mine = np.zeros(max(sbytes, 1), dtype=np.uint8)
+        if sbytes:
+            L.check(lib.crp_dev_memcpy(mine.ctypes.data, send, sbytes, 1, stream), "staged all-gather: device -> host")
+        L.check(lib.crp_stream_sync(stream), "stream sync")
+        tot = max((rd[i] + rb[i] for i in range(P)), default=0)
+        out = np.zeros(max(tot, 1), dtype=np.uint8)
+        szt = C.c_size_t * P
+        self._allgatherv_bytes(None, mine.ctypes.data, sbytes, out.ctypes.data, szt(*rb), szt(*rd))
+        for i in range(P):
+            if rb[i]:
+                L.check(lib.crp_dev_memcpy(int(recv) + rd[i], out[rd[i]:].ctypes.data, rb[i], 0, stream), "staged all-gather: host -> device")
+        L.check(lib.crp_stream_sync(stream), "stream sync")
+
+    def device_ranks(self):
+        """Ranks of the native RCCL communicator behind the device collectives, or None (host-staged / CPU)."""
+        return int(L.load().crp_rccl_nranks(self._rccl)) if self._rccl else None
+
     # ---- host control plane ---------------------------------------------------
+    @_fatal_on_error
     def _alltoall_i32(self, ctx, send, recv, count):
         n = self.nproc * count
         src = torch.from_numpy(_np_from_ptr(send, n, np.int32).copy())
@@ -101,6 +164,7 @@ class TorchComm:
         dist.all_to_all_single(dst, src, group=self.group)
         _np_from_ptr(recv, n, np.int32)[:] = dst.numpy()
 
+    @_fatal_on_error
     def _alltoallv_i32(self, ctx, send, scnts, sdispls, recv, rcnts, rdispls):
         P = self.nproc
         sc = [int(scnts[i]) for i in range(P)]
@@ -118,6 +182,7 @@ class TorchComm:
             out[rd[i]:rd[i] + rc[i]] = d[off:off + rc[i]]
             off += rc[i]
 
+    @_fatal_on_error
     def _allgatherv_bytes(self, ctx, send, sbytes, recv, rbytes, rdispls):
         P = self.nproc
         rb = [int(rbytes[i]) for i in range(P)]
@@ -132,6 +197,7 @@ class TorchComm:
         for i in range(P):
             out[rd[i]:rd[i] + rb[i]] = parts[i].numpy()[:rb[i]]
 
+    @_fatal_on_error
     def _barrier(self, ctx):
         t = torch.zeros(1, dtype=torch.int32)
         dist.all_reduce(t, group=self.group)
@@ -141,44 +207,57 @@ class TorchComm:
         dist.all_reduce(t, op=dist.ReduceOp.MAX if op == 0 else dist.ReduceOp.SUM, group=self.group)
         _np_from_ptr(out, count, dtype)[:] = t.numpy().astype(dtype)
 
+    @_fatal_on_error
     def _reduce_f64(self, ctx, inp, out, count, op):
         self._reduce(inp, out, count, op, np.float64)
 
+    @_fatal_on_error
     def _reduce_u64(self, ctx, inp, out, count, op):
         self._reduce(inp, out, count, op, np.uint64)
 
     # ---- device payload -------------------------------------------------------
+    @_fatal_on_error
     def _alltoallv_dev_f64(self, ctx, send, scnts, sdispls, recv, rcnts, rdispls, stream):
+        """Python form of the device all-to-all: CPU tests (host buffers) and the "host" rehearsal mode (device ->
+        host -> gloo -> device).  With a GPU per rank the table points at the library's RCCL function instead.
+        Honours arbitrary displacements, like the contract of crp_comm.h says."""
         P = self.nproc
         sc = [int(scnts[i]) for i in range(P)]
+        sd = [int(sdispls[i]) for i in range(P)]
         rc = [int(rcnts[i]) for i in range(P)]
-        ns, nr = int(sdispls[P]), int(rdispls[P])
-        if ns == 0 and nr == 0:
-            # nothing to move for this rank, but the collective must still be entered
-            pass
-        if torch.cuda.is_available() and exchange_mode() == "host":
-            # staged exchange: the same collective on host copies (gloo), ordered on `stream`
-            dev = torch.device("cuda", torch.cuda.current_device())
-            ext = torch.cuda.ExternalStream(int(stream)) if stream else torch.cuda.current_stream()
-            with torch.cuda.stream(ext):
-                src_d = torch.as_tensor(_CudaView(send, ns), device=dev) if ns else torch.empty(0, dtype=torch.float64, device=dev)
-                src = src_d.cpu()                      # synchronises with `stream`
-                dst = torch.empty(nr, dtype=torch.float64)
-                dist.all_to_all_single(dst, src, output_split_sizes=rc, input_split_sizes=sc, group=self.group)
-                if nr:
-                    torch.as_tensor(_CudaView(recv, nr), device=dev).copy_(dst)
-        elif torch.cuda.is_available():
-            dev = torch.device("cuda", torch.cuda.current_device())
-            src = torch.as_tensor(_CudaView(send, ns), device=dev) if ns else torch.empty(0, dtype=torch.float64, device=dev)
-            dst = torch.as_tensor(_CudaView(recv, nr), device=dev) if nr else torch.empty(0, dtype=torch.float64, device=dev)
-            ext = torch.cuda.ExternalStream(int(stream)) if stream else torch.cuda.current_stream()
-            with torch.cuda.stream(ext):
-                dist.all_to_all_single(dst, src, output_split_sizes=rc, input_split_sizes=sc, group=self.group)
+        rd = [int(rdispls[i]) for i in range(P)]
+        ns = max((sd[i] + sc[i] for i in range(P)), default=0)
+        nr = max((rd[i] + rc[i] for i in range(P)), default=0)
+        on_dev = torch.cuda.is_available()
+        lib = L.load() if on_dev else None
+        if on_dev:
+            src_h = np.zeros(max(ns, 1))
+            if ns:
+                L.check(lib.crp_dev_memcpy(src_h.ctypes.data, send, ns * 8, 1, stream), "staged exchange: device -> host")
+            L.check(lib.crp_stream_sync(stream), "stream sync")
         else:
-            src = torch.from_numpy(_np_from_ptr(send, ns, np.float64))
-            dst = torch.from_numpy(_np_from_ptr(recv, nr, np.float64))
-            dist.all_to_all_single(dst, src, output_split_sizes=rc, input_split_sizes=sc, group=self.group)
+            src_h = _np_from_ptr(send, ns, np.float64)
+        parts = [src_h[sd[i]:sd[i] + sc[i]] for i in range(P)]
+        src = torch.from_numpy(np.concatenate(parts) if parts else np.zeros(0))
+        dst = torch.empty(sum(rc), dtype=torch.float64)
+        dist.all_to_all_single(dst, src, output_split_sizes=rc, input_split_sizes=sc, group=self.group)
+        d = dst.numpy()
+        if on_dev:
+            off = 0
+            for i in range(P):
+                if rc[i]:
+                    L.check(lib.crp_dev_memcpy(int(C.cast(recv, C.c_void_p).value) + rd[i] * 8, d[off:].ctypes.data, rc[i] * 8, 0, stream),
+                            "staged exchange: host -> device")
+                off += rc[i]
+            L.check(lib.crp_stream_sync(stream), "stream sync")      # `d` must outlive the copies
+        else:
+            out = _np_from_ptr(recv, nr, np.float64)
+            off = 0
+            for i in range(P):
+                out[rd[i]:rd[i] + rc[i]] = d[off:off + rc[i]]
+                off += rc[i]
 
+    @_fatal_on_error
     def _alltoallv_bytes(self, ctx, send, scnts, sdispls, recv, rcnts, rdispls):
         P = self.nproc
         sc = [int(scnts[i]) for i in range(P)]
@@ -197,6 +276,7 @@ class TorchComm:
             off += rc[i]
 
     # ---- split / free ---------------------------------------------------------
+    @_fatal_on_error
     def _split(self, ctx, color, key):
         # ctypes callbacks may only return simple types: hand back the struct's address
         return C.addressof(self.split(color, key).struct)
@@ -214,15 +294,23 @@ class TorchComm:
         g = dist.new_group(ranks=ranks, use_local_synchronization=True)
         return TorchComm(g)
 
+    @_fatal_on_error
     def _free(self, ptr):
         c = _live.pop(C.addressof(ptr.contents), None)
         if c is not None:
             _retired.append(c)
+            c._drop_rccl()
 
     def free(self):
         c = _live.pop(C.addressof(self.struct), None)
         if c is not None:
             _retired.append(c)
+        self._drop_rccl()
+
+    def _drop_rccl(self):
+        if self._rccl:
+            L.load().crp_rccl_destroy(C.byref(self._rccl))
+            self._rccl = None
 
 
 class SelfComm:

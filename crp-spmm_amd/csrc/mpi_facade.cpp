@@ -4,21 +4,22 @@
 //
 // crp_comm_t over MPI: the control-plane members call the same MPI routines the
 // reference calls (src/rowpara_spmm.c:154-162,439-442; src/para2d_spmm.c:41-83).
-// The per-multiply B exchange moves DEVICE buffers.  With one GPU per rank it is RCCL: an RCCL
-// communicator is bootstrapped over the MPI one (unique id broadcast by rank 0) the first time a
-// device exchange is asked for, and the sparse all-to-all is one group of ncclSend / ncclRecv on the
-// caller's stream (peers with nothing to exchange are skipped) -- device to device over xGMI, no
-// host copy, asynchronous.  When ranks share a GPU (RCCL refuses that), when RCCL cannot be set
-// up, or with CRPSPMM_EXCHANGE=host, the payload is staged through host buffers and plain MPI
-// point-to-point in the reference's ring order (src/rowpara_spmm.c:275-303).
+// The per-multiply B exchange and the replication of an A row panel move DEVICE buffers.  With one GPU per
+// rank they are RCCL (include/crp_rccl.h): the RCCL communicator is bootstrapped over the MPI one (unique id
+// broadcast by rank 0) when the MPI communicator is wrapped -- i.e. inside the collective *_init call, never
+// inside exec --, and the collectives are groups of ncclSend / ncclRecv on the caller's stream: device to device
+// over xGMI, no host copy, asynchronous.  When ranks of one NODE share a GPU (RCCL refuses that; bus ids are only
+// compared among the ranks MPI_Comm_split_type(SHARED) puts together, they repeat across nodes), when RCCL
+// cannot be set up, or with CRPSPMM_EXCHANGE=host, the payload is staged through host buffers and plain MPI
+// point-to-point in the reference's ring order (src/rowpara_spmm.c:275-303).  Rank 0 says once which it is.
 #include <limits.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
 #include <mpi.h>
-#include <rccl/rccl.h>
 #include "crp_engine.h"
+#include "crp_rccl.h"
 #include "crpspmm_hip.h"
 #include "mat_redist.h"
 #include "para2d_spmm.h"
@@ -34,49 +35,59 @@ struct MpiCtx
     bool     owned;
     int      p2p;
     std::vector<double> hsend, hrecv;   // host staging of the device exchange
-    ncclComm_t nccl = nullptr;
-    int        nccl_state = 0;          // 0 not tried yet, 1 usable, -1 host staging
+    crp_rccl_p rccl = nullptr;          // device collectives; NULL = host staging
 };
 
-// Collective over x->comm: decide once how device payloads travel.
-bool rccl_ready(MpiCtx *x)
+// Collective over x->comm (called from wrap(), i.e. inside the *_init calls): decide how device payloads travel.
+void rccl_setup(MpiCtx *x)
 {
-    if (x->nccl_state != 0) return x->nccl_state > 0;
-    x->nccl_state = -1;
     int P, me;
     MPI_Comm_size(x->comm, &P);
     MPI_Comm_rank(x->comm, &me);
     const char *env = getenv("CRPSPMM_EXCHANGE");
     int want = !(env != NULL && strcmp(env, "host") == 0);
-    // every rank needs a GPU of its own: compare the PCI bus ids
+    // every rank needs a GPU of its own: compare the PCI bus ids of the ranks of this node
     char mine[64] = {0};
     if (crp_hip_device_bus_id(mine, sizeof(mine)) != 0) want = 0;
-    std::vector<char> all((size_t) P * 64, 0);
-    MPI_Allgather(mine, 64, MPI_CHAR, all.data(), 64, MPI_CHAR, x->comm);
-    for (int a = 0; a < P && want; a++)
-        for (int b = a + 1; b < P; b++)
-            if (strncmp(&all[(size_t) a * 64], &all[(size_t) b * 64], 64) == 0) want = 0;
+    {
+        MPI_Comm node;
+        MPI_Comm_split_type(x->comm, MPI_COMM_TYPE_SHARED, me, MPI_INFO_NULL, &node);
+        int np = 1;
+        MPI_Comm_size(node, &np);
+        std::vector<char> all((size_t) np * 64, 0);
+        MPI_Allgather(mine, 64, MPI_CHAR, all.data(), 64, MPI_CHAR, node);
+        for (int a = 0; a < np && want; a++)
+            for (int b = a + 1; b < np; b++)
+                if (strncmp(&all[(size_t) a * 64], &all[(size_t) b * 64], 64) == 0) want = 0;
+        MPI_Comm_free(&node);
+    }
     int all_want = 0;
     MPI_Allreduce(&want, &all_want, 1, MPI_INT, MPI_MIN, x->comm);
-    if (!all_want) return false;
-    ncclUniqueId id;
-    memset(&id, 0, sizeof(id));
-    int ok = 1;
-    if (me == 0) ok = (ncclGetUniqueId(&id) == ncclSuccess);
-    MPI_Bcast(&ok, 1, MPI_INT, 0, x->comm);
-    if (!ok) return false;
-    MPI_Bcast(&id, (int) sizeof(id), MPI_BYTE, 0, x->comm);
-    ok = (ncclCommInitRank(&x->nccl, P, id, me) == ncclSuccess);
-    int all_ok = 0;
-    MPI_Allreduce(&ok, &all_ok, 1, MPI_INT, MPI_MIN, x->comm);
-    if (!all_ok)
+    if (all_want)
     {
-        if (ok && x->nccl) ncclCommDestroy(x->nccl);
-        x->nccl = nullptr;
-        return false;
+        char id[CRP_RCCL_ID_BYTES];
+        memset(id, 0, sizeof(id));
+        int ok = 1;
+        if (me == 0) ok = (crp_rccl_get_unique_id(id) == 0);
+        MPI_Bcast(&ok, 1, MPI_INT, 0, x->comm);
+        if (ok)
+        {
+            MPI_Bcast(id, (int) sizeof(id), MPI_BYTE, 0, x->comm);
+            ok = (crp_rccl_create(id, P, me, &x->rccl) == 0);
+            int all_ok = 0;
+            MPI_Allreduce(&ok, &all_ok, 1, MPI_INT, MPI_MIN, x->comm);
+            if (!all_ok) crp_rccl_destroy(&x->rccl);
+        }
     }
-    x->nccl_state = 1;
-    return true;
+    static bool said = false;
+    int wrank = 0;
+    MPI_Comm_rank(MPI_COMM_WORLD, &wrank);
+    if (!said && wrank == 0 && P > 1)
+    {
+        said = true;
+        printf("[INFO] crpspmm device payloads: %s (%d ranks)\n", x->rccl ? "RCCL, device to device" : "host staging + MPI", P);
+        fflush(stdout);
+    }
 }
 
 void m_alltoall(void *c, const int *s, int *r, int count)
@@ -90,16 +101,28 @@ void m_alltoallv(void *c, const int *s, const int *sc, const int *sd, int *r, co
 void m_allgatherv(void *c, const void *s, size_t sb, void *r, const size_t *rb, const size_t *rd)
 {
     MpiCtx *x = (MpiCtx *) c;
-    int P;
+    int P, me;
     MPI_Comm_size(x->comm, &P);
-    std::vector<int> cnt(P), dsp(P);
-    for (int i = 0; i < P; i++)
+    MPI_Comm_rank(x->comm, &me);
+    bool small = true;
+    for (int i = 0; i < P; i++) small = small && rb[i] <= (size_t) INT_MAX && rd[i] <= (size_t) INT_MAX;
+    if (small)
     {
-        ASSERT_PRINTF(rb[i] <= INT_MAX && rd[i] <= INT_MAX, "allgatherv piece exceeds 2 GiB\n");
-        cnt[i] = (int) rb[i];
-        dsp[i] = (int) rd[i];
+        std::vector<int> cnt(P), dsp(P);
+        for (int i = 0; i < P; i++) { cnt[i] = (int) rb[i]; dsp[i] = (int) rd[i]; }
+        MPI_Allgatherv(s, (int) sb, MPI_BYTE, r, cnt.data(), dsp.data(), MPI_BYTE, x->comm);
+        return;
     }
-    MPI_Allgatherv(s, (int) sb, MPI_BYTE, r, cnt.data(), dsp.data(), MPI_BYTE, x->comm);
+    // pieces or displacements beyond what MPI's int counts carry (an nlpkkt240 value slice is 3 GB): one
+    // broadcast per source, in chunks
+    const size_t chunk = (size_t) 1 << 30;
+    if (sb > 0) memcpy((char *) r + rd[me], s, sb);
+    for (int q = 0; q < P; q++)
+        for (size_t off = 0; off < rb[q]; off += chunk)
+        {
+            const size_t len = rb[q] - off < chunk ? rb[q] - off : chunk;
+            MPI_Bcast((char *) r + rd[q] + off, (int) len, MPI_BYTE, q, x->comm);
+        }
 }
 void m_barrier(void *c) { MPI_Barrier(((MpiCtx *) c)->comm); }
 void m_red_f64(void *c, const double *in, double *out, int n, int op)
@@ -118,18 +141,10 @@ void m_alltoallv_dev(void *c, const double *send_dev, const long long *sc, const
     int P, me;
     MPI_Comm_size(x->comm, &P);
     MPI_Comm_rank(x->comm, &me);
-    if (rccl_ready(x))
+    if (x->rccl != nullptr)
     {
-        ncclResult_t r = ncclGroupStart();
-        for (int i = 0; i < P && r == ncclSuccess; i++)
-        {
-            const int q = (me + i) % P;
-            if (rc[q] > 0) r = ncclRecv(recv_dev + rd[q], (size_t) rc[q], ncclDouble, q, x->nccl, (hipStream_t) stream);
-            if (r == ncclSuccess && sc[q] > 0)
-                r = ncclSend(send_dev + sd[q], (size_t) sc[q], ncclDouble, q, x->nccl, (hipStream_t) stream);
-        }
-        if (r == ncclSuccess) r = ncclGroupEnd();
-        ASSERT_PRINTF(r == ncclSuccess, "RCCL exchange failed: %s\n", ncclGetErrorString(r));
+        const int r = crp_rccl_alltoallv_f64(x->rccl, send_dev, sc, sd, recv_dev, rc, rd, stream);
+        ASSERT_PRINTF(r == 0, "RCCL exchange failed (%d)\n", r);
         return;
     }
     const long long ns = sd[P], nr = rd[P];
@@ -189,6 +204,12 @@ void m_alltoallv_bytes(void *c, const void *s, const size_t *sc, const size_t *s
     MPI_Alltoallv(s, isc.data(), isd.data(), MPI_BYTE, r, irc.data(), ird.data(), MPI_BYTE, x->comm);
 }
 
+void m_allgatherv_dev(void *c, const void *send_dev, size_t sb, void *recv_dev, const size_t *rb, const size_t *rd, void *stream)
+{
+    const int r = crp_rccl_allgatherv(((MpiCtx *) c)->rccl, send_dev, sb, recv_dev, rb, rd, stream);
+    ASSERT_PRINTF(r == 0, "RCCL all-gather failed (%d)\n", r);
+}
+
 crp_comm_t *wrap(MPI_Comm comm, bool owned);
 
 crp_comm_t *m_split(void *c, int color, int key)
@@ -201,7 +222,7 @@ crp_comm_t *m_split(void *c, int color, int key)
 void m_free(crp_comm_t *self)
 {
     MpiCtx *x = (MpiCtx *) self->ctx;
-    if (x->nccl) ncclCommDestroy(x->nccl);
+    crp_rccl_destroy(&x->rccl);
     if (x->owned) MPI_Comm_free(&x->comm);
     delete x;
     free(self);
@@ -227,6 +248,8 @@ crp_comm_t *wrap(MPI_Comm comm, bool owned)
     c->alltoallv_bytes = m_alltoallv_bytes;
     c->split = m_split;
     c->free = m_free;
+    rccl_setup(x);
+    if (x->rccl != nullptr) c->allgatherv_dev = m_allgatherv_dev;
     return c;
 }
 
@@ -409,7 +432,7 @@ crp_comm_t *crp_mpi_comm_wrap(MPI_Comm comm)
 
 int crp_mpi_comm_uses_rccl(crp_comm_t *c)
 {
-    return (c != NULL && rccl_ready((MpiCtx *) c->ctx)) ? 1 : 0;
+    return (c != NULL && ((MpiCtx *) c->ctx)->rccl != nullptr) ? 1 : 0;
 }
 
 void rp_spmm_init(const int A_srow, const int A_nrow, const int *A_rowptr, const int *A_colidx, const double *A_val,

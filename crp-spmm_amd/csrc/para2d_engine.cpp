@@ -5,8 +5,8 @@
 // into the row panel AC_rowptr[pi] .. AC_rowptr[pi+1] (one-time replication,
 // reference :56-98), then a 1D row-parallel engine runs inside each grid
 // column on the BC_colptr[pj] .. BC_colptr[pj+1] columns of B and C.
-// The panel is assembled on the host through the communicator's allgatherv
-// and uploaded once by the 1D engine; the replication-cost statistic is
+// The panel's column indices and values are all-gathered between DEVICE buffers when the communicator
+// offers allgatherv_dev (RCCL), on the host through allgatherv_bytes otherwise; the replication-cost statistic is
 // computed without the reference's rank (P-1) -> rank 0 message, which
 // deadlocks at one rank (reference :102-109).
 #include <stdio.h>
@@ -14,6 +14,7 @@
 #include <string.h>
 #include <vector>
 #include "crp_engine.h"
+#include "crpspmm_hip.h"
 #include "utils.h"
 
 struct crp_para2d_spmm
@@ -23,6 +24,7 @@ struct crp_para2d_spmm
     crp_comm_t   *comm_col = nullptr;   // owned
     size_t rA_cost = 0;
     double t_init = 0.0, t_ag_A = 0.0;
+    bool   replicated_on_device = false;   // the panel's colidx / val were all-gathered between device buffers
 };
 
 extern "C" {
@@ -74,12 +76,54 @@ static void para2d_init_common(crp_comm_t *comm, int pm, int pn, const int *A0_r
         p_rowptr[p_nrow] = p_rowptr[0] + (int) p_nnz;
         p_colidx.resize((size_t) (p_nnz > 0 ? p_nnz : 1));
         p_val.resize((size_t) (p_nnz > 0 ? p_nnz : 1));
+        std::vector<size_t> cnt_i(pn), dsp_i(pn), cnt_v(pn), dsp_v(pn);
         off = 0;
-        for (int j = 0; j < pn; j++) { cnt[j] = sizeof(int) * (size_t) nnzs[j]; dsp[j] = off; off += cnt[j]; }
-        comm_row->allgatherv_bytes(comm_row->ctx, A_colidx, cnt[pj], p_colidx.data(), cnt.data(), dsp.data());
+        for (int j = 0; j < pn; j++) { cnt_i[j] = sizeof(int) * (size_t) nnzs[j]; dsp_i[j] = off; off += cnt_i[j]; }
         off = 0;
-        for (int j = 0; j < pn; j++) { cnt[j] = sizeof(double) * (size_t) nnzs[j]; dsp[j] = off; off += cnt[j]; }
-        comm_row->allgatherv_bytes(comm_row->ctx, A_val, cnt[pj], p_val.data(), cnt.data(), dsp.data());
+        for (int j = 0; j < pn; j++) { cnt_v[j] = sizeof(double) * (size_t) nnzs[j]; dsp_v[j] = off; off += cnt_v[j]; }
+        static const bool host_only = getenv("CRPSPMM_REPLICATE") != NULL && strcmp(getenv("CRPSPMM_REPLICATE"), "host") == 0;
+        if (comm_row->allgatherv_dev != NULL && !plan_only && !host_only && p_nnz > 0)
+        {
+            // Device replication (reference :81-83: two overlapped MPI_Iallgatherv on duplicate communicators):
+            // the own slices go up once, column indices and values are all-gathered between device buffers on
+            // two streams -- over xGMI every source feeds its pn - 1 peers on distinct links --, and the panel
+            // comes back through pinned memory for the plan and the format construction, which run on the host.
+            void *s_i = NULL, *s_v = NULL, *d_ci = NULL, *d_va = NULL, *d_ci_all = NULL, *d_va_all = NULL, *h_ci = NULL, *h_va = NULL;
+            int rc = crp_stream_create(&s_i);
+            if (rc == 0) rc = crp_stream_create(&s_v);
+            if (rc == 0) rc = crp_dev_malloc(&d_ci_all, sizeof(int) * (size_t) p_nnz);
+            if (rc == 0) rc = crp_dev_malloc(&d_va_all, sizeof(double) * (size_t) p_nnz);
+            if (rc == 0) rc = crp_host_malloc(&h_ci, sizeof(int) * (size_t) p_nnz);
+            if (rc == 0) rc = crp_host_malloc(&h_va, sizeof(double) * (size_t) p_nnz);
+            ASSERT_PRINTF(rc == 0, "para2d_spmm_init: device buffers for the panel replication (%d)\n", rc);
+            // own slice straight into its place of the gathered arrays (send == recv + displacement: no extra copy)
+            d_ci = (char *) d_ci_all + dsp_i[pj];
+            d_va = (char *) d_va_all + dsp_v[pj];
+            if (my_nnz > 0)
+            {
+                rc = crp_dev_memcpy(d_ci, A_colidx, cnt_i[pj], 0, s_i);
+                if (rc == 0) rc = crp_dev_memcpy(d_va, A_val, cnt_v[pj], 0, s_v);
+                ASSERT_PRINTF(rc == 0, "para2d_spmm_init: upload of the A0 slice (%d)\n", rc);
+            }
+            comm_row->allgatherv_dev(comm_row->ctx, d_ci, cnt_i[pj], d_ci_all, cnt_i.data(), dsp_i.data(), s_i);
+            comm_row->allgatherv_dev(comm_row->ctx, d_va, cnt_v[pj], d_va_all, cnt_v.data(), dsp_v.data(), s_v);
+            rc = crp_dev_memcpy(h_ci, d_ci_all, sizeof(int) * (size_t) p_nnz, 1, s_i);
+            if (rc == 0) rc = crp_dev_memcpy(h_va, d_va_all, sizeof(double) * (size_t) p_nnz, 1, s_v);
+            if (rc == 0) rc = crp_stream_sync(s_i);
+            if (rc == 0) rc = crp_stream_sync(s_v);
+            ASSERT_PRINTF(rc == 0, "para2d_spmm_init: panel replication on the device (%d)\n", rc);
+            memcpy(p_colidx.data(), h_ci, sizeof(int) * (size_t) p_nnz);
+            memcpy(p_val.data(), h_va, sizeof(double) * (size_t) p_nnz);
+            crp_host_free(h_ci); crp_host_free(h_va);
+            crp_dev_free(d_ci_all); crp_dev_free(d_va_all);
+            crp_stream_destroy(s_i); crp_stream_destroy(s_v);
+            e->replicated_on_device = true;
+        }
+        else
+        {
+            comm_row->allgatherv_bytes(comm_row->ctx, A_colidx, cnt_i[pj], p_colidx.data(), cnt_i.data(), dsp_i.data());
+            comm_row->allgatherv_bytes(comm_row->ctx, A_val, cnt_v[pj], p_val.data(), cnt_v.data(), dsp_v.data());
+        }
     }
     else
     {
@@ -152,6 +196,8 @@ void crp_para2d_spmm_exec_ex(crp_para2d_spmm_p e, int BC_layout, const double *B
     if (e == NULL) return;
     crp_rp_spmm_exec_ex(e->rp, BC_layout, B, ldB, C, ldC, stream);
 }
+
+int crp_para2d_spmm_replicated_on_device(crp_para2d_spmm_p e) { return (e && e->replicated_on_device) ? 1 : 0; }
 
 void crp_para2d_spmm_print_stat(crp_para2d_spmm_p e)
 {

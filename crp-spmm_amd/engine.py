@@ -211,6 +211,11 @@ class Para2dSpmm:
         return int(self._lib.crp_para2d_spmm_rA_cost(self.handle))
 
     @property
+    def replicated_on_device(self):
+        """True when init all-gathered the panel's column indices and values between device buffers."""
+        return bool(self._lib.crp_para2d_spmm_replicated_on_device(self.handle))
+
+    @property
     def t_ag_A(self):
         return float(self._lib.crp_para2d_spmm_t_ag_A(self.handle))
 

@@ -65,6 +65,13 @@ struct crp_comm
      * Returns a new communicator owned by the caller (release with ->free). */
     crp_comm_t *(*split)(void *ctx, int color, int key);
     void (*free)(crp_comm_t *self);
+
+    /* (appended member; NULL = not available, the engines then use allgatherv_bytes on host copies.)
+     * The one-time replication of an A row panel inside a grid row, between DEVICE buffers: every rank's
+     * `sbytes` land at recv_dev + rdispls[q] on all ranks (2 x MPI_Iallgatherv in src/para2d_spmm.c:81-83).
+     * Enqueued on `stream`. */
+    void (*allgatherv_dev)(void *ctx, const void *send_dev, size_t sbytes, void *recv_dev, const size_t *rbytes,
+                           const size_t *rdispls, void *stream);
 };
 
 /* Single-rank communicator (nproc = 1); every collective is a local copy.

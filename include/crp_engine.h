@@ -123,6 +123,9 @@ void crp_para2d_spmm_exec_ex(crp_para2d_spmm_p para2d_spmm, int BC_layout, const
 void crp_para2d_spmm_print_stat(crp_para2d_spmm_p para2d_spmm);
 void crp_para2d_spmm_clear_stat(crp_para2d_spmm_p para2d_spmm);
 crp_rp_spmm_p crp_para2d_spmm_rp(crp_para2d_spmm_p para2d_spmm);
+/* 1 when init replicated the panel's column indices and values between device buffers (the communicator's
+ * allgatherv_dev: RCCL; CRPSPMM_REPLICATE=host forces the host path), 0 when it went through allgatherv_bytes. */
+int crp_para2d_spmm_replicated_on_device(crp_para2d_spmm_p para2d_spmm);
 size_t crp_para2d_spmm_rA_cost(crp_para2d_spmm_p para2d_spmm);
 double crp_para2d_spmm_t_ag_A(crp_para2d_spmm_p para2d_spmm);
 

@@ -76,6 +76,9 @@ def main():
             pi, pj = me // pn, me % pn
             s0, e0 = int(a0[me]), int(a0[me + 1])
             e2 = engine.Para2dSpmm(world, pm, pn, a0, ac, ac, bc, rp[s0:e0 + 1], ci[rp[s0]:rp[e0]], va[rp[s0]:rp[e0]])
+            # the panel was replicated between device buffers (staged all-gather in this rehearsal mode, RCCL with a
+            # GPU per rank) whenever a grid row has more than one rank and something to gather
+            assert e2.replicated_on_device == (pn > 1), (pm, pn, e2.replicated_on_device)
             e2.rp.set_timing(False)
             Bl = torch.from_numpy(np.ascontiguousarray(B[ac[pi]:ac[pi + 1], bc[pj]:bc[pj + 1]])).to(dev)
             Cl = torch.full((int(ac[pi + 1] - ac[pi]), int(bc[pj + 1] - bc[pj])), float("nan"), dtype=torch.float64, device=dev)
@@ -101,7 +104,7 @@ def main():
         Cd = torch.full((e - s, n), float("nan"), dtype=torch.float64, device=dev)
         for timing in (True, False):
             eng.set_timing(timing)
-            for variant in (0, 3, 4, 1):
+            for variant in (0, 3, 4, 5, 1):
                 eng.set_variant(variant)
                 Cd.fill_(float("nan"))
                 eng.exec(0, Bd, Cd)

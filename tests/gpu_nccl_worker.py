@@ -27,6 +27,10 @@ def main():
     assert crp_comm.exchange_mode() == "nccl" and dist.get_backend() in ("nccl", "undefined", "cpu:gloo,cuda:nccl")
     world = crp_comm.TorchComm()
     assert (world.nproc, world.rank) == (1, 0)
+    # device payloads go through the library's own RCCL communicator (include/crp_rccl.h), not through Python
+    assert world.device_ranks() == 1 and world.struct.ctx
+    assert C.cast(world.struct.alltoallv_dev_f64, C.c_void_p).value == C.cast(lib.crp_rccl_comm_alltoallv_dev_f64, C.c_void_p).value
+    ctx = world.struct.ctx
 
     # ---- device all-to-all on a stream torch does not know, between raw device buffers
     stream = C.c_void_p()
@@ -40,7 +44,7 @@ def main():
     LL = C.c_longlong
     scn, sds = (LL * 1)(nel), (LL * 2)(0, nel)
     for rep in range(3):
-        world.struct.alltoallv_dev_f64(None, C.cast(send, C.POINTER(C.c_double)), scn, sds,
+        world.struct.alltoallv_dev_f64(ctx, C.cast(send, C.POINTER(C.c_double)), scn, sds,
                                        C.cast(recv, C.POINTER(C.c_double)), scn, sds, stream)
     out_h = np.zeros(nel)
     assert lib.crp_dev_memcpy(out_h.ctypes.data, recv, nel * 8, 1, stream) == 0      # ordered after the exchange on `stream`
@@ -49,13 +53,23 @@ def main():
     # empty exchange (a rank with nothing to send or receive still enters the collective)
     z = (LL * 1)(0)
     zd = (LL * 2)(0, 0)
-    world.struct.alltoallv_dev_f64(None, C.cast(send, C.POINTER(C.c_double)), z, zd,
+    world.struct.alltoallv_dev_f64(ctx, C.cast(send, C.POINTER(C.c_double)), z, zd,
                                    C.cast(recv, C.POINTER(C.c_double)), z, zd, stream)
     assert lib.crp_stream_sync(stream) == 0
 
+    # ---- all-gather between device buffers (the A panel replication): at one rank the own piece lands at its displacement
+    assert lib.crp_dev_memset(recv, 0, nel * 8, stream) == 0
+    SZ = C.c_size_t
+    half = nel * 4
+    rb, rd = (SZ * 1)(half), (SZ * 1)(64)
+    world.struct.allgatherv_dev(ctx, send, half, recv, rb, rd, stream)
+    assert lib.crp_dev_memcpy(out_h.ctypes.data, recv, nel * 8, 1, stream) == 0
+    assert lib.crp_stream_sync(stream) == 0
+    assert np.array_equal(out_h[8:8 + nel // 2], src_h[:nel // 2]) and not out_h[:8].any()
+
     # ---- split / barrier / reductions on the mixed backend
     sub = world.split(0, 0)
-    assert (sub.nproc, sub.rank) == (1, 0)
+    assert (sub.nproc, sub.rank) == (1, 0) and sub.device_ranks() == 1
     world.struct.barrier(None)
     a, b = (C.c_double * 2)(1.5, -2.0), (C.c_double * 2)()
     world.struct.reduce_f64(None, a, b, 2, 1)

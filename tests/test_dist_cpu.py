@@ -1,4 +1,5 @@
-"""CPU: the N > 1 path over torch.distributed (gloo), world_size 2 and 4."""
+"""CPU: the N > 1 path over torch.distributed (gloo), world_size 2, 4 and 8 (every grid is forced in turn: world 8
+includes the 2 x 4 grid of BASELINE configs[2])."""
 import os
 import subprocess
 import sys
@@ -8,7 +9,7 @@ import pytest
 from conftest import ROOT
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_engines_over_gloo(world):
     env = dict(os.environ)
     env.pop("RP_SPMM_REIDX", None)

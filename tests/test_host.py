@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol(crp):
     bound in _lib.SIGNATURES (MPI-typed facade headers are checked against libcrpspmm.so)."""
     from crp_spmm_amd import _lib
     inc = os.path.join(ROOT, "include")
-    core = ["crpspmm_hip.h", "crp_comm.h", "crp_engine.h", "utils.h", "spmat_part.h", "mmio_utils.h", "dev_type.h"]
+    core = ["crpspmm_hip.h", "crp_comm.h", "crp_engine.h", "utils.h", "spmat_part.h", "mmio_utils.h", "dev_type.h", "crp_rccl.h"]
     pat = re.compile(r"^\s*(?:const\s+)?[A-Za-z_][\w\s\*]*?\b(\w+)\s*\(", re.M)
     out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
     exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln}
