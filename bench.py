@@ -107,7 +107,7 @@ def kkt240_cached():
     got = mmio.csr_cache_read(path)
     if got is not None:
         return got[2], got[3], got[4]
-    rp, ci, va = gen.kkt3d(241)
+    rp, ci, va = gen.kkt3d_big(241)
     m = len(rp) - 1
     mmio.csr_cache_write(path, m, m, rp, ci, va)
     return rp, ci, va
@@ -169,8 +169,18 @@ def measured_traffic(matrix, data, n, world, kernel_name):
 def measure(args, matrix, mtx, steps, lib, torch, dist, comm, dev, world, rank, with_cpu):
     from crp_spmm_amd import engine, planner
     distributed = world > 1
+    t_stage = time.time()
+
+    def stage(msg):
+        # progress on stderr (large workloads take minutes before the first timed step)
+        nonlocal t_stage
+        if rank == 0:
+            print("[bench %7.1f s] %s" % (time.time() - t_stage, msg), file=sys.stderr)
+            sys.stderr.flush()
+    stage("building matrix %s" % matrix)
     label, data, m, k, rp, ci, va = build_matrix(matrix, mtx)
     n, nnz = args.n, int(rp[-1])
+    stage("matrix ready: %d rows, %d nnz; engine init" % (m, nnz))
     flops = 2.0 * nnz * n
 
     # ---- partition (planner runs on every rank: deterministic, same answer everywhere)
@@ -208,10 +218,12 @@ def measure(args, matrix, mtx, steps, lib, torch, dist, comm, dev, world, rank, 
     def step():
         eng.exec(0, B, Cmat, stream=stream)
 
+    stage("operands resident; first exec (builds the kernel's formats)")
     t_first = time.perf_counter()
     step()                                   # (builds the kernel's formats on first use)
     torch.cuda.synchronize()
     t_first = time.perf_counter() - t_first
+    stage("first exec done in %.1f s; device memory in use %.1f GB" % (t_first, torch.cuda.memory_allocated() / 1e9))
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -269,6 +281,7 @@ def measure(args, matrix, mtx, steps, lib, torch, dist, comm, dev, world, rank, 
                 step()
             torch.cuda.synchronize()
 
+    stage("checked; timing %d steps" % steps)
     # ---- timed region: K steps between barrier + synchronize; HIP events per step on the launch stream
     ev = [(C.c_void_p(), C.c_void_p()) for _ in range(steps)]
     for a, b in ev:
@@ -306,7 +319,9 @@ def measure(args, matrix, mtx, steps, lib, torch, dist, comm, dev, world, rank, 
     ki = rp_eng.kernel_info()
     kname = KERNEL_SYMBOL.get(ki["variant_name"], str(ki["variant_name"]))
     traffic, tsrc = measured_traffic(matrix, data, n, world, ki["variant_name"])
+    free_b, total_b = torch.cuda.mem_get_info()
     res = {
+        "hbm_in_use_GB": (total_b - free_b) / 1e9,
         "label": label, "data": data, "rows": m, "nnz": nnz, "n": n, "grid": "%dx%d" % (pm, pn),
         "value": flops * steps / elapsed / 1e9, "ms_per_step": ms_per_step, "kern_ms": kern_ms, "alg_bytes": alg_bytes,
         "achieved": achieved, "kernel_info": ki, "kernel": kname, "traffic": traffic, "traffic_source": tsrc,
@@ -385,7 +400,7 @@ def main():
                    "rows": r["rows"], "nnz": r["nnz"], "n": r["n"], "grid": r["grid"], "kernel_variant": args.variant,
                    "kernel_variant_resolved": r["kernel_info"]["variant_name"],
                    "locality_order": r["kernel_info"]["reordered"], "lattice_detected": r["kernel_info"]["lattice"],
-                   "rccl_ranks": rccl_ranks, "first_exec_s": r["first_exec_s"], "check_rel_err": r["check_rel_err"],
+                   "rccl_ranks": rccl_ranks, "first_exec_s": r["first_exec_s"], "hbm_in_use_GB": r["hbm_in_use_GB"], "check_rel_err": r["check_rel_err"],
                    "achieved_hbm_GBs_alg": r["alg_bytes"] / (r["ms_per_step"] * 1e-3) / 1e9 if not distributed else None,
                    "also": also},
         "roofline": {"bound": "hbm", "achieved": r["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -48,6 +48,7 @@ struct Team2Dev
     long long *tvoff = nullptr;
     double   *tval = nullptr;
     uint32_t *tmap = nullptr;      // per CSR nonzero: its slot in tval (value updates)
+    float    *tval32 = nullptr;    // fp32 copy of the value groups (fp32 path), built on first use
     long long entries = 0, value_entries = 0;
     bool lattice = false;
 };
@@ -66,8 +67,10 @@ struct crp_csr_dev
     PanelDev pan[2];          // [0]: R = 4, [1]: R = 8
     TeamDev  team;            // teams of four R = 8 panels (variant 4)
     Team2Dev team2;           // teams of eight R = 8 panels, LDS-shared B rows (variant 5)
-    int      auto_variant = 1; // what variant 0 resolves to (1 rowgroup, 2 panel R4, 3 panel R8)
+    int      auto_variant = 1; // what variant 0 resolves to below 96 columns (1 rowgroup, 2 panel R4, 3 panel R8)
+    bool     team2_pays = false;   // 64 consecutive rows (in format order) share columns: variant 0 takes team2 from 96 columns on
     long long b0_rows = 0, b1_rows = 0;   // 1 + largest local / receive-buffer row a column index addresses
+    float    *val32 = nullptr;            // fp32 copy of val (fp32 path), built on first use
     int      *rowmap = nullptr;           // row-subset matrices: C row of every row (device), else nullptr
     // locality order (locality.h): the derived formats (panels, teams) are built on the rows in processing order
     // perm[i] = original row at position i; f_* = that CSR, f_nz[p'] = original position of its nonzero p';
@@ -439,7 +442,7 @@ int crp_csr_dev_create(int nrow, int ncol, const int *rowptr, const int *colidx,
     // more columns than the caller's order does (fewer R = 8 panel entries).  A mesh numbered along its own lines
     // (the stride-lattice matrices) keeps the caller's order -- consecutive rows there are neighbours already and
     // the lattice schedules build on that.  CRPSPMM_REORDER=0 never, =1 whenever the matrix qualifies.
-    if (nnz > 0 && nrow >= 2048 && nrow == ncol && A->b1_rows == 0)
+    if (nnz > 0 && nrow >= 2048 && nrow == ncol && A->b1_rows == 0 && nnz <= 200000000LL)    // (the graph of a larger matrix costs tens of GB)
     {
         const char *er = getenv("CRPSPMM_REORDER");
         const int mode = er ? atoi(er) : -1;
@@ -494,6 +497,11 @@ int crp_csr_dev_create(int nrow, int ncol, const int *rowptr, const int *colidx,
         const double fill4 = (double) nnz / (4.0 * (double) e4);
         if (fill4 >= 0.45) A->auto_variant = ((double) e8 <= 0.72 * (double) e4) ? 3 : 2;
     }
+    // The LDS-sharing team kernel fetches a B row once per team of 64 rows: it pays when those rows name far fewer
+    // distinct columns than they have nonzeros (pwtk stand-in 0.10, shell 0.09, kkt 0.27, fem3d 0.13 of the nonzeros;
+    // Erdos-Renyi 0.99, where the CSR kernel stays).
+    if (nnz > 0 && nrow >= 64)
+        A->team2_pays = (double) crp::count_block_union(nrow, fmt_rowptr(A), fmt_colidx(A), 64) <= 0.6 * (double) nnz;
     const char *env = getenv("CRPSPMM_SPMM_VARIANT");
     if (env != NULL && atoi(env) >= 1 && atoi(env) <= 3) A->auto_variant = atoi(env);
     if (A->auto_variant >= 2)
@@ -540,6 +548,8 @@ int crp_csr_dev_destroy(crp_csr_dev_p *A_)
     if (A->team2.tvoff) (void) hipFree(A->team2.tvoff);
     if (A->team2.tval) (void) hipFree(A->team2.tval);
     if (A->team2.tmap) (void) hipFree(A->team2.tmap);
+    if (A->team2.tval32) (void) hipFree(A->team2.tval32);
+    if (A->val32) (void) hipFree(A->val32);
     if (A->rowptr) (void) hipFree(A->rowptr);
     if (A->colidx) (void) hipFree(A->colidx);
     if (A->val) (void) hipFree(A->val);
@@ -573,6 +583,9 @@ int crp_csr_dev_update_values(crp_csr_dev_p A, const double *val, void *stream)
             CRP_TRY(crp::scatter_vals_f64(A->nnz, A->pan[i].pmap, A->val, A->pan[i].pval, (hipStream_t) stream));
     if (A->team.built) CRP_TRY(crp::scatter_vals_f64(A->nnz, A->team.tmap, A->val, A->team.tval, (hipStream_t) stream));
     if (A->team2.built) CRP_TRY(crp::scatter_vals_f64(A->nnz, A->team2.tmap, A->val, A->team2.tval, (hipStream_t) stream));
+    // fp32 copies follow
+    if (A->val32) CRP_TRY(crp::convert_f64_f32(A->nnz, A->val, A->val32, (hipStream_t) stream));
+    if (A->team2.tval32) CRP_TRY(crp::convert_f64_f32(A->team2.value_entries * 8, A->team2.tval, A->team2.tval32, (hipStream_t) stream));
     return 0;
 }
 
@@ -634,10 +647,10 @@ int crp_spmm_csr_f64(crp_csr_dev_p A, int layout, int n, const double *B0, long 
     hipError_t e;
     if (layout == CRP_LAYOUT_COL_MAJOR) return (int) crp::spmm_cm_f64(a, (hipStream_t) stream);
     int v = (variant == 0) ? A->auto_variant : variant;
-    // auto: from 96 columns on the LDS-sharing team kernel replaces the row-panel kernels wherever those were
-    // chosen (measured on the pwtk, shell, kkt and fem3d stand-ins at n = 128 / 256 / 1024: 0.97 / 0.91 / 0.93,
-    // 0.83 / 0.73 / 0.68, 0.65 / 0.70 / 0.67, 0.87 / 0.93 / 0.88 of the row-panel time; at n = 32 it needs 1.7 x)
-    if (variant == 0 && v >= 2 && n >= 96 && A->nrow >= 64 && crp::spmm_team2_applicable(a)) v = 5;
+    // auto: from 96 columns on the LDS-sharing team kernel wherever teams share columns (measured against the
+    // create-time choice on the pwtk, shell, kkt and fem3d stand-ins at n = 128 / 256 / 1024: 0.97 / 0.91 / 0.93,
+    // 0.83 / 0.73 / 0.68, 0.65 / 0.70 / 0.67, 0.87 / 0.93 / 0.88 of its time; at n = 32 it needs 1.7 x)
+    if (variant == 0 && A->team2_pays && n >= 96 && crp::spmm_team2_applicable(a)) v = 5;
     if (v == 5 && (!crp::spmm_team2_applicable(a) || A->nnz == 0 || A->nrow < 8)) v = 3;
     if (v >= 2 && A->rowmap_fmt != nullptr) a.rowmap = A->rowmap_fmt;      // derived formats hold the rows in processing order
     if (v == 5)
@@ -646,7 +659,7 @@ int crp_spmm_csr_f64(crp_csr_dev_p A, int layout, int n, const double *B0, long 
         if (rc != 0) return rc;
         crp::Team2Args t;
         t.nteam = A->team2.nteam; t.torder = A->team2.torder; t.tpanel = A->team2.tpanel; t.tinfo = A->team2.tinfo;
-        t.tpro = A->team2.tpro; t.trec = A->team2.trec; t.tvoff = A->team2.tvoff; t.tval = A->team2.tval;
+        t.tpro = A->team2.tpro; t.trec = A->team2.trec; t.tvoff = A->team2.tvoff; t.tval = A->team2.tval; t.tval32 = nullptr;
         return (int) crp::spmm_rm_f64_team2(t, a, (hipStream_t) stream);
     }
     if (v == 4 && (!crp::spmm_team_applicable(a) || A->b1_rows > 0)) v = 3;   // team kernel: one B source, 256-column tile
@@ -675,6 +688,42 @@ int crp_spmm_csr_f64(crp_csr_dev_p A, int layout, int n, const double *B0, long 
     return (int) e;
 }
 
+// C[nrow x n] := A * B with values, B and C in fp32 (row-major only): the fp32 instance of the team kernel where it
+// applies and pays (variant 0 / 5), the fp32 CSR row-group kernel otherwise (variant 1, any width and alignment)
+int crp_spmm_csr_f32(crp_csr_dev_p A, int n, const float *B0, long long ldB0, const float *B1, long long ldB1, float *C,
+                     long long ldC, int variant, void *stream)
+{
+    if (A == NULL || n < 0) return -1;
+    if (variant != 0 && variant != 1 && variant != 5) return -1;
+    if (A->nrow == 0 || n == 0) return 0;
+    if (C == NULL || (B0 == NULL && B1 == NULL && A->nnz > 0)) return -1;
+    if (ldC < n || (B0 && ldB0 < n) || (B1 && ldB1 < n)) return -4;
+    if (A->val32 == nullptr)
+    {
+        CRP_TRY(hipMalloc((void **) &A->val32, sizeof(float) * (size_t) (A->nnz > 0 ? A->nnz : 1)));
+        CRP_TRY(crp::convert_f64_f32(A->nnz, A->val, A->val32, (hipStream_t) stream));
+    }
+    crp::SpmmArgsF32 a;
+    a.nrow = A->nrow; a.n = n; a.rowptr = A->rowptr; a.colidx = A->colidx; a.val = A->val32;
+    a.B0 = B0; a.ldB0 = ldB0; a.B1 = B1; a.ldB1 = ldB1; a.C = C; a.ldC = ldC; a.rowmap = A->rowmap;
+    const bool team = (variant == 5 || (variant == 0 && A->team2_pays && n >= 96)) && A->nnz > 0 && A->nrow >= 8 &&
+                      crp::spmm_team2_applicable_f32(a);
+    if (!team) return (int) crp::spmm_rm_f32_rowgroup(a, (hipStream_t) stream);
+    const int rc = ensure_team2(A);
+    if (rc != 0) return rc;
+    if (A->team2.tval32 == nullptr)
+    {
+        CRP_TRY(hipMalloc((void **) &A->team2.tval32, sizeof(float) * ((size_t) A->team2.value_entries * 8 + 1024)));
+        CRP_TRY(hipMemsetAsync(A->team2.tval32, 0, sizeof(float) * ((size_t) A->team2.value_entries * 8 + 1024), (hipStream_t) stream));
+        CRP_TRY(crp::convert_f64_f32(A->team2.value_entries * 8, A->team2.tval, A->team2.tval32, (hipStream_t) stream));
+    }
+    if (A->rowmap_fmt != nullptr) a.rowmap = A->rowmap_fmt;
+    crp::Team2Args t;
+    t.nteam = A->team2.nteam; t.torder = A->team2.torder; t.tpanel = A->team2.tpanel; t.tinfo = A->team2.tinfo;
+    t.tpro = A->team2.tpro; t.trec = A->team2.trec; t.tvoff = A->team2.tvoff; t.tval = A->team2.tval; t.tval32 = A->team2.tval32;
+    return (int) crp::spmm_rm_f32_team2(t, a, (hipStream_t) stream);
+}
+
 int crp_csr_dev_auto_variant(crp_csr_dev_p A) { return A ? A->auto_variant : -1; }
 int crp_csr_dev_reordered(crp_csr_dev_p A) { return A ? (A->perm.empty() ? 0 : 1) : -1; }
 int crp_csr_dev_resolved_variant(crp_csr_dev_p A, int n)
@@ -682,7 +731,7 @@ int crp_csr_dev_resolved_variant(crp_csr_dev_p A, int n)
     if (A == NULL) return -1;
     int v = A->auto_variant;
     if (v >= 2 && n < 24) v = 1;
-    if (v >= 2 && n >= 96 && A->nrow >= 64 && (n % 2 == 0)) v = 5;
+    if (A->team2_pays && n >= 96 && (n % 2 == 0)) v = 5;
     return v;
 }
 int crp_csr_dev_lattice(crp_csr_dev_p A) { return A ? ((A->team2.built && A->team2.lattice) || (A->team.built && A->team.lattice) ? 1 : 0) : -1; }

@@ -22,6 +22,22 @@ struct SpmmArgs
     const int    *rowmap;   // nullptr, or the C row of every row (row-subset matrices)
 };
 
+struct SpmmArgsF32          // the fp32 path (values, B and C in fp32; BASELINE configs[3])
+{
+    int nrow;
+    int n;
+    const int   *rowptr;
+    const int   *colidx;
+    const float *val;
+    const float *B0;
+    int64_t      ldB0;
+    const float *B1;
+    int64_t      ldB1;
+    float       *C;
+    int64_t      ldC;
+    const int   *rowmap;
+};
+
 struct PanelArgs
 {
     int R;
@@ -60,6 +76,7 @@ struct Team2Args          // panel_format.h, Team2Host
     const uint32_t *trec;      // record blocks (1 KiB each)
     const long long *tvoff;    // 8 * nteam
     const double   *tval;
+    const float    *tval32;    // the same value groups in fp32 (fp32 path), or nullptr
 };
 
 // spmm_kernels.hip
@@ -73,6 +90,11 @@ hipError_t spmm_rm_f64_team(const TeamArgs &t, const SpmmArgs &a, hipStream_t s)
 // team2_kernel.hip
 bool spmm_team2_applicable(const SpmmArgs &a);
 hipError_t spmm_rm_f64_team2(const Team2Args &t, const SpmmArgs &a, hipStream_t s);
+bool spmm_team2_applicable_f32(const SpmmArgsF32 &a);
+hipError_t spmm_rm_f32_team2(const Team2Args &t, const SpmmArgsF32 &a, hipStream_t s);
+
+// spmm_f32.hip: CSR row-group kernel of the fp32 path (any width, both sources)
+hipError_t spmm_rm_f32_rowgroup(const SpmmArgsF32 &a, hipStream_t s);
 
 // row_kernels.hip
 hipError_t gather_rows_f64(int layout, int nidx, int n, const int *ridx, const double *src, int64_t lds,
@@ -80,6 +102,7 @@ hipError_t gather_rows_f64(int layout, int nidx, int n, const int *ridx, const d
 hipError_t scatter_rows_f64(int layout, int nidx, int n, const int *ridx, const double *src, int64_t lds,
                             double *dst, int64_t ldd, hipStream_t s);
 hipError_t scatter_vals_f64(int64_t n, const uint32_t *map, const double *src, double *dst, hipStream_t s);
+hipError_t convert_f64_f32(int64_t n, const double *src, float *dst, hipStream_t s);
 hipError_t transpose_f64(int nrow, int ncol, const double *src, int64_t lds, double *dst, int64_t ldd,
                          hipStream_t s);
 

@@ -95,6 +95,27 @@ long long count_panel_entries(int nrow, const int *rowptr, const int *colidx, in
     return tot;
 }
 
+long long count_block_union(int nrow, const int *rowptr, const int *colidx, int block)
+{
+    const int nblk = (nrow + block - 1) / block;
+    std::vector<long long> part((size_t) host_threads(), 0);
+    parallel_chunks(nblk, 256, [&](long long b, long long e, int tid) {
+        std::vector<int> tmp;
+        long long cnt = 0;
+        for (long long g = b; g < e; g++)
+        {
+            const int r0 = (int) g * block, r1 = std::min(nrow, r0 + block);
+            tmp.assign(colidx + rowptr[r0], colidx + rowptr[r1]);
+            std::sort(tmp.begin(), tmp.end());
+            cnt += (long long) (std::unique(tmp.begin(), tmp.end()) - tmp.begin());
+        }
+        part[(size_t) tid] += cnt;
+    });
+    long long tot = 0;
+    for (long long v : part) tot += v;
+    return tot;
+}
+
 void build_panels(int nrow, const int *rowptr, const int *colidx, const double *val, int R, PanelHost *out,
                   bool team_schedule)
 {

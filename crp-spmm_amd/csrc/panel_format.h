@@ -143,6 +143,10 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
 // to pick R.  colidx may carry the two-source encoding.
 long long count_panel_entries(int nrow, const int *rowptr, const int *colidx, int R);
 
+// Distinct columns of every block of `block` consecutive rows, summed over the blocks: what a team of block / 8
+// consecutive panels would fetch (cheap pass used to decide whether the LDS-sharing kernel pays).
+long long count_block_union(int nrow, const int *rowptr, const int *colidx, int block);
+
 // team_schedule = false keeps the entries of every panel in column order whatever CRPSPMM_PANEL_ORDER
 // says (the team format is built on that order).
 void build_panels(int nrow, const int *rowptr, const int *colidx, const double *val, int R, PanelHost *out,

@@ -153,4 +153,18 @@ hipError_t scatter_vals_f64(int64_t n, const uint32_t *map, const double *src, d
     return hipGetLastError();
 }
 
+// fp32 copy of fp64 values (the fp32 path keeps A's values in fp64 as the caller gave them and derives its own copy)
+__global__ void convert_f64_f32_kernel(const int64_t n, const double *__restrict__ src, float *__restrict__ dst)
+{
+    for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t) gridDim.x * blockDim.x) dst[i] = (float) src[i];
+}
+
+hipError_t convert_f64_f32(int64_t n, const double *src, float *dst, hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    const int blocks = (int) ((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(convert_f64_f32_kernel, dim3(blocks), dim3(256), 0, s, n, src, dst);
+    return hipGetLastError();
+}
+
 }  // namespace crp

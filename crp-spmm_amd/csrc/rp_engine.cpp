@@ -511,7 +511,19 @@ void crp_rp_spmm_exec_ex(crp_rp_spmm_p e, int BC_layout, const double *B, long l
 
 void crp_rp_spmm_exec(crp_rp_spmm_p e, int BC_layout, const double *B, int ldB, double *C, int ldC)
 {
-    crp_rp_spmm_exec_ex(e, BC_layout, B, (long long) ldB, C, (long long) ldC, e ? e->stream : NULL);
+    // The reference's entry point has no stream argument.  Host operands run on the engine's own (non-blocking)
+    // stream.  Device operands were produced, and will be consumed, by work the caller enqueued somewhere the engine
+    // cannot know -- by HIP's rules the null stream orders against that (every blocking stream, and the null stream
+    // itself), the engine's non-blocking stream would not: device operands run on the null stream.
+    void *s = e ? e->stream : NULL;
+    if (e != NULL && !e->plan_only)
+    {
+        int bd = 0, cd = 0;
+        if (B == e->last_B && B != NULL) bd = e->last_B_dev; else crp_dev_ptr_is_device(B, &bd);
+        if (C == e->last_C && C != NULL) cd = e->last_C_dev; else crp_dev_ptr_is_device(C, &cd);
+        if (bd || cd) s = NULL;
+    }
+    crp_rp_spmm_exec_ex(e, BC_layout, B, (long long) ldB, C, (long long) ldC, s);
 }
 
 void crp_rp_spmm_print_stat(crp_rp_spmm_p e)

@@ -93,6 +93,16 @@ class RpSpmm:
         For layout 1 pass the operands as (n, ld) arrays holding the column-major data."""
         bp, ldb, _kb = _ptr_ld(B, BC_layout)
         cp, ldc, _kc = _ptr_ld(C_out, BC_layout)
+        # the kernels index the operands by the plan's sizes: a wrong shape would be an out-of-bounds device access
+        kb = getattr(self, "loc_B_nrow", None)
+        for name, x, rows in (("B", B, kb), ("C", C_out, self.A_nrow)):
+            if rows is None:
+                continue
+            want = (rows, self.glb_n) if BC_layout == 0 else (self.glb_n, rows)
+            got = tuple(x.shape)
+            if (BC_layout == 0 and (got[0] < want[0] or got[1] != want[1])) or \
+               (BC_layout == 1 and (got[0] != want[0] or got[1] < want[1])):
+                raise ValueError("%s has shape %s, the engine needs %s (layout %d)" % (name, got, want, BC_layout))
         if stream is None:
             stream = _current_stream(C_out)
         self._lib.crp_rp_spmm_exec_ex(self.handle, BC_layout, bp, ldb, cp, ldc, stream)

@@ -105,6 +105,50 @@ def kkt3d(g, seed=3):
     return _stencil_csr(2 * N, [(0, g, 1, 0, 1, _OFF27), (0, g, 1, N, 1, _OFF7), (N, g, 1, 0, 1, _OFF7)], seed)
 
 
+def kkt3d_big(g, seed=3, chunk=1 << 21):
+    """The same matrix as kkt3d(g), built without a global sort (kkt3d(241), the nlpkkt240-size stand-in, has 574 M
+    nonzeros): the stencil offsets are taken in ascending linear order, so every row's columns come out ascending and
+    the CSR is written chunk by chunk.  -> (rowptr int32, colidx int32, val float64); identical to kkt3d(g)."""
+    N = g * g * g
+    assert 41 * N < 2 ** 31, "nnz must fit the int32 row pointer of the reference's CSR"
+
+    def offs(pattern):
+        o = sorted(pattern, key=lambda d: d[0] + g * d[1] + g * g * d[2])
+        return np.array(o, dtype=np.int64)
+    o27, o7 = offs(_OFF27), offs(_OFF7)
+    lin27 = o27[:, 0] + g * o27[:, 1] + g * g * o27[:, 2]
+    lin7 = o7[:, 0] + g * o7[:, 1] + g * g * o7[:, 2]
+    rowptr = np.zeros(2 * N + 1, dtype=np.int64)
+    cols_parts, vals_parts = [], []
+
+    def block(row0, nodes, parts):
+        """rows row0 + (nodes - nodes[0]); parts = [(offset triples, linear offsets, column base)]"""
+        x, y, z = nodes % g, (nodes // g) % g, nodes // (g * g)
+        cs, oks = [], []
+        for (o3, lin, base) in parts:
+            ok = ((x[:, None] + o3[None, :, 0] >= 0) & (x[:, None] + o3[None, :, 0] < g) &
+                  (y[:, None] + o3[None, :, 1] >= 0) & (y[:, None] + o3[None, :, 1] < g) &
+                  (z[:, None] + o3[None, :, 2] >= 0) & (z[:, None] + o3[None, :, 2] < g))
+            cs.append(nodes[:, None] + lin[None, :] + base)
+            oks.append(ok)
+        cc, ok = np.concatenate(cs, axis=1), np.concatenate(oks, axis=1)
+        rowptr[row0 + 1:row0 + 1 + nodes.size] = ok.sum(axis=1)
+        rows = np.broadcast_to((row0 + np.arange(nodes.size, dtype=np.int64))[:, None], cc.shape)[ok]
+        cols = cc[ok]
+        lo, hi = np.minimum(rows, cols), np.maximum(rows, cols)
+        u = _u01(lo * np.int64(1 << 26) + hi, seed)
+        cols_parts.append(cols.astype(np.int32))
+        vals_parts.append(np.where(rows == cols, 40.0 + u, 2.0 * u - 1.0))
+
+    for n0 in range(0, N, chunk):
+        nodes = np.arange(n0, min(N, n0 + chunk), dtype=np.int64)
+        block(n0, nodes, [(o27, lin27, 0), (o7, lin7, N)])                 # [H  J^T]
+    for n0 in range(0, N, chunk):
+        nodes = np.arange(n0, min(N, n0 + chunk), dtype=np.int64)
+        block(N + n0, nodes, [(o7, lin7, 0)])                              # [J  0]
+    return np.cumsum(rowptr).astype(np.int32), np.concatenate(cols_parts), np.concatenate(vals_parts)
+
+
 def fem3d(g, dof=3, seed=5):
     """Queen_4147-like stand-in (BASELINE configs[3]): 3D solid mechanics, `dof` unknowns per node of a
     g^3 grid, every node coupled to its 27 neighbours: dof*g^3 rows, up to 27*dof (= 81) nnz/row."""

@@ -187,3 +187,13 @@ def locality_order_host(rowptr, colidx, ncol=None, nparts=8):
     if rc == 1:
         return perm[:m], None
     return perm[:m], dict(groups=int(info[0]), parts=int(info[1]), mean_dist_before=info[2], mean_dist_after=info[3])
+
+
+def spmm_csr_f32(A, B0, C_out, n=None, B1=None, variant=0, stream=None):
+    """crp_spmm_csr_f32: C := A * B with values, B and C in fp32 (row-major float32 torch tensors on the device)."""
+    lib = L.load()
+    if n is None:
+        n = C_out.shape[1]
+    b1p, ldb1 = (B1.data_ptr(), B1.stride(0)) if B1 is not None else (None, 0)
+    L.check(lib.crp_spmm_csr_f32(A.handle, n, B0.data_ptr(), B0.stride(0), b1p, ldb1, C_out.data_ptr(), C_out.stride(0), variant,
+                                 _stream(C_out) if stream is None else stream), "crp_spmm_csr_f32")

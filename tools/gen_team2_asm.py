@@ -44,7 +44,12 @@ NVREG = 26
 NSREG = 14
 
 
-def gen(nv, has_b1):
+def gen(nv, has_b1, f32=False):
+    """nv = 16-byte pieces per lane and row; f32: 4 floats per piece (values 4 bytes, 8 per part = 32 bytes, value
+    slot 128 bytes), else 2 doubles per piece (values 8 bytes, 64 bytes per part, value slot 256 bytes)."""
+    vw = 4 if f32 else 2                            # elements per 16-byte piece
+    vgrp = 32 if f32 else 64                        # bytes of one part's 8 values
+    vslot = 4 * vgrp
     b = VBASE
     A = {"s0": b, "s1": b + 4, "v": b + 8}
     B = {"s0": b + 10, "s1": b + 14, "v": b + 18}
@@ -53,9 +58,9 @@ def gen(nv, has_b1):
     slotb = 1024 * nv
     setb = 8 * slotb
     slot_shift = 11 if nv == 2 else 10
-    seq_align = 9 if nv == 2 else 8                 # 2^9 >= 8 rows x 4 FMAs x 8 bytes + return
+    seq_align = {(1, False): 8, (2, False): 9, (1, True): 9, (2, True): 10}[(nv, f32)]   # 2^x >= 8 rows x nv * vw FMAs x 8 bytes + return
     opr = nv + 1                                    # DMAs a wave issues per round
-    tag = "%d%d_%%=" % (nv, 1 if has_b1 else 0)
+    tag = "%s%d%d_%%=" % ("s" if f32 else "d", nv, 1 if has_b1 else 0)
     L = []
     emit = L.append
 
@@ -65,7 +70,10 @@ def gen(nv, has_b1):
         emit("ds_read_b128 v[%d:%d], v%d offset:%d" % (X["s0"], X["s0"] + 3, TA, k * setb))
         if nv == 2:
             emit("ds_read_b128 v[%d:%d], v%d offset:%d" % (X["s1"], X["s1"] + 3, TA, k * setb + 1024))
-        emit("ds_read_b64 v[%d:%d], %%[vsl] offset:%d" % (X["v"], X["v"] + 1, k * VSLOT + 64 * i))
+        if f32:
+            emit("ds_read_b32 v%d, %%[vsl] offset:%d" % (X["v"], k * vslot + vgrp * i))
+        else:
+            emit("ds_read_b64 v[%d:%d], %%[vsl] offset:%d" % (X["v"], X["v"] + 1, k * vslot + vgrp * i))
 
     def call(i, tb):
         emit("s_bfe_u32 s%d, %%[w1], 0x%x" % (T, (6 << 16) | (6 * i)))
@@ -100,9 +108,9 @@ def gen(nv, has_b1):
         # -- issue for round r + D
         emit("s_bitcmp1_b32 %[w0], 16")
         emit("s_cbranch_scc0 .Lt2ni%d%s" % (k, tag))
-        emit("v_lshl_add_u32 v%d, %%[w2], 6, %%[lane16]" % TV)
-        emit("s_mov_b64 exec, 0xffff")
-        emit("s_add_u32 m0, %%[vringw], %d" % (kd * VSLOT))
+        emit("v_lshl_add_u32 v%d, %%[w2], %d, %%[lane16]" % (TV, 5 if f32 else 6))
+        emit("s_mov_b64 exec, 0x%x" % ((1 << (vslot // 16)) - 1))
+        emit("s_add_u32 m0, %%[vringw], %d" % (kd * vslot))
         emit("s_nop 0")
         emit("global_load_lds_dwordx4 v%d, %%[vbase]" % TV)
         emit("s_mov_b64 exec, -1")
@@ -194,9 +202,13 @@ def gen(nv, has_b1):
                 for r in range(first, first + ln):
                     for v in range(nv):
                         base = X["s0"] if v == 0 else X["s1"]
-                        for w in range(2):
-                            emit("v_fmac_f64_dpp %%[a%d], v[%d:%d], v[%d:%d] row_newbcast:%d row_mask:0xf bank_mask:0xf"
-                                 % ((r * nv + v) * 2 + w, X["v"], X["v"] + 1, base + 2 * w, base + 2 * w + 1, r))
+                        for w in range(vw):
+                            if f32:
+                                emit("v_fmac_f32_dpp %%[a%d], v%d, v%d row_newbcast:%d row_mask:0xf bank_mask:0xf"
+                                     % ((r * nv + v) * vw + w, X["v"], base + w, r))
+                            else:
+                                emit("v_fmac_f64_dpp %%[a%d], v[%d:%d], v[%d:%d] row_newbcast:%d row_mask:0xf bank_mask:0xf"
+                                     % ((r * nv + v) * 2 + w, X["v"], X["v"] + 1, base + 2 * w, base + 2 * w + 1, r))
                 emit("s_setpc_b64 s[%d:%d]" % (RET, RET + 1))
                 code += 1
         assert code == NCODE
@@ -212,10 +224,11 @@ def main():
               % (VBASE, VBASE + NVREG - 1, SBASE, SBASE + NSREG - 1))
     out.write("#define CRP_TEAM2_CLOBBERS %s, %s\n" % (", ".join('"v%d"' % r for r in range(VBASE, VBASE + NVREG)),
                                                       ", ".join('"s%d"' % r for r in range(SBASE, SBASE + NSREG))))
-    for nv in (1, 2):
+    for f32 in (False, True):
+      for nv in (1, 2):
         for hb in (0, 1):
-            out.write("#define CRP_TEAM2_LOOP_NV%d_B%d \\\n" % (nv, hb))
-            lines = gen(nv, bool(hb))
+            out.write("#define CRP_TEAM2_LOOP_%s_NV%d_B%d \\\n" % ("F32" if f32 else "F64", nv, hb))
+            lines = gen(nv, bool(hb), f32)
             for k, l in enumerate(lines):
                 sep = "\\n\\t" if not l.endswith(":") else "\\n"
                 last = k == len(lines) - 1
