@@ -37,7 +37,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s 
 # kernel symbol behind every variant name (what rocprofv3 --kernel-trace shows for it)
 KERNEL_SYMBOL = {"csr-rowgroup": "crp::spmm_rm_f64_kernel<LPR,VW,NV>", "rowpanel-R4": "crp::spmm_panel_f64_kernel<4,...>",
                  "rowpanel-R8": "crp::spmm_panel_f64_kernel<8,...>", "team-R8": "crp::spmm_team_f64_kernel",
-                 "team2-R8": "crp::spmm_team2_f64_kernel<NV,HAS_B1>"}
+                 "team2-R8": "crp::spmm_team2_kernel<double,NV,HAS_B1>"}
 
 
 def find_mtx(args):
@@ -164,6 +164,75 @@ def measured_traffic(matrix, data, n, world, kernel_name):
     except Exception:
         pass
     return None, None
+
+
+def measure_f32(args, matrix, mtx, steps, lib, torch, dev):
+    """--dtype f32 (BASELINE configs[3]): the fp32 value path through the device-level C ABI (crp_spmm_csr_f32), one GPU.
+    Checked against the closed form of the fp64 product at relative Frobenius error 1e-5."""
+    from crp_spmm_amd import hip
+    label, data, m, k, rp, ci, va = build_matrix(matrix, mtx)
+    n, nnz = args.n, int(rp[-1])
+    A = hip.CsrDev(m, k, rp, ci, va)
+    ii = torch.arange(0, k, dtype=torch.float64, device=dev)[:, None]
+    jj = torch.arange(0, n, dtype=torch.float64, device=dev)[None, :]
+    B = ((ii * 0.19 + jj * 0.24) / float(k)).to(torch.float32).contiguous()       # fill_B scaled to O(1): fp32 has 24 bits
+    Cmat = torch.empty((m, n), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        hip.spmm_csr_f32(A, B, Cmat, n=n, variant=args.variant if args.variant in (0, 1, 5) else 0, stream=stream)
+    step()
+    torch.cuda.synchronize()
+    err = None
+    if args.check:
+        rows = np.repeat(np.arange(m), np.diff(rp))
+        s1 = np.bincount(rows, weights=va * ci, minlength=m)
+        s0 = np.bincount(rows, weights=va, minlength=m)
+        sel = np.arange(0, m, max(1, m // 20000))
+        expect = (0.19 * s1[sel, None] + 0.24 * np.arange(n)[None, :] * s0[sel, None]) / float(k)
+        got = Cmat[torch.from_numpy(sel).to(dev)].cpu().numpy().astype(np.float64)
+        err = float(np.linalg.norm(got - expect) / max(np.linalg.norm(expect), 1e-300))
+        if not err <= 1e-5:
+            raise SystemExit("fp32 result check failed, rel. Frobenius error %.3e" % err)
+    for _ in range(args.warmup):
+        step()
+    t_spin = time.perf_counter()
+    while time.perf_counter() - t_spin < 0.25:
+        for _ in range(20):
+            step()
+        torch.cuda.synchronize()
+    ev = [(C.c_void_p(), C.c_void_p()) for _ in range(steps)]
+    for a, b in ev:
+        lib.crp_event_create(C.byref(a))
+        lib.crp_event_create(C.byref(b))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for a, b in ev:
+        lib.crp_event_record(a, stream)
+        step()
+        lib.crp_event_record(b, stream)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ms = C.c_float()
+    per_step = []
+    for a, b in ev:
+        lib.crp_event_elapsed_ms(a, b, C.byref(ms))
+        per_step.append(ms.value)
+        lib.crp_event_destroy(a)
+        lib.crp_event_destroy(b)
+    kern_ms = float(np.mean(per_step))
+    from crp_spmm_amd import gen
+    alg = gen.alg_bytes(m, int(np.unique(ci).size), n, nnz, vb=4)       # A once, needed B rows once, C once, fp32 values
+    rv = int(lib.crp_csr_dev_resolved_variant(A.handle, n)) if args.variant == 0 else args.variant
+    vname = lib.crp_spmm_variant_name(rv if rv in (1, 5) else 1).decode()
+    ki = {"variant": rv, "variant_name": vname, "reordered": bool(lib.crp_csr_dev_reordered(A.handle)), "lattice": bool(lib.crp_csr_dev_lattice(A.handle))}
+    free_b, total_b = torch.cuda.mem_get_info()
+    A.free()
+    return {"hbm_in_use_GB": (total_b - free_b) / 1e9, "label": label, "data": data, "rows": m, "nnz": nnz, "n": n, "grid": "1x1",
+            "value": 2.0 * nnz * n * steps / elapsed / 1e9, "ms_per_step": elapsed / steps * 1e3, "kern_ms": kern_ms, "alg_bytes": alg,
+            "achieved": alg / (kern_ms * 1e-3) / 1e9, "kernel_info": ki,
+            "kernel": {"team2-R8": "crp::spmm_team2_kernel<float,NV,HAS_B1>", "csr-rowgroup": "crp::spmm_rm_f32_kernel<LPR,VW>"}.get(vname, vname),
+            "traffic": None, "traffic_source": None, "first_exec_s": None, "check_rel_err": err}
 
 
 def measure(args, matrix, mtx, steps, lib, torch, dist, comm, dev, world, rank, with_cpu):
@@ -344,6 +413,7 @@ def main():
     ap.add_argument("--matrix", default="pwtk")
     ap.add_argument("--mtx", default=None, help="Matrix-Market file to multiply instead of a generated matrix")
     ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--dtype", default="f64", choices=("f64", "f32"), help="f32: the fp32 value path (one GPU, device-level API)")
     ap.add_argument("--grid", default="amortized", choices=("amortized", "reference"),
                     help="N > 1: planner rule for the process grid (see module docstring)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -378,8 +448,14 @@ def main():
         comm = crp_comm.SelfComm()
 
     mtx = find_mtx(args)
-    main_res = measure(args, args.matrix, mtx, args.steps, lib, torch, dist, comm, dev, world, rank,
-                       with_cpu=(rank == 0 and world == 1 and not args.no_cpu_baseline))
+    if args.dtype == "f32":
+        if world != 1:
+            raise SystemExit("--dtype f32 is a one-GPU measurement")
+        main_res = measure_f32(args, args.matrix, mtx, args.steps, lib, torch, dev)
+        args.no_also = True
+    else:
+        main_res = measure(args, args.matrix, mtx, args.steps, lib, torch, dist, comm, dev, world, rank,
+                           with_cpu=(rank == 0 and world == 1 and not args.no_cpu_baseline))
     also = None
     if world == 1 and mtx is None and args.matrix == "pwtk" and args.variant == 0 and not args.no_also:
         r2 = measure(args, "pwtk_shell", None, min(args.steps, 100), lib, torch, dist, comm, dev, world, rank, with_cpu=False)
@@ -392,10 +468,10 @@ def main():
     what = "pwtk" if (args.matrix == "pwtk" and r["data"] == "real") else \
            ("pwtk stand-in" if args.matrix == "pwtk" else (os.path.basename(mtx) if mtx else args.matrix))
     out = {
-        "metric": "SpMM GFLOP/s (%s n=%d, fp64)" % (what, r["n"]),
+        "metric": "SpMM GFLOP/s (%s n=%d, %s)" % (what, r["n"], "fp32" if args.dtype == "f32" else "fp64"),
         "value": r["value"], "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "f64", "data": r["data"],
+        "dtype": args.dtype, "data": r["data"],
         "config": {"workload": "%s x n=%d, rp_spmm/para2d_spmm exec, operands resident in HBM" % (r["label"], r["n"]),
                    "rows": r["rows"], "nnz": r["nnz"], "n": r["n"], "grid": r["grid"], "kernel_variant": args.variant,
                    "kernel_variant_resolved": r["kernel_info"]["variant_name"],

@@ -598,3 +598,59 @@ def test_locality_order_all_variants(crp, orc, gpu, monkeypatch):
     A = hip.CsrDev(6000, 6000, rp3, ci3, va3)
     assert lib.crp_csr_dev_reordered(A.handle) == 0
     A.free()
+
+
+FP32_TOL = 1e-5      # fp32 path vs the fp64 oracle: relative Frobenius error (there is no fp32 reference: src/rowpara_spmm.h:28)
+
+
+@pytest.mark.parametrize("n", [1024, 300, 128, 52, 7])
+def test_fp32_path_vs_fp64_oracle(crp, orc, gpu, n):
+    """crp_spmm_csr_f32 (BASELINE configs[3]: Queen-class FEM matrix, n = 1024, fp32): the fem3d stand-in and a random
+    matrix, every variant (auto, CSR row-group, team kernel), against the fp64 oracle at FP32_TOL; widths that are not
+    multiples of 4 take the row-group kernel."""
+    import torch
+    from crp_spmm_amd import gen, hip
+    cases = [("fem3d", gen.fem3d(12)), ("random", gen.random_csr(777, 1234, 70, seed=n, empty_every=13))]
+    for name, (rp, ci, va) in cases:
+        m = len(rp) - 1
+        k = max(int(ci.max()) + 1, m) if name == "fem3d" else 1234
+        B = np.random.default_rng(n).uniform(-1, 1, size=(k, n))
+        ref = orc.spmm_csr(rp, ci, va, B)
+        A = hip.CsrDev(m, k, rp, ci, va)
+        Bd = _t(B.astype(np.float32), gpu)
+        for variant in (0, 1, 5):
+            Cd = torch.full((m, n), float("nan"), dtype=torch.float32, device=gpu)
+            hip.spmm_csr_f32(A, Bd, Cd, n=n, variant=variant)
+            torch.cuda.synchronize()
+            got = Cd.cpu().numpy().astype(np.float64)
+            assert orc.rel_fro_err(ref, got) <= FP32_TOL, (name, n, variant, orc.rel_fro_err(ref, got))
+        A.free()
+
+
+def test_fp32_two_source_and_update(crp, orc, gpu):
+    """fp32 path: two-source column index through both kernels, and value updates reaching the fp32 copies."""
+    import torch
+    from crp_spmm_amd import gen, hip
+    lib = crp.load()
+    m, k = 500, 900
+    rp, ci, va = gen.random_csr(m, k, 30, seed=2)
+    lo, hi = 300, 650
+    remote_rows = np.concatenate([np.arange(0, lo), np.arange(hi, k)])
+    pos = np.full(k, -1)
+    pos[remote_rows] = np.arange(remote_rows.size)
+    c2 = np.where((ci >= lo) & (ci < hi), ci - lo, ~pos[ci]).astype(np.int32)
+    n = 200
+    B = np.random.default_rng(1).normal(size=(k, n))
+    A = hip.CsrDev(m, hi - lo, rp, c2, va)
+    B0 = _t(B[lo:hi].astype(np.float32), gpu)
+    B1 = _t(B[remote_rows].astype(np.float32), gpu)
+    for vals in (va, 0.5 * va - 1.0):
+        if vals is not va:
+            assert lib.crp_csr_dev_update_values(A.handle, vals.ctypes.data, None) == 0
+        ref = orc.spmm_csr(rp, ci, vals, B)
+        for variant in (1, 5):
+            Cd = torch.full((m, n), float("nan"), dtype=torch.float32, device=gpu)
+            hip.spmm_csr_f32(A, B0, Cd, n=n, B1=B1, variant=variant)
+            torch.cuda.synchronize()
+            assert orc.rel_fro_err(ref, Cd.cpu().numpy().astype(np.float64)) <= FP32_TOL, variant
+    A.free()

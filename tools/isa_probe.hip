@@ -88,6 +88,43 @@ __global__ __launch_bounds__(64) void saddr_dma(const double *src, double *out)
     for (int i = lane; i < 512; i += 64) out[i] = buf[i];
 }
 
+// 5. fp32 inner block two ways (BASELINE configs[3] names an "MFMA B-tile path"): a block of 4 entries x 16 rows x 256
+//    columns per wave, (a) as 16 x v_mfma_f32_16x16x4_f32 -- every (row, entry) pair multiplied, present or not --,
+//    (b) as v_fmac_f32_dpp only for the present pairs (NPAIR of the 64: fill = NPAIR / 64), 4 FMAs per pair.
+typedef float f4x __attribute__((ext_vector_type(4)));
+__global__ void blk_mfma(float *out, int iters)
+{
+    f4x acc[16];
+    for (int i = 0; i < 16; i++) acc[i] = (f4x) (threadIdx.x * 1e-3f + i);
+    float a = 1.0f + threadIdx.x * 1e-6f, b = 0.5f;
+    for (int it = 0; it < iters; it++)
+    {
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+    }
+    f4x s = acc[0];
+    for (int i = 1; i < 16; i++) s += acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+template <int NPAIR>
+__global__ void blk_fma(float *out, int iters)
+{
+    float acc[64];
+    for (int i = 0; i < 64; i++) acc[i] = threadIdx.x * 1e-3f + i;
+    float va = 1.0f + (threadIdx.x & 15) * 1e-6f, vb = 0.5f;
+    for (int it = 0; it < iters; it++)
+    {
+#pragma unroll
+        for (int p = 0; p < NPAIR; p++)
+#pragma unroll
+            for (int w = 0; w < 4; w++)
+                asm volatile("v_fmac_f32_dpp %0, %1, %2 row_newbcast:5 row_mask:0xf bank_mask:0xf" : "+v"(acc[(p * 4 + w) & 63]) : "v"(va), "v"(vb));
+    }
+    float s = 0;
+    for (int i = 0; i < 64; i++) s += acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 int main()
 {
     int rc = 0;
@@ -173,6 +210,35 @@ int main()
         printf("saddr LDS-DMA with offset:1024: mismatches if offset moves both addresses %ld; if only the global address %ld (ho[0]=%g ho[128]=%g)\n",
                both, alt, ho[0], ho[128]);
         if (both != 0) rc = rc ? rc : 0;        // informational: the kernel picks the form that matches
+    }
+    // ---- 5. fp32 block: MFMA against masked FMAs
+    {
+        float *d;
+        hipMalloc(&d, 4 * 2000000);
+        const int threads = 1024, blocks = 256, iters = 4000;       // 4 waves per SIMD
+        auto timeit = [&](auto launch) {
+            hipEvent_t e0, e1;
+            hipEventCreate(&e0); hipEventCreate(&e1);
+            float ms = 0;
+            for (int rep = 0; rep < 2; rep++)
+            {
+                hipEventRecord(e0);
+                launch();
+                hipEventRecord(e1);
+                hipEventSynchronize(e1);
+                hipEventElapsedTime(&ms, e0, e1);
+            }
+            return ms;
+        };
+        const double blocks_per_simd = (double) iters * 4;          // blocks (4 entries x 16 rows x 256 columns) per SIMD
+        const float t_mfma = timeit([&] { blk_mfma<<<blocks, threads>>>(d, iters); });
+        const float t_f64 = timeit([&] { blk_fma<64><<<blocks, threads>>>(d, iters); });
+        const float t_f38 = timeit([&] { blk_fma<38><<<blocks, threads>>>(d, iters); });
+        const float t_f32 = timeit([&] { blk_fma<32><<<blocks, threads>>>(d, iters); });
+        printf("fp32 block of 4 entries x 16 rows x 256 columns, ns per block per SIMD (4 waves per SIMD):\n"
+               "  16 x v_mfma_f32_16x16x4_f32 (all 64 pairs)      %.1f\n  v_fmac_f32_dpp, fill 1.00 (64 pairs, 256 FMAs) %.1f\n"
+               "  v_fmac_f32_dpp, fill 0.60 (38 pairs)            %.1f\n  v_fmac_f32_dpp, fill 0.50 (32 pairs)            %.1f\n",
+               t_mfma * 1e6 / blocks_per_simd, t_f64 * 1e6 / blocks_per_simd, t_f38 * 1e6 / blocks_per_simd, t_f32 * 1e6 / blocks_per_simd);
     }
     return rc;
 }
