@@ -215,7 +215,13 @@ static int ensure_team2(crp_csr_dev *A)
     crp::build_panels(A->nrow, fmt_rowptr(A), fmt_colidx(A), fmt_val(A), 8, &h, false);
     fmt_slotmap_to_caller(A, &h.pmap);
     crp::Team2Host th;
-    crp::build_team2(h, A->nrow, fmt_rowptr(A), fmt_colidx(A), &th);
+    std::vector<int> colpos;                    // position of every row in the processing order (square, re-ordered matrices)
+    if (!A->perm.empty())
+    {
+        colpos.resize(A->perm.size());
+        for (size_t i = 0; i < A->perm.size(); i++) colpos[(size_t) A->perm[i]] = (int) i;
+    }
+    crp::build_team2(h, A->nrow, fmt_rowptr(A), fmt_colidx(A), &th, colpos.empty() ? nullptr : colpos.data());
     t.nteam = th.nteam;
     t.entries = th.real_entries;
     t.lattice = th.lattice;

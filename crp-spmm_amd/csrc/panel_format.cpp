@@ -686,11 +686,26 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
 }
 
 // ---- team2 streams (panel_format.h) ------------------------------------------------------------------
-void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *colidx, Team2Host *out)
+void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *colidx, Team2Host *out, const int *colpos)
 {
     constexpr int T = TEAM2_T, D = TEAM2_D, CAP = TEAM2_CAP;
     TeamHost th;
     build_teams(p, nrow, rowptr, colidx, &th, T);
+    // Phase key of a union entry: (position of its B row in the processing order) mod S, S = rows a team advances
+    // along its sweep (8 x the consecutive panels of a lattice team, 64 for eight consecutive panels).  Teams are
+    // dealt to the workgroups of an XCD in order and start a fraction of a microsecond apart; a B row shared by
+    // neighbouring teams sits S positions further in the next one.  Walking every team's union by this key makes
+    // all its readers ask for it at the same point of their lives, i.e. within the few microseconds a line
+    // survives in the XCD's L2 -- instead of at unrelated moments of 35-microsecond lives.
+    // CRPSPMM_TEAM2_PHASE=0 keeps the balanced order of build_teams().
+    int S = 64;
+    if (th.lattice)
+    {
+        int st = 2, a = 0, b = 0, c = 0;
+        if (const char *es = getenv("CRPSPMM_TEAM2_SHAPE"); es != NULL && sscanf(es, "%d,%d,%d", &a, &b, &c) == 3 && a * b * c == 8) st = c;
+        S = 8 * st;
+    }
+    static const bool phase = getenv("CRPSPMM_TEAM2_PHASE") == NULL || atoi(getenv("CRPSPMM_TEAM2_PHASE")) != 0;
     const int nteam = th.nteam;
     out->nteam = nteam;
     out->lattice = th.lattice;
@@ -718,6 +733,15 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
                 bool used = false;
                 for (int w = 0; w < T; w++) used = used || th.tsrc[(size_t) q * T + (size_t) w] >= 0;
                 if (used) nodes.push_back(q);
+            }
+            if (phase)
+            {
+                auto key = [&](int q) {
+                    const int c = th.tcol[(size_t) q];
+                    const long long ps = c >= 0 ? (colpos ? colpos[c] : c) : (long long) (~c);
+                    return (int) (ps % S);
+                };
+                std::stable_sort(nodes.begin(), nodes.end(), [&](int x, int y) { return key(x) < key(y); });
             }
             // contiguous row ranges of every (node, wave)
             auto ranges = [&](unsigned m, Part *dst) {

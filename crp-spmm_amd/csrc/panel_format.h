@@ -137,7 +137,9 @@ struct Team2Host
 };
 // p must hold its entries in column order (build_panels(..., team_schedule = false)); p.pmap is consumed to
 // build vmap (indexed like p.pmap: by the CSR nonzero position the panels were built from).
-void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *colidx, Team2Host *out);
+// colpos (optional, square matrices in a locality order): position of row c of B in the processing order of the
+// rows of A, for the phase key of the union order (see build_team2); NULL = the column index itself.
+void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *colidx, Team2Host *out, const int *colpos = nullptr);
 
 // Number of panel entries (before padding) a given R would need: cheap pass used
 // to pick R.  colidx may carry the two-source encoding.
