@@ -32,7 +32,11 @@ The reads of part i + 1 are issued before the wait for part i.
 
 usage: tools/gen_team2_asm.py > crp-spmm_amd/csrc/team2_consume.inc
 """
+import os
 import sys
+
+# cache policy of the B-row DMA (experiment knob at generation time): '', ' nt', ' sc0', ' sc1', ' sc0 sc1'
+BPOL = os.environ.get('T2_BPOL', '')
 
 D = 3
 NSET = 4
@@ -133,9 +137,9 @@ def gen(nv, has_b1, f32=False):
             emit(".Lt2bj%d%s:" % (k, tag))
         emit("s_add_u32 m0, %%[wslot], %d" % (kd * setb))
         emit("s_nop 0")
-        emit("global_load_lds_dwordx4 %%[voffa], s[%d:%d]" % (RB, RB + 1))
+        emit("global_load_lds_dwordx4 %%[voffa], s[%d:%d]%s" % (RB, RB + 1, BPOL))
         if nv == 2:
-            emit("global_load_lds_dwordx4 %%[voffb], s[%d:%d] offset:1024" % (RB, RB + 1))
+            emit("global_load_lds_dwordx4 %%[voffb], s[%d:%d] offset:1024%s" % (RB, RB + 1, BPOL))
         emit(".Lt2ni%d%s:" % (k, tag))
         # -- next record block (one wave, every 8 rounds)
         emit("s_bitcmp1_b32 %[w0], 19")
