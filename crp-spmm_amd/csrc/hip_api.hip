@@ -43,6 +43,7 @@ struct Team2Dev
 {
     bool built = false;
     int  nteam = 0;
+    int ngrid = 0;                 // entries of torder (= the launch grid, 8 equal runs, -1 = no team)
     int *torder = nullptr, *tpanel = nullptr, *tinfo = nullptr, *tpro = nullptr;
     uint32_t *trec = nullptr;
     long long *tvoff = nullptr;
@@ -231,7 +232,8 @@ static int ensure_team2(crp_csr_dev *A)
         if (e == hipSuccess && bytes) e = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
         return e;
     };
-    hipError_t e = up((void **) &t.torder, th.torder.data(), sizeof(int) * th.torder.size(), 4);
+    t.ngrid = (int) th.tgrid.size();
+    hipError_t e = up((void **) &t.torder, th.tgrid.data(), sizeof(int) * th.tgrid.size(), 4);      // the launch grid (panel_format.h)
     if (e == hipSuccess) e = up((void **) &t.tpanel, th.tpanel.data(), sizeof(int) * th.tpanel.size(), 4);
     if (e == hipSuccess) e = up((void **) &t.tinfo, th.tinfo.data(), sizeof(int) * th.tinfo.size(), 16);
     if (e == hipSuccess) e = up((void **) &t.tpro, th.tpro.data(), sizeof(int) * th.tpro.size(), 8);
@@ -664,7 +666,7 @@ int crp_spmm_csr_f64(crp_csr_dev_p A, int layout, int n, const double *B0, long 
         const int rc = ensure_team2(A);
         if (rc != 0) return rc;
         crp::Team2Args t;
-        t.nteam = A->team2.nteam; t.torder = A->team2.torder; t.tpanel = A->team2.tpanel; t.tinfo = A->team2.tinfo;
+        t.nteam = A->team2.nteam; t.ngrid = A->team2.ngrid; t.torder = A->team2.torder; t.tpanel = A->team2.tpanel; t.tinfo = A->team2.tinfo;
         t.tpro = A->team2.tpro; t.trec = A->team2.trec; t.tvoff = A->team2.tvoff; t.tval = A->team2.tval; t.tval32 = nullptr;
         return (int) crp::spmm_rm_f64_team2(t, a, (hipStream_t) stream);
     }
@@ -725,7 +727,7 @@ int crp_spmm_csr_f32(crp_csr_dev_p A, int n, const float *B0, long long ldB0, co
     }
     if (A->rowmap_fmt != nullptr) a.rowmap = A->rowmap_fmt;
     crp::Team2Args t;
-    t.nteam = A->team2.nteam; t.torder = A->team2.torder; t.tpanel = A->team2.tpanel; t.tinfo = A->team2.tinfo;
+    t.nteam = A->team2.nteam; t.ngrid = A->team2.ngrid; t.torder = A->team2.torder; t.tpanel = A->team2.tpanel; t.tinfo = A->team2.tinfo;
     t.tpro = A->team2.tpro; t.trec = A->team2.trec; t.tvoff = A->team2.tvoff; t.tval = A->team2.tval; t.tval32 = A->team2.tval32;
     return (int) crp::spmm_rm_f32_team2(t, a, (hipStream_t) stream);
 }

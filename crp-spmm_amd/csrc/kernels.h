@@ -69,6 +69,7 @@ struct TeamArgs
 struct Team2Args          // panel_format.h, Team2Host
 {
     int nteam;
+    int ngrid;                 // entries of torder: the launch grid (Team2Host::tgrid), a multiple of 8
     const int      *torder;
     const int      *tpanel;    // 8 * nteam
     const int      *tinfo;     // 4 * nteam: rounds, first record block, union entries, 0

@@ -430,6 +430,116 @@ void locality_order(const PanelHost &p, int group, std::vector<int> *order)
 }
 
 // ---- teams: four panels whose B rows one workgroup loads once (panel_format.h) --------------------
+
+// ---- greedy clustering (teams of panels, super-teams of teams) -----------------------------------------
+// Items carry sorted lists of distinct keys (CSR iptr / ikey).  Groups of up to G items are grown from the lowest
+// unassigned item by repeatedly adding the unassigned item that shares most keys with the group's union (ties: the
+// nearest index).  Work per group: the union's keys times the items per key.  Items are handled in independent
+// ranges of `span` items (threads), a group never crosses a range.  -> group of every item, in creation order;
+// slot = its position inside the group.
+static void greedy_cluster(int n, const std::vector<long long> &iptr, const std::vector<uint32_t> &ikey, int G, int span,
+                           std::vector<int> *group_of, std::vector<int> *slot_of, int *ngroups)
+{
+    group_of->assign((size_t) n, -1);
+    slot_of->assign((size_t) n, 0);
+    const int nrange = (n + span - 1) / span;
+    std::vector<int> range_groups((size_t) nrange, 0);
+    parallel_chunks(nrange, 1, [&](long long rb, long long re, int) {
+        for (long long rg = rb; rg < re; rg++)
+        {
+            const int i0 = (int) rg * span, i1 = std::min(n, i0 + span), cnt = i1 - i0;
+            // inverted index of the range: (key, item) pairs sorted by key
+            std::vector<std::pair<uint32_t, int>> pairs;
+            pairs.reserve((size_t) (iptr[(size_t) i1] - iptr[(size_t) i0]));
+            for (int i = i0; i < i1; i++)
+                for (long long q = iptr[(size_t) i]; q < iptr[(size_t) i + 1]; q++) pairs.push_back({ikey[(size_t) q], i - i0});
+            std::sort(pairs.begin(), pairs.end());
+            // dense local key ids
+            std::vector<long long> kptr;
+            std::vector<int> kitem(pairs.size());
+            std::vector<int> lkey(pairs.size());               // per pair (in item order below): local key id
+            for (size_t t = 0; t < pairs.size(); t++)
+            {
+                if (t == 0 || pairs[t].first != pairs[t - 1].first) kptr.push_back((long long) t);
+                kitem[t] = pairs[t].second;
+            }
+            kptr.push_back((long long) pairs.size());
+            // item -> local key ids (same order as ikey)
+            std::vector<long long> lptr((size_t) cnt + 1, 0);
+            for (int i = 0; i < cnt; i++) lptr[(size_t) i + 1] = lptr[(size_t) i] + (iptr[(size_t) (i0 + i) + 1] - iptr[(size_t) (i0 + i)]);
+            {
+                std::vector<long long> fill(lptr.begin(), lptr.end() - 1);
+                const int nk = (int) kptr.size() - 1;
+                for (int kk = 0; kk < nk; kk++)
+                    for (long long t = kptr[(size_t) kk]; t < kptr[(size_t) kk + 1]; t++) lkey[(size_t) fill[(size_t) kitem[(size_t) t]]++] = kk;
+            }
+            const int nk = (int) kptr.size() - 1;
+            std::vector<char> assigned((size_t) cnt, 0), inkey((size_t) nk, 0);
+            std::vector<int> cc((size_t) cnt, 0), touched, ukeys;
+            int seed = 0, groups = 0;
+            auto add = [&](int it) {
+                for (long long q = lptr[(size_t) it]; q < lptr[(size_t) it + 1]; q++)
+                {
+                    const int kk = lkey[(size_t) q];
+                    if (inkey[(size_t) kk]) continue;
+                    inkey[(size_t) kk] = 1;
+                    ukeys.push_back(kk);
+                    for (long long t = kptr[(size_t) kk]; t < kptr[(size_t) kk + 1]; t++)
+                    {
+                        const int r = kitem[(size_t) t];
+                        if (assigned[(size_t) r]) continue;
+                        if (cc[(size_t) r]++ == 0) touched.push_back(r);
+                    }
+                }
+            };
+            for (;;)
+            {
+                while (seed < cnt && assigned[(size_t) seed]) seed++;
+                if (seed >= cnt) break;
+                const int gid = groups++;
+                int members = 0;
+                auto take = [&](int it) {
+                    assigned[(size_t) it] = 1;
+                    (*group_of)[(size_t) (i0 + it)] = gid;          // range-local id, made global below
+                    (*slot_of)[(size_t) (i0 + it)] = members++;
+                    add(it);
+                };
+                take(seed);
+                while (members < G)
+                {
+                    int best = -1, bo = 0;
+                    for (int r : touched)
+                    {
+                        if (assigned[(size_t) r]) continue;
+                        const int o = cc[(size_t) r];
+                        if (o > bo || (o == bo && best >= 0 && std::abs(r - seed) < std::abs(best - seed))) { best = r; bo = o; }
+                    }
+                    if (best < 0)
+                    {
+                        // nothing shares a key with the group (isolated rows, empty panels): the next unassigned item
+                        int nx = seed;
+                        while (nx < cnt && assigned[(size_t) nx]) nx++;
+                        if (nx >= cnt) break;
+                        best = nx;
+                    }
+                    take(best);
+                }
+                for (int r : touched) cc[(size_t) r] = 0;
+                touched.clear();
+                for (int kk : ukeys) inkey[(size_t) kk] = 0;
+                ukeys.clear();
+            }
+            range_groups[(size_t) rg] = groups;
+        }
+    });
+    std::vector<int> base((size_t) nrange + 1, 0);
+    for (int rg = 0; rg < nrange; rg++) base[(size_t) rg + 1] = base[(size_t) rg] + range_groups[(size_t) rg];
+    parallel_chunks(n, 1 << 16, [&](long long b, long long e, int) {
+        for (long long i = b; i < e; i++) (*group_of)[(size_t) i] += base[(size_t) (i / span)];
+    });
+    *ngroups = base[(size_t) nrange];
+}
+
 void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *colidx, TeamHost *out, int T)
 {
     constexpr int TMAX = 8;
@@ -456,11 +566,93 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
         }
     }
     out->lattice = lattice;
+    auto real_count = [&](int panel) {
+        int c = 0;
+        for (int q = p.pptr[panel]; q < p.pptr[panel + 1]; q++)
+        {
+            const unsigned m = (p.pmask4[(size_t) q >> 2] >> (8 * (q & 3))) & 0xFFu;
+            if (m == 0) break;          // padding starts here: real entries always carry a row
+            c++;
+        }
+        return c;
+    };
+    // Off a lattice, teams of eight are CLUSTERED: the eight panels of a team are picked for the columns they share
+    // (greedy_cluster), not for being consecutive -- on a 3-D stencil in natural order eight consecutive panels are
+    // a thin strip of one grid line (9.9 union entries per row on the 27-point fem3d stand-in), a cluster is a
+    // compact block (6.9); nlpkkt stand-in 7.1 (its lattice teams) -> 4.4.  CRPSPMM_TEAM2_CLUSTER=0 turns it off.
+    static const bool cluster_on = getenv("CRPSPMM_TEAM2_CLUSTER") == NULL || atoi(getenv("CRPSPMM_TEAM2_CLUSTER")) != 0;
+    static const bool cluster_lattice = getenv("CRPSPMM_TEAM2_CLUSTER") != NULL && atoi(getenv("CRPSPMM_TEAM2_CLUSTER")) == 2;
+    if (T == 8 && cluster_lattice) lattice = out->lattice = false;
+    bool clustered = T == 8 && cluster_on && np >= 16;
+    std::vector<int> team_of, slot_of;
+    if (clustered)
+    {
+        std::vector<long long> iptr((size_t) np + 1, 0);
+        std::vector<uint32_t> ikey;
+        ikey.reserve(p.pcol.size());
+        for (int q = 0; q < np; q++)
+        {
+            const int e0 = p.pptr[q], e1 = e0 + real_count(q);
+            const size_t at = ikey.size();
+            for (int e = e0; e < e1; e++) ikey.push_back(col_key(p.pcol[(size_t) e]));
+            std::sort(ikey.begin() + (long) at, ikey.end());
+            ikey.erase(std::unique(ikey.begin() + (long) at, ikey.end()), ikey.end());
+            iptr[(size_t) q + 1] = (long long) ikey.size();
+        }
+        int ng = 0;
+        greedy_cluster(np, iptr, ikey, T, 1 << 15, &team_of, &slot_of, &ng);
+        if (lattice)
+        {
+            // A lattice has both: its tooth-shaped teams sweep in lockstep along the teeth and re-fetch less (pwtk
+            // stand-in: 1.8 x B against 2.1 x B for clusters with 5.0 / 4.9 union entries per row), so they stay
+            // unless the clusters need clearly fewer B rows (nlpkkt stand-in: 7.1 -> 4.5 entries per row).
+            // Union entries of a grouping = distinct (group, column) pairs.
+            auto union_total = [&](auto group_of_panel) {
+                std::vector<std::pair<long long, int>> ord((size_t) np);
+                for (int q = 0; q < np; q++) ord[(size_t) q] = {group_of_panel(q), q};
+                std::sort(ord.begin(), ord.end());
+                std::vector<size_t> gs;
+                for (size_t t = 0; t < ord.size(); t++)
+                    if (t == 0 || ord[t].first != ord[t - 1].first) gs.push_back(t);
+                gs.push_back(ord.size());
+                const int ngr = (int) gs.size() - 1;
+                std::vector<long long> part((size_t) ngr, 0);
+                parallel_chunks(ngr, 256, [&](long long b, long long e, int) {
+                    std::vector<uint32_t> keys;
+                    for (long long g = b; g < e; g++)
+                    {
+                        keys.clear();
+                        for (size_t t = gs[(size_t) g]; t < gs[(size_t) g + 1]; t++)
+                        {
+                            const int q = ord[t].second;
+                            keys.insert(keys.end(), ikey.begin() + (long) iptr[(size_t) q], ikey.begin() + (long) iptr[(size_t) q + 1]);
+                        }
+                        std::sort(keys.begin(), keys.end());
+                        part[(size_t) g] = (long long) (std::unique(keys.begin(), keys.end()) - keys.begin());
+                    }
+                });
+                long long tot = 0;
+                for (long long v : part) tot += v;
+                return tot;
+            };
+            const long long u_cl = union_total([&](int q) { return (long long) team_of[(size_t) q]; });
+            const long long u_la = union_total([&](int q) {
+                int i, j, t;
+                lattice_coords(q, R, D1, D2, M, &i, &j, &t);
+                return ((long long) (i / si) << 40) | ((long long) (j / sj) << 24) | (long long) (t / st);
+            });
+            if ((double) u_la <= 1.15 * (double) u_cl) clustered = false;
+            else lattice = out->lattice = false;
+        }
+    }
+    out->clustered = clustered;
+    if (clustered) out->plocal = slot_of;
     // membership: (team key, slot)
     struct Mem { long long key; int slot, panel, a, b, t; };
     std::vector<Mem> mem((size_t) np);
     for (int q = 0; q < np; q++)
     {
+        if (clustered) { mem[(size_t) q] = {(long long) team_of[(size_t) q], slot_of[(size_t) q], q, 0, 0, team_of[(size_t) q]}; continue; }
         if (lattice)
         {
             int i, j, t;
@@ -496,16 +688,6 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
     out->nteam = nteam;
 
     // union entry lists: 4-way merge by (column key, occurrence inside the panel)
-    auto real_count = [&](int panel) {
-        int c = 0;
-        for (int q = p.pptr[panel]; q < p.pptr[panel + 1]; q++)
-        {
-            const unsigned m = (p.pmask4[(size_t) q >> 2] >> (8 * (q & 3))) & 0xFFu;
-            if (m == 0) break;          // padding starts here: real entries always carry a row
-            c++;
-        }
-        return c;
-    };
     std::vector<int> cnt((size_t) nteam, 0);
     std::vector<std::vector<int>> ucol((size_t) nteam);
     std::vector<std::vector<uint32_t>> umask((size_t) nteam);
@@ -666,6 +848,31 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
     // else the natural order
     out->torder.resize((size_t) nteam);
     for (int g = 0; g < nteam; g++) out->torder[(size_t) g] = g;
+    if (clustered && nteam >= 128)
+    {
+        // Clustered teams: the workgroups resident on an XCD at one time (64: 32 CUs x 2) start together and walk
+        // their unions by the same phase key, so rows shared INSIDE such a generation are requested together and
+        // served by the XCD's L2 once.  Generations = super-teams of 64 teams clustered by shared columns, again
+        // greedily; the kernel deals the order to the XCDs in eight contiguous runs.
+        std::vector<long long> iptr((size_t) nteam + 1, 0);
+        std::vector<uint32_t> ikey;
+        ikey.reserve((size_t) real);
+        for (int g = 0; g < nteam; g++)
+        {
+            const size_t at = ikey.size();
+            for (int c : ucol[(size_t) g]) ikey.push_back(col_key(c));
+            std::sort(ikey.begin() + (long) at, ikey.end());
+            ikey.erase(std::unique(ikey.begin() + (long) at, ikey.end()), ikey.end());
+            iptr[(size_t) g + 1] = (long long) ikey.size();
+        }
+        std::vector<int> super_of, sslot;
+        int ns = 0;
+        greedy_cluster(nteam, iptr, ikey, 64, 1 << 13, &super_of, &sslot, &ns);
+        std::sort(out->torder.begin(), out->torder.end(), [&](int x, int y) {
+            if (super_of[(size_t) x] != super_of[(size_t) y]) return super_of[(size_t) x] < super_of[(size_t) y];
+            return sslot[(size_t) x] < sslot[(size_t) y];
+        });
+    }
     if (lattice)
     {
         const int chunk = (nteam + 7) / 8;
@@ -739,6 +946,8 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
                 auto key = [&](int q) {
                     const int c = th.tcol[(size_t) q];
                     const long long ps = c >= 0 ? (colpos ? colpos[c] : c) : (long long) (~c);
+                    // clustered teams (square part): where the row of A with this number sits inside ITS team
+                    if (th.clustered && c >= 0 && ps / 8 < (long long) th.plocal.size()) return (int) (ps % 8) * 8 + th.plocal[(size_t) (ps / 8)];      // (row of the panel, slot): neighbours in the order belong to different waves
                     return (int) (ps % S);
                 };
                 std::stable_sort(nodes.begin(), nodes.end(), [&](int x, int y) { return key(x) < key(y); });
@@ -829,6 +1038,27 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
         }
     }
     out->tvoff[(size_t) nteam * T] = run;
+    // launch grid: the order cut into 8 contiguous pieces of equal work (rounds + a fixed cost per team), one per
+    // XCD -- pieces of equal team COUNT leave XCDs idle when the teams differ (KKT systems: 27-point primal rows,
+    // short dual rows; 73 % of the wave slots busy on the nlpkkt stand-in)
+    {
+        long long total = 0;
+        for (int g = 0; g < nteam; g++) total += res[(size_t) g].nr + 4;
+        std::vector<int> cut(9, nteam);
+        cut[0] = 0;
+        long long acc = 0;
+        int x = 1;
+        for (int i = 0; i < nteam && x < 8; i++)
+        {
+            acc += res[(size_t) out->torder[(size_t) i]].nr + 4;
+            while (x < 8 && acc * 8 >= total * x) cut[(size_t) x++] = i + 1;
+        }
+        int cpx = 1;
+        for (int q = 0; q < 8; q++) cpx = std::max(cpx, cut[(size_t) q + 1] - cut[(size_t) q]);
+        out->tgrid.assign((size_t) cpx * 8, -1);
+        for (int q = 0; q < 8; q++)
+            for (int i = cut[(size_t) q]; i < cut[(size_t) q + 1]; i++) out->tgrid[(size_t) q * cpx + (size_t) (i - cut[(size_t) q])] = out->torder[(size_t) i];
+    }
     out->trec.assign((size_t) blk0[(size_t) nteam] * 256 + 256, 0u);
     out->tval.assign((size_t) run * 8, 0.0);
     // vmap through the panel format's slot map: pmap[nz] = q * 8 + row of the panel format

@@ -78,6 +78,8 @@ struct TeamHost
     int nteam = 0;
     int T = 4;                     // panels (= waves) per team: 4 (2 x 2 teeth) or 6 (3 x 2 teeth)
     bool lattice = false;
+    bool clustered = false;        // T = 8 off a lattice: panels grouped by shared columns (plocal = slot of every panel in its team)
+    std::vector<int>      plocal;
     std::vector<int>      tpanel;  // T * nteam: panel of wave w, or -1
     std::vector<int>      tptr;    // nteam + 1: union entry offsets (multiples of PANEL_PAD)
     std::vector<int>      tcol;    // union entries: column index
@@ -125,6 +127,8 @@ struct Team2Host
     bool lattice = false;
     std::vector<int>       tpanel;   // 8 * nteam: panel of wave w, or -1
     std::vector<int>       torder;   // processing order of the teams
+    std::vector<int>       tgrid;    // the launch grid: 8 runs of tgrid.size() / 8 entries, run x = what XCD x processes, in
+                                     // order (a contiguous piece of torder; -1 = no team); the pieces carry equal ROUNDS
     std::vector<int>       tinfo;    // 4 * nteam: rounds, first record block, parts of all waves, filled slots
     std::vector<int>       tpro;     // nteam * TEAM2_D * 8 * 2: {column, value offset} wave w fetches for round d < TEAM2_D
     std::vector<uint32_t>  trec;     // record blocks: 256 words each

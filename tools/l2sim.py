@@ -32,12 +32,22 @@ def team_rounds(t):
     return out
 
 
+def xcd_queues(rounds, order, nxcd=8):
+    """The launch grid of build_team2 (csrc/panel_format.cpp): the order cut into pieces of equal rounds + 4 per team."""
+    w = [len(rounds[g]) + 4 for g in order]
+    total, acc, cuts, x = sum(w), 0, [0], 1
+    for i, wi in enumerate(w):
+        acc += wi
+        while x < nxcd and acc * nxcd >= total * x:
+            cuts.append(i + 1)
+            x += 1
+    cuts += [len(order)] * (nxcd + 1 - len(cuts))
+    return [list(order[cuts[q]:cuts[q + 1]]) for q in range(nxcd)]
+
+
 def simulate(rounds, order, rows, wgs, nxcd=8):
-    nteam = len(order)
-    cpx = (nteam + nxcd - 1) // nxcd
     miss = req = 0
-    for x in range(nxcd):
-        queue = [order[i] for i in range(x * cpx, min(nteam, (x + 1) * cpx))]
+    for queue in xcd_queues(rounds, list(order), nxcd):
         lru = OrderedDict()
         active = []                                       # [team, next round]
         qi = 0
