@@ -616,8 +616,12 @@ def test_team2_streams_replay(crp, orc):
     from crp_spmm_amd import gen, hip
     rng = np.random.default_rng(2)
     cases = []
+    # pwtk-like bands (a near band of 14, two far bands of 6): the tooth-shaped lattice teams are kept
+    offs = tuple(range(1, 15)) + tuple(range(304, 310)) + tuple(range(3040, 3046))
+    cases.append(("lattice",) + gen.banded_fem(9120, offsets=offs, seed=3))
+    # a thin 3-D stencil: also a lattice, but teams clustered by shared columns need fewer B rows and win
     nx, ny, nz = 300, 5, 3
-    cases.append(("lattice",) + gen.banded_fem(nx * ny * nz, offsets=(1, 2, 3, nx, nx + 1, nx * ny, nx * ny + 1), seed=3))
+    cases.append(("clustered",) + gen.banded_fem(nx * ny * nz, offsets=(1, 2, 3, nx, nx + 1, nx * ny, nx * ny + 1), seed=3))
     cases.append(("random",) + gen.random_csr(611, 611, 14, seed=5, empty_every=9))
     cases.append(("tiny",) + gen.random_csr(13, 40, 5, seed=1))
     rp, ci, va = gen.random_csr(200, 64, 6, seed=8)
@@ -630,8 +634,12 @@ def test_team2_streams_replay(crp, orc):
         t = hip.team2_format_host(rp, ci, va)
         assert np.array_equal(np.sort(t["tpanel"][t["tpanel"] >= 0]), np.arange((m + 7) // 8)), name
         assert np.array_equal(np.sort(t["torder"]), np.arange(t["nteam"])), name
-        if name == "lattice":
-            assert t["lattice"]
+        if name in ("lattice", "clustered"):
+            assert t["lattice"] == (name == "lattice")
+        if name in ("clustered", "random"):
+            # clustered teams are not runs of consecutive panels
+            tp = t["tpanel"]
+            assert any(np.any(np.diff(np.sort(row[row >= 0])) != 1) for row in tp), name
         B = rng.uniform(-1, 1, size=(k, 3))
         got = _replay_team2(t, m, B, va)
         ref = orc.spmm_csr(rp, ci, va, B)
