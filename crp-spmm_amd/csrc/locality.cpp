@@ -123,6 +123,51 @@ void part_order(const Graph &g, const std::vector<int> &part, int pid, const std
     }
 }
 
+
+// Steps 2 and 3 of the header comment on any weighted graph: `nparts` (a power of two) parts of equal weight by
+// recursive bisection along breadth-first level structures, reverse Cuthill-McKee inside every part.
+// -> the vertices part after part; first[q] = where part q starts in that order (nparts + 1 entries).
+void slab_order(const Graph &g, int nparts, std::vector<int> *gorder_out, std::vector<int> *first)
+{
+    const int ng = g.n;
+    int depth = 0;
+    while ((1 << depth) < nparts) depth++;
+    std::vector<int> part((size_t) ng, 0), mark((size_t) ng, 0), level((size_t) ng, 0), placed((size_t) ng, 0), scratch, order;
+    int stamp = 0;
+    std::vector<std::vector<int>> members(1);
+    members[0].resize((size_t) ng);
+    std::iota(members[0].begin(), members[0].end(), 0);
+    for (int d = 0; d < depth; d++)
+    {
+        std::vector<std::vector<int>> next(members.size() * 2);
+        for (size_t pid = 0; pid < members.size(); pid++)
+        {
+            // (part ids are re-assigned after every level: vertex v of part pid goes to 2 pid or 2 pid + 1)
+            part_order(g, part, (int) pid, members[pid], false, stamp, mark, level, placed, scratch, order);
+            long long total = 0, run = 0;
+            for (int v : order) total += g.weight[(size_t) v];
+            size_t cut = 0;
+            while (cut < order.size() && (run + g.weight[(size_t) order[cut]] / 2) * 2 < total) run += g.weight[(size_t) order[cut++]];
+            next[2 * pid].assign(order.begin(), order.begin() + (long) cut);
+            next[2 * pid + 1].assign(order.begin() + (long) cut, order.end());
+        }
+        members.swap(next);
+        for (size_t pid = 0; pid < members.size(); pid++)
+            for (int v : members[pid]) part[(size_t) v] = (int) pid;
+    }
+    // ---- 3. reverse Cuthill-McKee inside every part
+    std::vector<int> &gorder = *gorder_out;
+    gorder.clear();
+    if (first) first->assign(1, 0);
+    gorder.reserve((size_t) ng);
+    for (size_t pid = 0; pid < members.size(); pid++)
+    {
+        part_order(g, part, (int) pid, members[pid], true, stamp, mark, level, placed, scratch, order);
+        gorder.insert(gorder.end(), order.begin(), order.end());
+        if (first) first->push_back((int) gorder.size());
+    }
+}
+
 }  // namespace
 
 bool locality_reorder(int nrow, int ncol, const int *rowptr, const int *colidx, int nparts, std::vector<int> *perm,
@@ -185,40 +230,10 @@ bool locality_reorder(int nrow, int ncol, const int *rowptr, const int *colidx, 
     nbr.clear();
     nbr.shrink_to_fit();
 
-    // ---- 2. recursive bisection along breadth-first level structures
-    int depth = 0;
-    while ((1 << depth) < nparts) depth++;
-    std::vector<int> part((size_t) ng, 0), mark((size_t) ng, 0), level((size_t) ng, 0), placed((size_t) ng, 0), scratch, order;
-    int stamp = 0;
-    std::vector<std::vector<int>> members(1);
-    members[0].resize((size_t) ng);
-    std::iota(members[0].begin(), members[0].end(), 0);
-    for (int d = 0; d < depth; d++)
-    {
-        std::vector<std::vector<int>> next(members.size() * 2);
-        for (size_t pid = 0; pid < members.size(); pid++)
-        {
-            // (part ids are re-assigned after every level: vertex v of part pid goes to 2 pid or 2 pid + 1)
-            part_order(g, part, (int) pid, members[pid], false, stamp, mark, level, placed, scratch, order);
-            long long total = 0, run = 0;
-            for (int v : order) total += g.weight[(size_t) v];
-            size_t cut = 0;
-            while (cut < order.size() && (run + g.weight[(size_t) order[cut]] / 2) * 2 < total) run += g.weight[(size_t) order[cut++]];
-            next[2 * pid].assign(order.begin(), order.begin() + (long) cut);
-            next[2 * pid + 1].assign(order.begin() + (long) cut, order.end());
-        }
-        members.swap(next);
-        for (size_t pid = 0; pid < members.size(); pid++)
-            for (int v : members[pid]) part[(size_t) v] = (int) pid;
-    }
-    // ---- 3. reverse Cuthill-McKee inside every part
+    // ---- 2., 3.
     std::vector<int> gorder;
-    gorder.reserve((size_t) ng);
-    for (size_t pid = 0; pid < members.size(); pid++)
-    {
-        part_order(g, part, (int) pid, members[pid], true, stamp, mark, level, placed, scratch, order);
-        gorder.insert(gorder.end(), order.begin(), order.end());
-    }
+    std::vector<int> first;
+    slab_order(g, nparts, &gorder, &first);
     if ((int) gorder.size() != ng) return false;
     // ---- rows of the groups in that order
     std::vector<int> gstart((size_t) ng + 1, 0);
@@ -229,7 +244,7 @@ bool locality_reorder(int nrow, int ncol, const int *rowptr, const int *colidx, 
     if (info != nullptr)
     {
         info->groups = ng;
-        info->parts = (int) members.size();
+        info->parts = (int) first.size() - 1;
         // mean distance, in the new order, between a row and the rows its columns name: what the sweep has to keep
         std::vector<int> pos((size_t) nrow);
         for (int i = 0; i < nrow; i++) pos[(size_t) (*perm)[(size_t) i]] = i;
@@ -244,6 +259,19 @@ bool locality_reorder(int nrow, int ncol, const int *rowptr, const int *colidx, 
         info->mean_dist_after = after / (double) nnz;
     }
     return true;
+}
+
+bool graph_slab_order(int n, const std::vector<int> &ptr, const std::vector<int> &adj, const std::vector<int> &weight, int nparts,
+                      std::vector<int> *order, std::vector<int> *first)
+{
+    if (n <= 0 || (int) ptr.size() != n + 1 || (int) weight.size() != n) return false;
+    Graph g;
+    g.n = n;
+    g.ptr = ptr;
+    g.adj = adj;
+    g.weight = weight;
+    slab_order(g, nparts, order, first);
+    return (int) order->size() == n;
 }
 
 }  // namespace crp

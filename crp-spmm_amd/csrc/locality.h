@@ -18,4 +18,10 @@ struct LocalityInfo
 bool locality_reorder(int nrow, int ncol, const int *rowptr, const int *colidx, int nparts, std::vector<int> *perm,
                       LocalityInfo *info = nullptr);
 
+// The slab order of locality.cpp (steps 2 and 3) on any weighted graph (symmetric adjacency, no self loops):
+// `nparts` (a power of two) parts of equal weight, reverse Cuthill-McKee inside each.  order = the vertices part
+// after part; first (optional) = where every part starts, nparts + 1 entries.
+bool graph_slab_order(int n, const std::vector<int> &ptr, const std::vector<int> &adj, const std::vector<int> &weight, int nparts,
+                      std::vector<int> *order, std::vector<int> *first = nullptr);
+
 }  // namespace crp

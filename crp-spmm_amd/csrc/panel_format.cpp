@@ -4,6 +4,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include "locality.h"
 #include "panel_format.h"
 #include "par.h"
 
@@ -868,8 +869,48 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
         std::vector<int> super_of, sslot;
         int ns = 0;
         greedy_cluster(nteam, iptr, ikey, 64, 1 << 13, &super_of, &sslot, &ns);
+        // order of the super-teams: the slab order of locality.cpp on their graph (two super-teams are adjacent when
+        // they share a B row; weight = union entries) -- eight slabs, one per XCD, each swept along its long axis,
+        // so that an XCD's L2 sees one compact region and consecutive generations are neighbours
+        std::vector<int> srank((size_t) ns);
+        {
+            std::vector<std::pair<uint32_t, int>> ks;
+            ks.reserve(ikey.size());
+            for (int g = 0; g < nteam; g++)
+                for (long long q = iptr[(size_t) g]; q < iptr[(size_t) g + 1]; q++) ks.push_back({ikey[(size_t) q], super_of[(size_t) g]});
+            std::sort(ks.begin(), ks.end());
+            ks.erase(std::unique(ks.begin(), ks.end()), ks.end());
+            std::vector<int> weight((size_t) ns, 0);
+            std::vector<std::pair<int, int>> edges;
+            for (size_t a = 0; a < ks.size();)
+            {
+                size_t b = a;
+                while (b < ks.size() && ks[b].first == ks[a].first) b++;
+                for (size_t x = a; x < b; x++)
+                {
+                    weight[(size_t) ks[x].second]++;
+                    for (size_t y = a; y < b; y++)
+                        if (x != y) edges.push_back({ks[x].second, ks[y].second});
+                }
+                a = b;
+                if (edges.size() > (size_t) 1 << 24) { std::sort(edges.begin(), edges.end()); edges.erase(std::unique(edges.begin(), edges.end()), edges.end()); }
+            }
+            std::sort(edges.begin(), edges.end());
+            edges.erase(std::unique(edges.begin(), edges.end()), edges.end());
+            std::vector<int> gp((size_t) ns + 1, 0), ga(edges.size());
+            for (size_t e = 0; e < edges.size(); e++) { gp[(size_t) edges[e].first + 1]++; ga[e] = edges[e].second; }
+            for (int q = 0; q < ns; q++) gp[(size_t) q + 1] += gp[(size_t) q];
+            std::vector<int> so;
+            static const int sorder = getenv("CRPSPMM_T2_SORDER") ? atoi(getenv("CRPSPMM_T2_SORDER")) : 1;
+            if (sorder == 0 || ns < 16 || !graph_slab_order(ns, gp, ga, weight, 8, &so))
+            {
+                so.resize((size_t) ns);
+                for (int q = 0; q < ns; q++) so[(size_t) q] = q;
+            }
+            for (int q = 0; q < ns; q++) srank[(size_t) so[(size_t) q]] = q;
+        }
         std::sort(out->torder.begin(), out->torder.end(), [&](int x, int y) {
-            if (super_of[(size_t) x] != super_of[(size_t) y]) return super_of[(size_t) x] < super_of[(size_t) y];
+            if (super_of[(size_t) x] != super_of[(size_t) y]) return srank[(size_t) super_of[(size_t) x]] < srank[(size_t) super_of[(size_t) y]];
             return sslot[(size_t) x] < sslot[(size_t) y];
         });
     }
