@@ -39,6 +39,7 @@ struct TeamDev
     bool lattice = false;
 };
 
+constexpr int TEAM2_MIN_N = 112;      // fp64 columns from which auto picks variant 5 (fp32: twice that)
 struct Team2Dev
 {
     bool built = false;
@@ -655,10 +656,10 @@ int crp_spmm_csr_f64(crp_csr_dev_p A, int layout, int n, const double *B0, long 
     hipError_t e;
     if (layout == CRP_LAYOUT_COL_MAJOR) return (int) crp::spmm_cm_f64(a, (hipStream_t) stream);
     int v = (variant == 0) ? A->auto_variant : variant;
-    // auto: from 96 columns on the LDS-sharing team kernel wherever teams share columns (measured against the
-    // create-time choice on the pwtk, shell, kkt and fem3d stand-ins at n = 128 / 256 / 1024: 0.97 / 0.91 / 0.93,
-    // 0.83 / 0.73 / 0.68, 0.65 / 0.70 / 0.67, 0.87 / 0.93 / 0.88 of its time; at n = 32 it needs 1.7 x)
-    if (variant == 0 && A->team2_pays && n >= 96 && crp::spmm_team2_applicable(a)) v = 5;
+    // auto: from TEAM2_MIN_N columns on the LDS-sharing team kernel wherever teams share columns (against the best
+    // other variant on the pwtk / shell / fem3d stand-ins: n = 128: 1.00 / 0.81 / 0.73 of its time, n = 256: 0.85 /
+    // 0.65 / 0.63; at n = 96 -- a tile of 128 columns three quarters used -- 1.17 / 1.00 / 0.94, at n = 32 1.6 x)
+    if (variant == 0 && A->team2_pays && n >= TEAM2_MIN_N && crp::spmm_team2_applicable(a)) v = 5;
     if (v == 5 && (!crp::spmm_team2_applicable(a) || A->nnz == 0 || A->nrow < 8)) v = 3;
     if (v >= 2 && A->rowmap_fmt != nullptr) a.rowmap = A->rowmap_fmt;      // derived formats hold the rows in processing order
     if (v == 5)
@@ -714,7 +715,7 @@ int crp_spmm_csr_f32(crp_csr_dev_p A, int n, const float *B0, long long ldB0, co
     crp::SpmmArgsF32 a;
     a.nrow = A->nrow; a.n = n; a.rowptr = A->rowptr; a.colidx = A->colidx; a.val = A->val32;
     a.B0 = B0; a.ldB0 = ldB0; a.B1 = B1; a.ldB1 = ldB1; a.C = C; a.ldC = ldC; a.rowmap = A->rowmap;
-    const bool team = (variant == 5 || (variant == 0 && A->team2_pays && n >= 96)) && A->nnz > 0 && A->nrow >= 8 &&
+    const bool team = (variant == 5 || (variant == 0 && A->team2_pays && n >= 2 * TEAM2_MIN_N)) && A->nnz > 0 && A->nrow >= 8 &&
                       crp::spmm_team2_applicable_f32(a);
     if (!team) return (int) crp::spmm_rm_f32_rowgroup(a, (hipStream_t) stream);
     const int rc = ensure_team2(A);
@@ -739,7 +740,7 @@ int crp_csr_dev_resolved_variant(crp_csr_dev_p A, int n)
     if (A == NULL) return -1;
     int v = A->auto_variant;
     if (v >= 2 && n < 24) v = 1;
-    if (A->team2_pays && n >= 96 && (n % 2 == 0)) v = 5;
+    if (A->team2_pays && n >= TEAM2_MIN_N && (n % 2 == 0)) v = 5;
     return v;
 }
 int crp_csr_dev_lattice(crp_csr_dev_p A) { return A ? ((A->team2.built && A->team2.lattice) || (A->team.built && A->team.lattice) ? 1 : 0) : -1; }
