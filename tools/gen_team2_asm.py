@@ -29,6 +29,10 @@ KiB) -> read the next record -> parts: B row slice by ds_read_b128 per 16-byte p
 ds_read_b64 (lane l holds value l & 7), call of sequence code_i: rows first..first+len-1, per row
     v_fmac_f64_dpp acc, values, slice row_newbcast:row   (NV * 2 of them)
 The reads of part i + 1 are issued before the wait for part i.
+fp32 instances (gen(..., f32=True)): the same loop with 128-byte value slots (8 floats per part: ds_read_b32, lane l
+holds value l & 7) and per row NV * 4 x v_fmac_f32_dpp on the four floats of the lane's 16-byte piece.
+T2_BPOL (environment, generation time) appends a cache policy to the B-row DMAs; measured on the pwtk stand-in:
+nt +35 % time, sc0 / sc1 / sc0 sc1 within +-2 %; the committed file uses none.
 
 usage: tools/gen_team2_asm.py > crp-spmm_amd/csrc/team2_consume.inc
 """
