@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <vector>
 #include "dev_type.h"
+#include "locality.h"
 #include "panel_format.h"
 #include "mmio_utils.h"
 #include "spmat_part.h"
@@ -123,6 +124,41 @@ int main()
             if (own != t.tvoff.back()) { printf("FAIL team value streams %lld %lld\n", own, t.tvoff.back()); return 1; }
         }
     unsetenv("CRPSPMM_PANEL_ORDER");
+
+    // team2 streams (variant 5): clustered / lattice / consecutive teams, super-teams, launch grid; locality order
+    {
+        std::vector<Csr> t2 = mats;
+        t2.push_back(banded(9120, {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 304, 305, 306, 307, 308, 309, 3040, 3041, 3042, 3043, 3044, 3045}));
+        t2.push_back(banded(300 * 40 + 5, {1, 2, 300, 301, 302}));          // enough teams for super-teams (>= 128)
+        for (const Csr &a : t2)
+        {
+            crp::PanelHost h8;
+            crp::build_panels(a.m, a.rp.data(), a.ci.data(), a.va.data(), 8, &h8, false);
+            std::vector<int> perm, pos;
+            bool square = a.m == a.k;
+            for (int c : a.ci) square = square && c >= 0;
+            if (square && crp::locality_reorder(a.m, a.k, a.rp.data(), a.ci.data(), 8, &perm))
+            {
+                if ((int) perm.size() != a.m) { printf("FAIL locality size\n"); return 1; }
+                pos.assign((size_t) a.m, -1);
+                for (int i = 0; i < a.m; i++) pos[(size_t) perm[(size_t) i]] = i;
+                for (int v : pos) if (v < 0) { printf("FAIL locality is not a permutation\n"); return 1; }
+            }
+            crp::Team2Host t;
+            crp::build_team2(h8, a.m, a.rp.data(), a.ci.data(), &t, pos.empty() ? nullptr : pos.data());
+            std::vector<int> seen((size_t) std::max(t.nteam, 1), 0);
+            if (t.tgrid.size() % 8) { printf("FAIL tgrid size\n"); return 1; }
+            for (int g : t.tgrid)
+                if (g >= 0) { if (g >= t.nteam) { printf("FAIL tgrid entry\n"); return 1; } seen[(size_t) g]++; }
+            for (int g = 0; g < t.nteam; g++) if (seen[(size_t) g] != 1) { printf("FAIL tgrid is not a cover\n"); return 1; }
+            long long parts = 0;
+            for (int g = 0; g < t.nteam; g++) parts += t.tinfo[(size_t) g * 4 + 2];
+            if (parts != t.parts || t.tvoff.back() != parts) { printf("FAIL team2 parts %lld %lld %lld\n", parts, t.parts, t.tvoff.back()); return 1; }
+            if (t.vmap.size() != a.ci.size()) { printf("FAIL team2 vmap\n"); return 1; }
+            for (size_t p2 = 0; p2 < t.vmap.size(); p2++)
+                if (t.vmap[p2] >= t.tval.size() || t.tval[t.vmap[p2]] != a.va[p2]) { printf("FAIL team2 vmap entry %zu\n", p2); return 1; }
+        }
+    }
 
     // planner
     {
