@@ -45,6 +45,7 @@ struct Team2Dev
     bool built = false;
     int  nteam = 0;
     int ngrid = 0;                 // entries of torder (= the launch grid, 8 equal runs, -1 = no team)
+    int tw = 8;                    // waves per team (Team2Host::T)
     int *torder = nullptr, *tpanel = nullptr, *tinfo = nullptr, *tpro = nullptr;
     uint32_t *trec = nullptr;
     long long *tvoff = nullptr;
@@ -209,6 +210,13 @@ static int ensure_team(crp_csr_dev *A)
 }
 
 // Build (once) and upload the team2 streams on top of the R = 8 panels (column-ordered entries). Blocking.
+// CRPSPMM_TEAM2_WAVES=8|16: panels (= waves) per team of variant 5
+static int team2_waves()
+{
+    static const int w = getenv("CRPSPMM_TEAM2_WAVES") && atoi(getenv("CRPSPMM_TEAM2_WAVES")) == 16 ? 16 : 8;
+    return w;
+}
+
 static int ensure_team2(crp_csr_dev *A)
 {
     Team2Dev &t = A->team2;
@@ -217,6 +225,8 @@ static int ensure_team2(crp_csr_dev *A)
     crp::build_panels(A->nrow, fmt_rowptr(A), fmt_colidx(A), fmt_val(A), 8, &h, false);
     fmt_slotmap_to_caller(A, &h.pmap);
     crp::Team2Host th;
+    th.T = team2_waves();
+    t.tw = th.T;
     std::vector<int> colpos;                    // position of every row in the processing order (square, re-ordered matrices)
     if (!A->perm.empty())
     {
@@ -667,7 +677,7 @@ int crp_spmm_csr_f64(crp_csr_dev_p A, int layout, int n, const double *B0, long 
         const int rc = ensure_team2(A);
         if (rc != 0) return rc;
         crp::Team2Args t;
-        t.nteam = A->team2.nteam; t.ngrid = A->team2.ngrid; t.torder = A->team2.torder; t.tpanel = A->team2.tpanel; t.tinfo = A->team2.tinfo;
+        t.nteam = A->team2.nteam; t.ngrid = A->team2.ngrid; t.tw = A->team2.tw; t.torder = A->team2.torder; t.tpanel = A->team2.tpanel; t.tinfo = A->team2.tinfo;
         t.tpro = A->team2.tpro; t.trec = A->team2.trec; t.tvoff = A->team2.tvoff; t.tval = A->team2.tval; t.tval32 = nullptr;
         return (int) crp::spmm_rm_f64_team2(t, a, (hipStream_t) stream);
     }
@@ -728,7 +738,7 @@ int crp_spmm_csr_f32(crp_csr_dev_p A, int n, const float *B0, long long ldB0, co
     }
     if (A->rowmap_fmt != nullptr) a.rowmap = A->rowmap_fmt;
     crp::Team2Args t;
-    t.nteam = A->team2.nteam; t.ngrid = A->team2.ngrid; t.torder = A->team2.torder; t.tpanel = A->team2.tpanel; t.tinfo = A->team2.tinfo;
+    t.nteam = A->team2.nteam; t.ngrid = A->team2.ngrid; t.tw = A->team2.tw; t.torder = A->team2.torder; t.tpanel = A->team2.tpanel; t.tinfo = A->team2.tinfo;
     t.tpro = A->team2.tpro; t.trec = A->team2.trec; t.tvoff = A->team2.tvoff; t.tval = A->team2.tval; t.tval32 = A->team2.tval32;
     return (int) crp::spmm_rm_f32_team2(t, a, (hipStream_t) stream);
 }
@@ -795,6 +805,8 @@ int crp_team_format_host(int nrow, const int *rowptr, const int *colidx, const d
     return 0;
 }
 
+int crp_team2_waves(void) { return team2_waves(); }
+
 int crp_team2_format_host(int nrow, const int *rowptr, const int *colidx, const double *val, int *nteam, int *lattice,
                           int **tpanel, int **tinfo, int **tpro, unsigned **trec, long long *nrecwords,
                           long long **tvoff, double **tval, long long *nvalent, int **torder, unsigned **vmap)
@@ -805,6 +817,7 @@ int crp_team2_format_host(int nrow, const int *rowptr, const int *colidx, const 
     crp::PanelHost h;
     crp::build_panels(nrow, rowptr, colidx, val, 8, &h, false);
     crp::Team2Host th;
+    th.T = team2_waves();
     crp::build_team2(h, nrow, rowptr, colidx, &th);
     *nteam = th.nteam;
     if (lattice) *lattice = th.lattice ? 1 : 0;

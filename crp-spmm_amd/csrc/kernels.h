@@ -70,10 +70,11 @@ struct Team2Args          // panel_format.h, Team2Host
 {
     int nteam;
     int ngrid;                 // entries of torder: the launch grid (Team2Host::tgrid), a multiple of 8
+    int tw;                    // waves (= panels) per team: 8 or 16 (Team2Host::T)
     const int      *torder;
-    const int      *tpanel;    // 8 * nteam
+    const int      *tpanel;    // tw * nteam
     const int      *tinfo;     // 4 * nteam: rounds, first record block, union entries, 0
-    const int      *tpro;      // nteam * TEAM2_D * 8 * 2: {column, value offset}
+    const int      *tpro;      // nteam * TEAM2_D * tw * 2: {column, value offset}
     const uint32_t *trec;      // record blocks (1 KiB each)
     const long long *tvoff;    // 8 * nteam
     const double   *tval;

@@ -7,6 +7,24 @@
 #include "locality.h"
 #include "panel_format.h"
 #include "par.h"
+#include <time.h>
+
+// CRPSPMM_TIMING=1: phase times of the format builders on stderr
+namespace {
+struct PhaseClock
+{
+    bool on = getenv("CRPSPMM_TIMING") != NULL && atoi(getenv("CRPSPMM_TIMING")) != 0;
+    double t0 = now();
+    static double now() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double) ts.tv_sec + 1e-9 * (double) ts.tv_nsec; }
+    void lap(const char *what)
+    {
+        if (!on) return;
+        const double t = now();
+        fprintf(stderr, "[crpspmm timing] %-44s %8.3f s\n", what, t - t0);
+        t0 = t;
+    }
+};
+}  // namespace
 
 namespace crp {
 
@@ -543,29 +561,33 @@ static void greedy_cluster(int n, const std::vector<long long> &iptr, const std:
 
 void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *colidx, TeamHost *out, int T)
 {
-    constexpr int TMAX = 8;
-    if (T != 4 && T != 6 && T != 8) T = 4;
+    constexpr int TMAX = 16;
+    if (T != 4 && T != 6 && T != 8 && T != 16) T = 4;
     const int TI = T / 2;                 // lattice teams: TI teeth along i times 2 along j
     out->T = T;
     const int np = p.npanel, R = p.R;
     double D1 = 0, D2 = 0;
     int M = 0;
+    PhaseClock clk;
     bool lattice = (np >= 64) && detect_stride_lattice(nrow, rowptr, colidx, R, &D1, &D2, &M);
+    clk.lap("build_teams: lattice detection");
     // teams of eight (team2): shape of a team in tooth coordinates, si x sj teeth x st consecutive panels along
     // the teeth (CRPSPMM_TEAM2_SHAPE=si,sj,st with si * sj * st = 8; "0" = eight consecutive panels even on a lattice)
     int si = TI, sj = 2, st = 1;
-    if (T == 8)
+    if (T >= 8)
     {
         // 2 x 2 teeth x 2 consecutive panels: 4.98 union entries per row on the pwtk stand-in, against 6.5 for
-        // 4 x 2 x 1 and 5.4 for eight consecutive panels (0.351 / 0.418 / 0.424 ms with the first team2 kernel)
-        si = 2; sj = 2; st = 2;
+        // 4 x 2 x 1 and 5.4 for eight consecutive panels (0.351 / 0.418 / 0.424 ms with the first team2 kernel);
+        // teams of sixteen: 2 x 2 x 4
+        si = 2; sj = 2; st = T / 4;
         if (const char *es = getenv("CRPSPMM_TEAM2_SHAPE"); es != NULL)
         {
             int a = 0, b = 0, c = 0;
-            if (sscanf(es, "%d,%d,%d", &a, &b, &c) == 3 && a > 0 && b > 0 && c > 0 && a * b * c == 8) { si = a; sj = b; st = c; }
-            else if (atoi(es) == 0) lattice = false;
+            if (sscanf(es, "%d,%d,%d", &a, &b, &c) == 3 && a > 0 && b > 0 && c > 0 && a * b * c == T) { si = a; sj = b; st = c; }
+            else if (atoi(es) == 0 && strchr(es, ',') == NULL) lattice = false;
         }
     }
+    out->st = st;
     out->lattice = lattice;
     auto real_count = [&](int panel) {
         int c = 0;
@@ -583,8 +605,8 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
     // compact block (6.9); nlpkkt stand-in 7.1 (its lattice teams) -> 4.4.  CRPSPMM_TEAM2_CLUSTER=0 turns it off.
     static const bool cluster_on = getenv("CRPSPMM_TEAM2_CLUSTER") == NULL || atoi(getenv("CRPSPMM_TEAM2_CLUSTER")) != 0;
     static const bool cluster_lattice = getenv("CRPSPMM_TEAM2_CLUSTER") != NULL && atoi(getenv("CRPSPMM_TEAM2_CLUSTER")) == 2;
-    if (T == 8 && cluster_lattice) lattice = out->lattice = false;
-    bool clustered = T == 8 && cluster_on && np >= 16;
+    if (T >= 8 && cluster_lattice) lattice = out->lattice = false;
+    bool clustered = T >= 8 && cluster_on && np >= 2 * T;
     std::vector<int> team_of, slot_of;
     if (clustered)
     {
@@ -648,6 +670,7 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
     }
     out->clustered = clustered;
     if (clustered) out->plocal = slot_of;
+    clk.lap("build_teams: panel clustering (+ lattice choice)");
     // membership: (team key, slot)
     struct Mem { long long key; int slot, panel, a, b, t; };
     std::vector<Mem> mem((size_t) np);
@@ -675,7 +698,8 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
     for (size_t s0 = 0; s0 < mem.size();)
     {
         size_t s1 = s0;
-        int slots[TMAX] = {-1, -1, -1, -1, -1, -1, -1, -1};
+        int slots[TMAX];
+        for (int w = 0; w < TMAX; w++) slots[w] = -1;
         while (s1 < mem.size() && mem[s1].key == mem[s0].key && slots[mem[s1].slot] < 0)
         {
             slots[mem[s1].slot] = mem[s1].panel;
@@ -751,7 +775,8 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
             // nodes whose user sets are disjoint and cover the waves (a node shared by A and B plus one
             // shared by C and D; or four private nodes; ...).  All waves then meet a shared node after
             // exactly the same number of own entries, i.e. in the same ring slot of the same round.
-            int cursor[TMAX] = {0, 0, 0, 0, 0, 0, 0, 0};
+            int cursor[TMAX];
+            for (int w = 0; w < TMAX; w++) cursor[w] = 0;
             size_t left = nodes.size();
             auto emit = [&](int id) {
                 Node &nd = nodes[(size_t) id];
@@ -763,7 +788,8 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
             };
             while (left > 0)
             {
-                bool covered[TMAX] = {false, false, false, false, false, false, false, false};
+                bool covered[TMAX];
+                for (int w = 0; w < TMAX; w++) covered[w] = false;
                 for (int w = 0; w < T; w++)
                 {
                     if (covered[w]) continue;
@@ -797,6 +823,7 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
             cnt[(size_t) g] = (int) uc.size();
         }
     });
+    clk.lap("build_teams: union lists + balanced passes");
     out->tptr.assign((size_t) nteam + 1, 0);
     long long real = 0;
     for (int g = 0; g < nteam; g++)
@@ -845,6 +872,7 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
         out->tvoff[(size_t) nteam * T] = run;
     }
 
+    clk.lap("build_teams: layout (tcol, tsrc, value streams)");
     // processing order: XCD blocks of neighbouring team columns swept in lockstep along t (lattice),
     // else the natural order
     out->torder.resize((size_t) nteam);
@@ -868,7 +896,7 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
         }
         std::vector<int> super_of, sslot;
         int ns = 0;
-        greedy_cluster(nteam, iptr, ikey, 64, 1 << 13, &super_of, &sslot, &ns);
+        greedy_cluster(nteam, iptr, ikey, T == 16 ? 32 : 64, 1 << 13, &super_of, &sslot, &ns);   // the workgroups resident on an XCD
         // order of the super-teams: the slab order of locality.cpp on their graph (two super-teams are adjacent when
         // they share a B row; weight = union entries) -- eight slabs, one per XCD, each swept along its long axis,
         // so that an XCD's L2 sees one compact region and consecutive generations are neighbours
@@ -931,14 +959,20 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
             });
         }
     }
+    clk.lap("build_teams: processing order (super-teams)");
 }
 
 // ---- team2 streams (panel_format.h) ------------------------------------------------------------------
 void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *colidx, Team2Host *out, const int *colpos)
 {
-    constexpr int T = TEAM2_T, D = TEAM2_D, CAP = TEAM2_CAP;
+    constexpr int D = TEAM2_D, CAP = TEAM2_CAP, TMAX = 16;
+    const int T = out->T == 16 ? 16 : TEAM2_T;
+    const int sbits = T == 16 ? 4 : 3, fbase = T == 16 ? 20 : 16;          // slot bits and first flag bit of record word 0
+    const size_t blkw = (size_t) 32 * T;                                    // words of a record block (8 rounds x T waves x 4)
+    PhaseClock clk;
     TeamHost th;
     build_teams(p, nrow, rowptr, colidx, &th, T);
+    clk.lap("build_team2: build_teams total");
     // Phase key of a union entry: (position of its B row in the processing order) mod S, S = rows a team advances
     // along its sweep (8 x the consecutive panels of a lattice team, 64 for eight consecutive panels).  Teams are
     // dealt to the workgroups of an XCD in order and start a fraction of a microsecond apart; a B row shared by
@@ -946,13 +980,7 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
     // all its readers ask for it at the same point of their lives, i.e. within the few microseconds a line
     // survives in the XCD's L2 -- instead of at unrelated moments of 35-microsecond lives.
     // CRPSPMM_TEAM2_PHASE=0 keeps the balanced order of build_teams().
-    int S = 64;
-    if (th.lattice)
-    {
-        int st = 2, a = 0, b = 0, c = 0;
-        if (const char *es = getenv("CRPSPMM_TEAM2_SHAPE"); es != NULL && sscanf(es, "%d,%d,%d", &a, &b, &c) == 3 && a * b * c == 8) st = c;
-        S = 8 * st;
-    }
+    const int S = th.lattice ? 8 * th.st : 8 * T;
     static const bool phase = getenv("CRPSPMM_TEAM2_PHASE") == NULL || atoi(getenv("CRPSPMM_TEAM2_PHASE")) != 0;
     const int nteam = th.nteam;
     out->nteam = nteam;
@@ -988,7 +1016,7 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
                     const int c = th.tcol[(size_t) q];
                     const long long ps = c >= 0 ? (colpos ? colpos[c] : c) : (long long) (~c);
                     // clustered teams (square part): where the row of A with this number sits inside ITS team
-                    if (th.clustered && c >= 0 && ps / 8 < (long long) th.plocal.size()) return (int) (ps % 8) * 8 + th.plocal[(size_t) (ps / 8)];      // (row of the panel, slot): neighbours in the order belong to different waves
+                    if (th.clustered && c >= 0 && ps / 8 < (long long) th.plocal.size()) return (int) (ps % 8) * 16 + th.plocal[(size_t) (ps / 8)];      // (row of the panel, slot): neighbours in the order belong to different waves
                     return (int) (ps % S);
                 };
                 std::stable_sort(nodes.begin(), nodes.end(), [&](int x, int y) { return key(x) < key(y); });
@@ -1011,20 +1039,21 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
             const int last_col = nodes.empty() ? 0 : th.tcol[(size_t) nodes[0]];
             while (left > 0)
             {
-                int cnt[T] = {0, 0, 0, 0, 0, 0, 0, 0};
+                int cnt[TMAX];
+                for (int w = 0; w < TMAX; w++) cnt[w] = 0;
                 int nslot = 0;
                 const size_t base_col = to.col.size();
-                to.col.resize(base_col + 8, last_col);
-                to.own.resize(to.own.size() + 8);
+                to.col.resize(base_col + (size_t) T, last_col);
+                to.own.resize(to.own.size() + (size_t) T);
                 while (head < nodes.size() && taken[head]) head++;
                 int seen = 0;
-                for (size_t t = head; t < nodes.size() && nslot < 8 && seen < 32; t++)
+                for (size_t t = head; t < nodes.size() && nslot < T && seen < 4 * T; t++)
                 {
                     if (taken[t]) continue;
                     seen++;
                     const int q = nodes[t];
-                    Part tmp[T][4];
-                    int kk[T];
+                    Part tmp[TMAX][4];
+                    int kk[TMAX];
                     bool fits = true;
                     for (int w = 0; w < T; w++)
                     {
@@ -1039,7 +1068,7 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
                             Part pt = tmp[w][i];
                             pt.slot = nslot;
                             pt.src = th.tsrc[(size_t) q * T + (size_t) w];
-                            to.own[(size_t) to.nr * 8 + (size_t) w].push_back(pt);
+                            to.own[(size_t) to.nr * T + (size_t) w].push_back(pt);
                             cnt[w]++;
                             to.nparts++;
                         }
@@ -1054,9 +1083,10 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
         }
     });
 
+    clk.lap("build_team2: rounds (phase sort, list scheduler)");
     // ---- layout: record blocks, value streams
     out->tinfo.assign((size_t) nteam * 4, 0);
-    out->tpro.assign((size_t) nteam * D * 8 * 2, 0);
+    out->tpro.assign((size_t) nteam * D * T * 2, 0);
     out->tvoff.assign((size_t) nteam * T + 1, 0);
     std::vector<int> blk0((size_t) nteam + 1, 0);
     long long run = 0;
@@ -1070,12 +1100,12 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
         out->tinfo[(size_t) g * 4 + 2] = to.nparts;
         out->tinfo[(size_t) g * 4 + 3] = to.filled;
         out->real_entries += to.filled;
-        out->slots += (long long) to.nr * 8;
+        out->slots += (long long) to.nr * T;
         out->parts += to.nparts;
         for (int w = 0; w < T; w++)
         {
             out->tvoff[(size_t) g * T + (size_t) w] = run;
-            for (int r = 0; r < to.nr; r++) run += (long long) to.own[(size_t) r * 8 + (size_t) w].size();
+            for (int r = 0; r < to.nr; r++) run += (long long) to.own[(size_t) r * T + (size_t) w].size();
         }
     }
     out->tvoff[(size_t) nteam * T] = run;
@@ -1100,7 +1130,7 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
         for (int q = 0; q < 8; q++)
             for (int i = cut[(size_t) q]; i < cut[(size_t) q + 1]; i++) out->tgrid[(size_t) q * cpx + (size_t) (i - cut[(size_t) q])] = out->torder[(size_t) i];
     }
-    out->trec.assign((size_t) blk0[(size_t) nteam] * 256 + 256, 0u);
+    out->trec.assign((size_t) blk0[(size_t) nteam] * blkw + blkw, 0u);
     out->tval.assign((size_t) run * 8, 0.0);
     // vmap through the panel format's slot map: pmap[nz] = q * 8 + row of the panel format
     std::vector<uint32_t> slot_of(p.pcol.size() * 8, 0xFFFFFFFFu);       // panel-format value slot -> tval slot
@@ -1114,12 +1144,12 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
                 const long long k0 = k;
                 for (int r = 0; r < to.nr; r++)
                 {
-                    const std::vector<Part> &ow = to.own[(size_t) r * 8 + (size_t) w];
+                    const std::vector<Part> &ow = to.own[(size_t) r * T + (size_t) w];
                     uint32_t x = (uint32_t) ow.size(), y = 0;
                     for (size_t i = 0; i < ow.size(); i++)
                     {
                         const Part &pt = ow[i];
-                        x |= (uint32_t) pt.slot << (4 + 3 * i);
+                        x |= (uint32_t) pt.slot << (4 + sbits * (int) i);
                         y |= (uint32_t) (pt.first * 8 - pt.first * (pt.first - 1) / 2 + pt.len - 1) << (6 * i);
                         for (int rr = pt.first; rr < pt.first + pt.len; rr++)
                         {
@@ -1128,37 +1158,39 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
                         }
                         k++;
                     }
-                    uint32_t *rec = &out->trec[((size_t) blk0[(size_t) g] + (size_t) (r >> 3)) * 256 + (size_t) (r & 7) * 32 + (size_t) w * 4];
+                    uint32_t *rec = &out->trec[((size_t) blk0[(size_t) g] + (size_t) (r >> 3)) * blkw + (size_t) (r & 7) * 4 * T + (size_t) w * 4];
                     rec[0] = x;
                     rec[1] = y;
                 }
                 // value offsets and columns fetched D rounds ahead
                 std::vector<long long> voff((size_t) to.nr + 1, 0);
-                for (int r = 0; r < to.nr; r++) voff[(size_t) r + 1] = voff[(size_t) r] + (long long) to.own[(size_t) r * 8 + (size_t) w].size();
+                for (int r = 0; r < to.nr; r++) voff[(size_t) r + 1] = voff[(size_t) r] + (long long) to.own[(size_t) r * T + (size_t) w].size();
                 (void) k0;
                 for (int r = 0; r < to.nr; r++)
                 {
                     const int rd = r + D;
-                    uint32_t *rec = &out->trec[((size_t) blk0[(size_t) g] + (size_t) (r >> 3)) * 256 + (size_t) (r & 7) * 32 + (size_t) w * 4];
+                    uint32_t *rec = &out->trec[((size_t) blk0[(size_t) g] + (size_t) (r >> 3)) * blkw + (size_t) (r & 7) * 4 * T + (size_t) w * 4];
                     rec[2] = (uint32_t) (rd < to.nr ? voff[(size_t) rd] : voff[(size_t) to.nr]);
-                    rec[3] = (uint32_t) (rd < to.nr ? to.col[(size_t) rd * 8 + (size_t) w] : to.col[0]);
+                    rec[3] = (uint32_t) (rd < to.nr ? to.col[(size_t) rd * T + (size_t) w] : to.col[0]);
                     // flags that steer the kernel's round (tools/gen_team2_asm.py)
-                    if (rd < to.nr) rec[0] |= 1u << 16;                                   // ISSUE: fetch for round r + D
-                    if (r + D - 1 >= to.nr) rec[0] |= 1u << 17;                           // TAIL: fewer than D-1 younger rounds in flight
-                    if (r == to.nr - 1) rec[0] |= 1u << 18;                               // LAST
-                    if (w == 0 && (r & 7) == 0 && (r >> 3) + 1 < (to.nr + 7) / 8) rec[0] |= 1u << 19;   // RECS: fetch the next record block
+                    if (rd < to.nr) rec[0] |= 1u << fbase;                                   // ISSUE: fetch for round r + D
+                    if (r + D - 1 >= to.nr) rec[0] |= 1u << (fbase + 1);                           // TAIL: fewer than D-1 younger rounds in flight
+                    if (r == to.nr - 1) rec[0] |= 1u << (fbase + 2);                               // LAST
+                    if (w == 0 && (r & 7) == 0 && (r >> 3) + 1 < (to.nr + 7) / 8) rec[0] |= 1u << (fbase + 3);   // RECS: fetch the next record block
                 }
                 for (int d = 0; d < D; d++)
                 {
-                    int *pr = &out->tpro[(((size_t) g * D + (size_t) d) * 8 + (size_t) w) * 2];
-                    pr[0] = (d < to.nr) ? to.col[(size_t) d * 8 + (size_t) w] : (to.nr > 0 ? to.col[0] : 0);
+                    int *pr = &out->tpro[(((size_t) g * D + (size_t) d) * T + (size_t) w) * 2];
+                    pr[0] = (d < to.nr) ? to.col[(size_t) d * T + (size_t) w] : (to.nr > 0 ? to.col[0] : 0);
                     pr[1] = (int) ((d < to.nr) ? voff[(size_t) d] : voff[(size_t) to.nr]);
                 }
             }
         }
     });
+    clk.lap("build_team2: records, value streams");
     out->vmap.assign(p.pmap.size(), 0u);
     for (size_t nz = 0; nz < p.pmap.size(); nz++) out->vmap[nz] = slot_of[(size_t) p.pmap[nz]];
+    clk.lap("build_team2: value-update map");
 }
 
 void apply_team_schedule(PanelHost *p, const TeamHost &t)

@@ -78,6 +78,7 @@ struct TeamHost
     int nteam = 0;
     int T = 4;                     // panels (= waves) per team: 4 (2 x 2 teeth) or 6 (3 x 2 teeth)
     bool lattice = false;
+    int st = 1;                    // lattice teams of 8 / 16: consecutive panels along the teeth (the team's advance = 8 st rows)
     bool clustered = false;        // T = 8 off a lattice: panels grouped by shared columns (plocal = slot of every panel in its team)
     std::vector<int>      plocal;
     std::vector<int>      tpanel;  // T * nteam: panel of wave w, or -1
@@ -123,6 +124,7 @@ constexpr int TEAM2_D = 3;
 constexpr int TEAM2_CAP = 4;
 struct Team2Host
 {
+    int T = TEAM2_T;                 // panels (= waves = slots of a round) per team: 8, or 16 (set before build_team2)
     int nteam = 0;
     bool lattice = false;
     std::vector<int>       tpanel;   // 8 * nteam: panel of wave w, or -1

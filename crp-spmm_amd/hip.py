@@ -138,7 +138,7 @@ def team_format_host(rowptr, colidx, val):
 
 
 def team2_format_host(rowptr, colidx, val):
-    """crp_team2_format_host -> dict(nteam, lattice, tpanel[nteam, 8], tinfo[nteam, 4], tpro[nteam, 3, 8, 2],
+    """crp_team2_format_host -> dict(nteam, waves W (8 or 16), lattice, tpanel[nteam, W], tinfo[nteam, 4], tpro[nteam, 3, W, 2],
     trec (uint32 words), tvoff, tval[groups, 8], torder, vmap)."""
     lib = L.load()
     rp = np.ascontiguousarray(rowptr, dtype=np.int32)
@@ -158,14 +158,15 @@ def team2_format_host(rowptr, colidx, val):
                                       C.byref(tpr), C.byref(tr), C.byref(nrw), C.byref(tv), C.byref(tval), C.byref(nve),
                                       C.byref(to), C.byref(vm)), "crp_team2_format_host")
     nt = nteam.value
+    W = int(lib.crp_team2_waves())
 
     def take(ptr, cnt, dt):
         out = np.ctypeslib.as_array(ptr, (max(cnt, 1),))[:cnt].astype(dt).copy()
         L.c_free(C.cast(ptr, C.c_void_p))
         return out
-    return dict(nteam=nt, lattice=bool(lat.value), tpanel=take(tp, 8 * nt, np.int32).reshape(nt, 8),
-                tinfo=take(ti, 4 * nt, np.int32).reshape(nt, 4), tpro=take(tpr, 48 * nt, np.int32).reshape(nt, 3, 8, 2),
-                trec=take(tr, nrw.value, np.uint32), tvoff=take(tv, 8 * nt + 1, np.int64),
+    return dict(nteam=nt, waves=W, lattice=bool(lat.value), tpanel=take(tp, W * nt, np.int32).reshape(nt, W),
+                tinfo=take(ti, 4 * nt, np.int32).reshape(nt, 4), tpro=take(tpr, 6 * W * nt, np.int32).reshape(nt, 3, W, 2),
+                trec=take(tr, nrw.value, np.uint32), tvoff=take(tv, W * nt + 1, np.int64),
                 tval=take(tval, 8 * nve.value, np.float64).reshape(-1, 8), torder=take(to, nt, np.int32),
                 vmap=take(vm, nnz, np.uint32))
 

@@ -160,7 +160,12 @@ int crp_team_format_host(int nrow, const int *rowptr, const int *colidx, const d
  * of round r+3's parts in the wave's stream, column this wave fetches for round r+3}; tpro[((3g + d)*8 + w)*2 ..]
  * = {column, value offset} of round d < 3; wave w's value groups (8 doubles per part, rows outside the part's
  * range 0) start at tval[8 * tvoff[8g + w]]; vmap[nz] = slot in tval of CSR nonzero nz.  *nvalent = groups in
- * tval.  malloc'd copies (caller frees).  Used by the CPU tests, which replay the streams in numpy. */
+ * tval.  malloc'd copies (caller frees).  Used by the CPU tests, which replay the streams in numpy.
+ * With W = crp_team2_waves() = 16 (CRPSPMM_TEAM2_WAVES=16: teams of 16 panels, one 1024-thread workgroup per CU)
+ * every "8 waves / 8 slots" above reads 16: tpanel[16g + w], tpro[((3g + d)*16 + w)*2], tvoff[16g + w], record
+ * blocks of 8 rounds x 16 waves x 4 words, ring slots 4 bits each from bit 4 of word 0, flags at bits 20-23
+ * (W = 8: slots 3 bits each, flags at bits 16-19). */
+int crp_team2_waves(void);
 int crp_team2_format_host(int nrow, const int *rowptr, const int *colidx, const double *val, int *nteam, int *lattice,
                           int **tpanel, int **tinfo, int **tpro, unsigned **trec, long long *nrecwords,
                           long long **tvoff, double **tval, long long *nvalent, int **torder, unsigned **vmap);

@@ -558,37 +558,42 @@ def _replay_team2(t, m, B, va=None):
     """Replays the team2 streams the way csrc/team2_kernel.hip walks them: per team and wave, round by round;
     the column behind ring slot e of round r is what wave e fetched for that round (tpro for the first 3
     rounds, the record of round r - 3 afterwards); the parts of round r take their values from the wave's stream
-    at the offset the record of round r - 3 (or tpro) announced."""
+    at the offset the record of round r - 3 (or tpro) announced.  W = 8 or 16 waves per team."""
+    W = t["waves"]
+    sbits, fbase = (3, 16) if W == 8 else (4, 20)
     C_out = np.zeros((m, B.shape[1]))
     written = np.zeros(m, dtype=bool)
-    rec = t["trec"].reshape(-1, 8, 8, 4)          # [block][round in block][wave][word]
+    rec = t["trec"].reshape(-1, 8, W, 4)          # [block][round in block][wave][word]
     for g in range(t["nteam"]):
         nr, blk0 = int(t["tinfo"][g, 0]), int(t["tinfo"][g, 1])
-        cols = np.zeros((nr, 8), dtype=np.int64)
-        voffs = np.zeros((nr, 8), dtype=np.int64)
+        cols = np.zeros((nr, W), dtype=np.int64)
+        voffs = np.zeros((nr, W), dtype=np.int64)
         for r in range(nr):
-            for w in range(8):
+            for w in range(W):
                 if r < 3:
                     cols[r, w], voffs[r, w] = t["tpro"][g, r, w]
                 else:
                     cols[r, w] = np.int32(rec[blk0 + ((r - 3) >> 3), (r - 3) & 7, w, 3])
                     voffs[r, w] = rec[blk0 + ((r - 3) >> 3), (r - 3) & 7, w, 2]
         parts_total = 0
-        for w in range(8):
+        for w in range(W):
             panel = int(t["tpanel"][g, w])
-            k0 = int(t["tvoff"][8 * g + w])
+            k0 = int(t["tvoff"][W * g + w])
             k = 0
             acc = np.zeros((8, B.shape[1]))
             for r in range(nr):
                 x, y = int(rec[blk0 + (r >> 3), r & 7, w, 0]), int(rec[blk0 + (r >> 3), r & 7, w, 1])
                 cnt = x & 7
                 assert cnt <= 4 and (x & 8) == 0
+                # flags: ISSUE while a round r + 3 exists, TAIL near the end, LAST on the last round
+                assert bool(x >> fbase & 1) == (r + 3 < nr) and bool(x >> (fbase + 2) & 1) == (r == nr - 1)
+                assert bool(x >> (fbase + 1) & 1) == (r + 2 >= nr)
                 if panel < 0:
                     assert cnt == 0
                 if cnt:
                     assert voffs[r, w] == k, (g, w, r)         # the announced offset is where the stream stands
                 for i in range(cnt):
-                    slot = (x >> (4 + 3 * i)) & 7
+                    slot = (x >> (4 + sbits * i)) & (W - 1)
                     first, ln = _range_of_code((y >> (6 * i)) & 63)
                     c = int(cols[r, slot])
                     assert 0 <= c < B.shape[0]
@@ -597,7 +602,7 @@ def _replay_team2(t, m, B, va=None):
                     k += 1
                 parts_total += cnt
             if panel >= 0:
-                assert k0 + k == int(t["tvoff"][8 * g + w + 1])
+                assert k0 + k == int(t["tvoff"][W * g + w + 1])
                 lo, hi = panel * 8, min(m, panel * 8 + 8)
                 C_out[lo:hi] = acc[:hi - lo]
                 assert not written[lo:hi].any()

@@ -1,12 +1,17 @@
 set -o pipefail
-bash tools/prof_r02.sh bench || exit 1
-OUT=gpurun_out/r02
-for cfg in "fem3d 1024 f64" "fem3d 1024 f32" "kkt 256 f64" "fem3d 256 f64"; do
-  set -- $cfg
-  timeout -k 10 300 python bench.py --steps 50 --no-cpu-baseline --no-also --matrix $1 --n $2 --dtype $3 > $OUT/bench_$1_n$2_$3.json 2> $OUT/bench_$1_n$2_$3.err || { tail -3 $OUT/bench_$1_n$2_$3.err; exit 1; }
-  echo "$cfg: $(python3 -c "import json;d=json.load(open('$OUT/bench_$1_n$2_$3.json'));print(d['value'], d['unit'], d['ms_per_step'], 'frac %.3f'%d['roofline']['frac'])")"
-done
-for n in 256 128; do
-  timeout -k 10 900 python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-also --matrix kkt240 --n $n > $OUT/bench_kkt240_n$n.json 2> $OUT/bench_kkt240_n$n.err || { tail -5 $OUT/bench_kkt240_n$n.err; exit 1; }
-  echo "kkt240 n=$n: $(python3 -c "import json;d=json.load(open('$OUT/bench_kkt240_n$n.json'));print(d['value'], d['ms_per_step'], 'frac %.3f'%d['roofline']['frac'], d['config'].get('first_exec_s'), d['config'].get('hbm_in_use_GB'))")"
-done
+mkdir -p gpurun_out/b28
+export CRPSPMM_TEAM2_WAVES=16
+bash tools/prof_counters.sh gpurun_out/b28/c16 \
+     "TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum" \
+     "TCC_EA0_RDREQ_sum GRBM_GUI_ACTIVE" \
+     "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES" \
+     "SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_VMEM SQ_INSTS_LDS" \
+     "FETCH_SIZE" "TA_TA_BUSY_sum TD_TD_BUSY_sum TCP_PENDING_STALL_CYCLES_sum" \
+     "SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA" \
+     -- --no-also --matrix pwtk > gpurun_out/b28/c16.txt 2>&1
+cat gpurun_out/b28/c16.txt
+unset CRPSPMM_TEAM2_WAVES
+bash tools/prof_counters.sh gpurun_out/b28/c8 \
+     "SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA" \
+     -- --no-also --matrix pwtk > gpurun_out/b28/c8.txt 2>&1
+cat gpurun_out/b28/c8.txt

@@ -52,9 +52,15 @@ NVREG = 26
 NSREG = 14
 
 
-def gen(nv, has_b1, f32=False):
+def gen(nv, has_b1, f32=False, tw=8):
     """nv = 16-byte pieces per lane and row; f32: 4 floats per piece (values 4 bytes, 8 per part = 32 bytes, value
-    slot 128 bytes), else 2 doubles per piece (values 8 bytes, 64 bytes per part, value slot 256 bytes)."""
+    slot 128 bytes), else 2 doubles per piece (values 8 bytes, 64 bytes per part, value slot 256 bytes).
+    tw = waves (= panels = slots of a round) per team: 8, or 16 (one 1024-thread workgroup per CU; slot numbers take 4
+    bits in w0, the flags move up to bits 20-23, a record block is 2 KiB)."""
+    sbits = 3 if tw == 8 else 4                     # bits of a slot number in w0
+    fbase = 16 if tw == 8 else 20                   # first flag bit of w0: ISSUE, TAIL, LAST, RECS
+    recrow = 16 * tw                                # bytes of the records of one round
+    recblk = 8 * recrow                             # ... of a record block
     vw = 4 if f32 else 2                            # elements per 16-byte piece
     vgrp = 32 if f32 else 64                        # bytes of one part's 8 values
     vslot = 4 * vgrp
@@ -64,20 +70,23 @@ def gen(nv, has_b1, f32=False):
     TA, TV, REC = b + 20, b + 21, b + 22
     PC, RET, TBA, TBB, T, CNT, RB, RS = SBASE, SBASE + 2, SBASE + 4, SBASE + 6, SBASE + 8, SBASE + 9, SBASE + 10, SBASE + 12
     slotb = 1024 * nv
-    setb = 8 * slotb
+    setb = tw * slotb
     slot_shift = 11 if nv == 2 else 10
     seq_align = {(1, False): 8, (2, False): 9, (1, True): 9, (2, True): 10}[(nv, f32)]   # 2^x >= 8 rows x nv * vw FMAs x 8 bytes + return
     opr = nv + 1                                    # DMAs a wave issues per round
-    tag = "%s%d%d_%%=" % ("s" if f32 else "d", nv, 1 if has_b1 else 0)
+    tag = "%s%d%d%s_%%=" % ("s" if f32 else "d", nv, 1 if has_b1 else 0, "w" if tw == 16 else "")
     L = []
     emit = L.append
 
     def rd(k, i, X):
-        emit("s_bfe_u32 s%d, %%[w0], 0x%x" % (T, (3 << 16) | (4 + 3 * i)))
-        emit("v_lshl_add_u32 v%d, s%d, %d, %%[seta]" % (TA, T, slot_shift))
-        emit("ds_read_b128 v[%d:%d], v%d offset:%d" % (X["s0"], X["s0"] + 3, TA, k * setb))
+        emit("s_bfe_u32 s%d, %%[w0], 0x%x" % (T, (sbits << 16) | (4 + sbits * i)))
+        # (a DS offset has 16 bits: the upper two sets of the 128 KiB ring of tw = 16, nv = 2 go through a second base)
+        far = k * setb + 1024 * (nv - 1) > 65535
+        koff = (k - 2) * setb if far else k * setb
+        emit("v_lshl_add_u32 v%d, s%d, %d, %%[%s]" % (TA, T, slot_shift, "seta2" if far else "seta"))
+        emit("ds_read_b128 v[%d:%d], v%d offset:%d" % (X["s0"], X["s0"] + 3, TA, koff))
         if nv == 2:
-            emit("ds_read_b128 v[%d:%d], v%d offset:%d" % (X["s1"], X["s1"] + 3, TA, k * setb + 1024))
+            emit("ds_read_b128 v[%d:%d], v%d offset:%d" % (X["s1"], X["s1"] + 3, TA, koff + 1024))
         if f32:
             emit("ds_read_b32 v%d, %%[vsl] offset:%d" % (X["v"], k * vslot + vgrp * i))
         else:
@@ -104,7 +113,7 @@ def gen(nv, has_b1, f32=False):
     for k in range(NSET):
         kd = (k + D) % NSET                          # set of round r + D
         emit(".Lt2round%d%s:" % (k, tag))
-        emit("s_bitcmp1_b32 %[w0], 17")
+        emit("s_bitcmp1_b32 %%[w0], %d" % (fbase + 1))
         emit("s_cbranch_scc1 .Lt2tw%d%s" % (k, tag))
         emit("s_waitcnt vmcnt(%d)" % ((D - 1) * opr))
         emit("s_barrier")
@@ -114,7 +123,7 @@ def gen(nv, has_b1, f32=False):
         emit("s_barrier")
         emit(".Lt2body%d%s:" % (k, tag))
         # -- issue for round r + D
-        emit("s_bitcmp1_b32 %[w0], 16")
+        emit("s_bitcmp1_b32 %%[w0], %d" % fbase)
         emit("s_cbranch_scc0 .Lt2ni%d%s" % (k, tag))
         emit("v_lshl_add_u32 v%d, %%[w2], %d, %%[lane16]" % (TV, 5 if f32 else 6))
         emit("s_mov_b64 exec, 0x%x" % ((1 << (vslot // 16)) - 1))
@@ -146,21 +155,23 @@ def gen(nv, has_b1, f32=False):
             emit("global_load_lds_dwordx4 %%[voffb], s[%d:%d] offset:1024%s" % (RB, RB + 1, BPOL))
         emit(".Lt2ni%d%s:" % (k, tag))
         # -- next record block (one wave, every 8 rounds)
-        emit("s_bitcmp1_b32 %[w0], 19")
+        emit("s_bitcmp1_b32 %%[w0], %d" % (fbase + 3))
         emit("s_cbranch_scc0 .Lt2nr%d%s" % (k, tag))
-        emit("s_add_u32 s%d, s%d, 1024" % (RS, RS))
+        emit("s_add_u32 s%d, s%d, %d" % (RS, RS, recblk))
         emit("s_addc_u32 s%d, s%d, 0" % (RS + 1, RS + 1))
-        emit("s_xor_b32 %[recdst], %[recdst], 1024")
+        emit("s_xor_b32 %%[recdst], %%[recdst], %d" % recblk)
         emit("s_mov_b32 m0, %[recdst]")
         emit("s_nop 0")
         emit("global_load_lds_dwordx4 %%[lane16], s[%d:%d]" % (RS, RS + 1))
+        for piece in range(1, recblk // 1024):      # (an immediate offset moves the global AND the LDS address)
+            emit("global_load_lds_dwordx4 %%[lane16], s[%d:%d] offset:%d" % (RS, RS + 1, 1024 * piece))
         emit(".Lt2nr%d%s:" % (k, tag))
         # -- record of the next round (LDS reads return in order: it is there when the parts are done)
         if k < NSET - 1:
-            emit("ds_read_b128 v[%d:%d], %%[recaddr] offset:%d" % (REC, REC + 3, (k + 1) * 128))
+            emit("ds_read_b128 v[%d:%d], %%[recaddr] offset:%d" % (REC, REC + 3, (k + 1) * recrow))
         else:
-            emit("v_add_u32 %[recoff], 512, %[recoff]")
-            emit("v_and_b32 %[recoff], 0x7ff, %[recoff]")
+            emit("v_add_u32 %%[recoff], %d, %%[recoff]" % (NSET * recrow))
+            emit("v_and_b32 %%[recoff], 0x%x, %%[recoff]" % (2 * recblk - 1))
             emit("v_add_u32 %[recaddr], %[recbase], %[recoff]")
             emit("ds_read_b128 v[%d:%d], %%[recaddr]" % (REC, REC + 3))
         # -- parts
@@ -190,7 +201,7 @@ def gen(nv, has_b1, f32=False):
             if c != 1:
                 emit("s_branch .Lt2pe%d%s" % (k, tag))
         emit(".Lt2pe%d%s:" % (k, tag))
-        emit("s_bitcmp1_b32 %[w0], 18")
+        emit("s_bitcmp1_b32 %%[w0], %d" % (fbase + 2))
         emit("s_cbranch_scc1 .Lt2done%s" % tag)
         emit("s_waitcnt lgkmcnt(0)")
         emit("v_readfirstlane_b32 %%[w0], v%d" % REC)
@@ -232,11 +243,12 @@ def main():
               % (VBASE, VBASE + NVREG - 1, SBASE, SBASE + NSREG - 1))
     out.write("#define CRP_TEAM2_CLOBBERS %s, %s\n" % (", ".join('"v%d"' % r for r in range(VBASE, VBASE + NVREG)),
                                                       ", ".join('"s%d"' % r for r in range(SBASE, SBASE + NSREG))))
-    for f32 in (False, True):
+    for tw in (8, 16):
+     for f32 in (False, True):
       for nv in (1, 2):
         for hb in (0, 1):
-            out.write("#define CRP_TEAM2_LOOP_%s_NV%d_B%d \\\n" % ("F32" if f32 else "F64", nv, hb))
-            lines = gen(nv, bool(hb), f32)
+            out.write("#define CRP_TEAM2_LOOP_%s_NV%d_B%d%s \\\n" % ("F32" if f32 else "F64", nv, hb, "_W16" if tw == 16 else ""))
+            lines = gen(nv, bool(hb), f32, tw)
             for k, l in enumerate(lines):
                 sep = "\\n\\t" if not l.endswith(":") else "\\n"
                 last = k == len(lines) - 1

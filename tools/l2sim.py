@@ -18,16 +18,17 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 
 def team_rounds(t):
     """cols[g] = int array [rounds, 8] of the B rows team g fetches, in issue order."""
-    rec = t["trec"].reshape(-1, 8, 8, 4)
+    W = t.get("waves", 8)
+    rec = t["trec"].reshape(-1, 8, W, 4)
     out = []
     for g in range(t["nteam"]):
         nr, blk0 = int(t["tinfo"][g, 0]), int(t["tinfo"][g, 1])
-        c = np.empty((nr, 8), dtype=np.int64)
+        c = np.empty((nr, W), dtype=np.int64)
         k = min(nr, 3)
         c[:k] = t["tpro"][g, :k, :, 0]
         if nr > 3:
             nb = (nr - 3 + 7) >> 3
-            c[3:] = rec[blk0:blk0 + nb, :, :, 3].reshape(-1, 8)[:nr - 3].astype(np.int32)
+            c[3:] = rec[blk0:blk0 + nb, :, :, 3].reshape(-1, W)[:nr - 3].astype(np.int32)
         out.append(c)
     return out
 
@@ -98,7 +99,10 @@ def main():
     rounds = team_rounds(t)
     tot = sum(len(r) for r in rounds)
     uniq = len(np.unique(np.concatenate([r.reshape(-1) for r in rounds])))
-    print("%s: %d rows, %d teams, %d rounds, %.2f slots/row, distinct B rows %d" % (a.matrix, m, t["nteam"], tot, 8.0 * tot / m, uniq))
+    W = t.get("waves", 8)
+    if "--wgs" not in sys.argv and W == 16:
+        a.wgs = 32                                     # one 1024-thread workgroup per CU
+    print("%s: %d rows, %d teams of %d, %d rounds, %.2f slots/row, distinct B rows %d" % (a.matrix, m, t["nteam"], W, tot, float(W) * tot / m, uniq))
     for rows in a.rows:
         req, miss = simulate(rounds, list(t["torder"]), rows, a.wgs)
         print("  L2 rows %5d wgs/xcd %d: requests %.3f GB, misses %.3f GB (%.2f x B), hit rate %.3f"
