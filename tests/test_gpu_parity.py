@@ -654,3 +654,17 @@ def test_fp32_two_source_and_update(crp, orc, gpu):
             torch.cuda.synchronize()
             assert orc.rel_fro_err(ref, Cd.cpu().numpy().astype(np.float64)) <= FP32_TOL, variant
     A.free()
+
+
+def test_team2_sixteen_panel_teams_in_a_child_process(crp, orc, gpu):
+    """CRPSPMM_TEAM2_WAVES=16 (teams of 16 panels, 1024-thread workgroups; read once per process, hence the child):
+    the team2 and fp32 parity tests of this file again, in one pytest child process on the same GPU."""
+    import subprocess
+    import sys
+    env = dict(os.environ, CRPSPMM_TEAM2_WAVES="16")
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_parity.py"), "-x", "-q", "-m", "gpu", "-k",
+                        "(team2 or fp32 or locality) and not child_process"], env=env, capture_output=True, text=True, timeout=900,
+                       cwd=os.path.dirname(here))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
