@@ -81,6 +81,10 @@ struct Team2Args          // panel_format.h, Team2Host
     const float    *tval32;    // the same value groups in fp32 (fp32 path), or nullptr
 };
 
+// narrow_kernel.hip: row-panel format, n <= 64 (several entries of a panel per instruction)
+bool spmm_narrow_applicable(const PanelArgs &p, const SpmmArgs &a);
+hipError_t spmm_rm_f64_narrow(const PanelArgs &p, const SpmmArgs &a, hipStream_t s);
+
 // spmm_kernels.hip
 hipError_t spmm_rm_f64_rowgroup(const SpmmArgs &a, hipStream_t s);
 hipError_t spmm_cm_f64(const SpmmArgs &a, hipStream_t s);

@@ -836,6 +836,7 @@ hipError_t spmm_rm_f64_panel(const PanelArgs &p_, const SpmmArgs &a, hipStream_t
     // team schedule: the per-round workgroup barrier pays from 128 columns on (n = 128: 0.204 -> 0.184 ms,
     // n = 1024: 1.40 -> 1.27 ms on the pwtk stand-in); at n <= 64 the rounds are too short (0.096 -> 0.099 ms)
     if (a.n <= 64) p.psync = nullptr;
+    if (spmm_narrow_applicable(p, a)) return spmm_rm_f64_narrow(p, a, s);      // narrow_kernel.hip
     if (p.R == 4) return launch_panel_shape<4>(p, a, s);
     if (p.R == 8) return launch_panel_shape<8>(p, a, s);
     return hipErrorInvalidValue;

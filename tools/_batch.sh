@@ -1,17 +1,10 @@
 set -o pipefail
-mkdir -p gpurun_out/b28
-export CRPSPMM_TEAM2_WAVES=16
-bash tools/prof_counters.sh gpurun_out/b28/c16 \
-     "TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum" \
-     "TCC_EA0_RDREQ_sum GRBM_GUI_ACTIVE" \
-     "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES" \
-     "SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_VMEM SQ_INSTS_LDS" \
-     "FETCH_SIZE" "TA_TA_BUSY_sum TD_TD_BUSY_sum TCP_PENDING_STALL_CYCLES_sum" \
-     "SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA" \
-     -- --no-also --matrix pwtk > gpurun_out/b28/c16.txt 2>&1
-cat gpurun_out/b28/c16.txt
-unset CRPSPMM_TEAM2_WAVES
-bash tools/prof_counters.sh gpurun_out/b28/c8 \
-     "SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA" \
-     -- --no-also --matrix pwtk > gpurun_out/b28/c8.txt 2>&1
-cat gpurun_out/b28/c8.txt
+mkdir -p gpurun_out/b32
+timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "not child_process" > gpurun_out/b32/pytest.txt 2>&1 || { tail -30 gpurun_out/b32/pytest.txt; exit 1; }
+tail -1 gpurun_out/b32/pytest.txt
+for cfg in "pwtk 32" "pwtk_shell 32" "fem3d 32" "pwtk 24"; do
+  set -- $cfg
+  timeout -k 10 300 python bench.py --steps 100 --no-cpu-baseline --no-also --matrix $1 --n $2 > gpurun_out/b32/bench_$1_$2.json 2> gpurun_out/b32/bench_$1_$2.err || { tail -3 gpurun_out/b32/bench_$1_$2.err; exit 1; }
+  echo "$1 n=$2: $(python3 -c "import json;d=json.load(open('gpurun_out/b32/bench_$1_$2.json'));print(d['roofline']['kernel'][-44:], 'frac %.3f'%d['roofline']['frac'])")"
+done
+CRPSPMM_NARROW_MAX=64 timeout -k 10 300 python bench.py --steps 100 --no-cpu-baseline --no-also --matrix pwtk --n 64 2>/dev/null | python3 -c "import json,sys;d=json.loads(sys.stdin.read());print('n=64 narrow:', d['roofline']['kernel'][-44:], 'frac %.3f'%d['roofline']['frac'])"
