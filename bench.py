@@ -387,6 +387,8 @@ def measure(args, matrix, mtx, steps, lib, torch, dist, comm, dev, world, rank, 
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
     ki = rp_eng.kernel_info()
     kname = KERNEL_SYMBOL.get(ki["variant_name"], str(ki["variant_name"]))
+    if ki["variant_name"] == "rowpanel-R8" and 24 <= n // pn <= 32 and (n // pn) % 2 == 0 and os.environ.get("CRPSPMM_NARROW", "1") != "0":
+        kname = "crp::spmm_narrow_f64_kernel<NP,HAS_B1,OFF32> (row-panel format, four entries per instruction)"
     traffic, tsrc = measured_traffic(matrix, data, n, world, ki["variant_name"])
     free_b, total_b = torch.cuda.mem_get_info()
     res = {

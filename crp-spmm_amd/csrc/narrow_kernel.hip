@@ -8,19 +8,21 @@
 // operands are what multi-GPU runs see.  There the row-panel kernel of spmm_kernels.hip is bound by the SCALAR unit
 // (38 M scalar instructions per launch on the pwtk stand-in at n = 32 and 64 alike: one EXEC write per row and
 // entry; the vector memory path is 36 % busy), because a B row slice of 256 bytes fills only 16 lanes and the
-// per-entry bookkeeping is paid for a quarter of a wave.  Here a wave takes G = 64 / LPG entries of its panel PER
-// INSTRUCTION: lanes [q * LPG, (q + 1) * LPG) hold entry e + q -- its B row slice (16 bytes per lane), its row mask,
+// per-entry bookkeeping is paid for a quarter of a wave.  Here a wave takes G = 4 entries of its panel PER
+// INSTRUCTION: lanes [16 q, 16 q + 16) hold entry e + q -- its B row slice (16 bytes per lane), its row mask,
 // and its 8 values in the lanes' low three bits -- and every row's FMA is ONE v_fmac_f64_dpp per column of the lane
 // for all G entries at once: the scalar factor comes through DPP row_newbcast:row from the lane's own 16-lane row,
-// and rows that an entry does not have are switched off through EXEC, set by a VECTOR compare of the lanes' masks
-// (v_cmpx), so that no scalar instruction is spent per row and an absent (row, column) pair is never multiplied
-// (no 0 * Inf).  The G partial sums of a row are added across the lane groups once per panel.
+// and rows that an entry does not have are switched off through EXEC, from a VECTOR compare of the lanes' masks
+// (one scalar move per row and FOUR entries instead of one per row and entry), so that an absent (row, column) pair is
+// never multiplied (no 0 * Inf).  The G partial sums of a row are added across the lane groups once per panel.
 // Column indices and masks of 64 entries are fetched by one coalesced load each and handed to the lane groups by
-// ds_bpermute.  Latency is hidden by occupancy (about 60 VGPRs: eight waves per SIMD), not by a register ring.
+// ds_bpermute.  Latency is hidden by occupancy (70 VGPRs: seven waves per SIMD, two steps in flight each), not by a
+// register ring.  pwtk stand-in n = 32: 0.090 ms (row-panel kernel) -> 0.062 ms, 8.6 M scalar instructions.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include "kernels.h"
+#include "narrow_rows.inc"
 
 namespace crp {
 
@@ -29,17 +31,19 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 
 }  // namespace
 
+// NP = 16-byte pieces per lane: 1 (n <= 32: columns 2 l, 2 l + 1 of lane l of a 16-lane group) or 2 (n <= 64: also columns
+// 32 + 2 l, 33 + 2 l -- the masks and the addressing of a step are then paid once for twice the FMAs).
 // OFF32: B0 alone and smaller than 4 GiB -- every lane multiplies ITS column by the row stride once per 64 entries and
 // the 32-bit byte offsets travel through ds_bpermute like the masks (the 64-bit multiply per step and lane group of the
-// general path is 84 of its 230 vector cycles per step)
-template <int LPG, bool HAS_B1, bool OFF32>
-__global__ __launch_bounds__(256) void spmm_narrow_f64_kernel(
+// general path was 84 of its 230 vector cycles per step).
+template <int NP, bool HAS_B1, bool OFF32>
+__global__ __launch_bounds__(256, NP == 2 ? 4 : 7) void spmm_narrow_f64_kernel(
     const int norder, const int nrow, const int n, const int *__restrict__ porder, const int *__restrict__ pcol,
     const uint32_t *__restrict__ pmask4, const double *__restrict__ pval,
     const double *__restrict__ B0, const int64_t ldB0, const double *__restrict__ B1, const int64_t ldB1,
     double *__restrict__ C, const int64_t ldC, const int *__restrict__ rowmap)
 {
-    constexpr int G = 64 / LPG;
+    constexpr int LPG = 16, G = 4;                                          // lanes per entry, entries per step
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     // XCD-aware placement, as in the row-panel kernel (the processing order is laid out for four-wave workgroups)
@@ -54,17 +58,23 @@ __global__ __launch_bounds__(256) void spmm_narrow_f64_kernel(
     const int nent = __builtin_amdgcn_readfirstlane(rec.z) * 8;            // padded to a multiple of 8: mask-0 entries, valid column
 
     const int q = lane / LPG, l = lane % LPG;
-    const bool ok = (2 * l + 1) < n;
-    const int bo = ok ? 2 * l : 0;                 // lanes past n read the row's first bytes: valid, never stored
-    const uint8_t *pmask = reinterpret_cast<const uint8_t *>(pmask4);
-    double a[16];
+    bool ok[NP];
+    int bo[NP];                                                             // lanes past n read the row's first bytes: valid, never stored
 #pragma unroll
-    for (int i = 0; i < 16; i++) a[i] = 0.0;
+    for (int p = 0; p < NP; p++)
+    {
+        ok[p] = (32 * p + 2 * l + 1) < n;
+        bo[p] = ok[p] ? 32 * p + 2 * l : 0;
+    }
+    const uint8_t *pmask = reinterpret_cast<const uint8_t *>(pmask4);
+    double a[16 * NP];
+#pragma unroll
+    for (int i = 0; i < 16 * NP; i++) a[i] = 0.0;
 
     const uint32_t ld32 = (uint32_t) (ldB0 * 8);
-    const char *const B0b = reinterpret_cast<const char *>(B0) + bo * 8;
+    const char *const B0b = reinterpret_cast<const char *>(B0);
     const int sh0 = q * 4;                                                  // ds_bpermute address of lane q
-    auto fetch = [&](const int mycol, const int mymask, const int ebase, const int s, double &v, d2 &b, int &mk) {
+    auto fetch = [&](const int mycol, const int mymask, const int ebase, const int s, double &v, d2 (&b)[NP], int &mk) {
         const int src = s * G + q;
         v = pval[(size_t) (ebase + src) * 8 + (size_t) (lane & 7)];
         if constexpr (OFF32)
@@ -72,56 +82,32 @@ __global__ __launch_bounds__(256) void spmm_narrow_f64_kernel(
             const int idx = sh0 + s * (G * 4);
             const uint32_t off = (uint32_t) __builtin_amdgcn_ds_bpermute(idx, mycol);      // mycol holds the byte offset of the row
             mk = __builtin_amdgcn_ds_bpermute(idx, mymask);
-            b = *reinterpret_cast<const d2 *>(B0b + off);
+#pragma unroll
+            for (int p = 0; p < NP; p++) b[p] = *reinterpret_cast<const d2 *>(B0b + off + bo[p] * 8);
         }
         else
         {
             const int col = __shfl(mycol, src);
             mk = __shfl(mymask, src);
             const double *brow = (!HAS_B1 || col >= 0) ? (B0 + (int64_t) col * ldB0) : (B1 + (int64_t) (~col) * ldB1);
-            b = *reinterpret_cast<const d2 *>(brow + bo);
+#pragma unroll
+            for (int p = 0; p < NP; p++) b[p] = *reinterpret_cast<const d2 *>(brow + bo[p]);
         }
     };
-    auto rows = [&](const double v, const d2 b, const int mk) {
+    // One step (narrow_rows.inc): the eight row masks of the lanes' entries first (vector compares into SGPR pairs, EXEC
+    // still full), then per row EXEC := its mask and the row's FMAs.  (EXEC written by the scalar unit needs no wait
+    // states before a DPP instruction; written by v_cmpx it needs five, which cost 40 idle cycles per step and wave.)
+    auto rows = [&](const double v, const d2 (&b)[NP], const int mk) {
         int t;
-        asm volatile(
-                "v_and_b32 %[t], 1, %[mk]\n\tv_cmpx_ne_u32 vcc, 0, %[t]\n\ts_nop 4\n\t"
-                "v_fmac_f64_dpp %[a0], %[v], %[bx] row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-                "v_fmac_f64_dpp %[a1], %[v], %[by] row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-                "s_mov_b64 exec, -1\n\t"
-                "v_and_b32 %[t], 2, %[mk]\n\tv_cmpx_ne_u32 vcc, 0, %[t]\n\ts_nop 4\n\t"
-                "v_fmac_f64_dpp %[a2], %[v], %[bx] row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
-                "v_fmac_f64_dpp %[a3], %[v], %[by] row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
-                "s_mov_b64 exec, -1\n\t"
-                "v_and_b32 %[t], 4, %[mk]\n\tv_cmpx_ne_u32 vcc, 0, %[t]\n\ts_nop 4\n\t"
-                "v_fmac_f64_dpp %[a4], %[v], %[bx] row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
-                "v_fmac_f64_dpp %[a5], %[v], %[by] row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
-                "s_mov_b64 exec, -1\n\t"
-                "v_and_b32 %[t], 8, %[mk]\n\tv_cmpx_ne_u32 vcc, 0, %[t]\n\ts_nop 4\n\t"
-                "v_fmac_f64_dpp %[a6], %[v], %[bx] row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
-                "v_fmac_f64_dpp %[a7], %[v], %[by] row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
-                "s_mov_b64 exec, -1\n\t"
-                "v_and_b32 %[t], 16, %[mk]\n\tv_cmpx_ne_u32 vcc, 0, %[t]\n\ts_nop 4\n\t"
-                "v_fmac_f64_dpp %[a8], %[v], %[bx] row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
-                "v_fmac_f64_dpp %[a9], %[v], %[by] row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
-                "s_mov_b64 exec, -1\n\t"
-                "v_and_b32 %[t], 32, %[mk]\n\tv_cmpx_ne_u32 vcc, 0, %[t]\n\ts_nop 4\n\t"
-                "v_fmac_f64_dpp %[a10], %[v], %[bx] row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
-                "v_fmac_f64_dpp %[a11], %[v], %[by] row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
-                "s_mov_b64 exec, -1\n\t"
-                "v_and_b32 %[t], 64, %[mk]\n\tv_cmpx_ne_u32 vcc, 0, %[t]\n\ts_nop 4\n\t"
-                "v_fmac_f64_dpp %[a12], %[v], %[bx] row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-                "v_fmac_f64_dpp %[a13], %[v], %[by] row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-                "s_mov_b64 exec, -1\n\t"
-                "v_and_b32 %[t], 0x80, %[mk]\n\tv_cmpx_ne_u32 vcc, 0, %[t]\n\ts_nop 4\n\t"
-                "v_fmac_f64_dpp %[a14], %[v], %[bx] row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-                "v_fmac_f64_dpp %[a15], %[v], %[by] row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-                "s_mov_b64 exec, -1"
-                : [a0] "+v"(a[0]), [a1] "+v"(a[1]), [a2] "+v"(a[2]), [a3] "+v"(a[3]), [a4] "+v"(a[4]), [a5] "+v"(a[5]),
-                  [a6] "+v"(a[6]), [a7] "+v"(a[7]), [a8] "+v"(a[8]), [a9] "+v"(a[9]), [a10] "+v"(a[10]), [a11] "+v"(a[11]),
-                  [a12] "+v"(a[12]), [a13] "+v"(a[13]), [a14] "+v"(a[14]), [a15] "+v"(a[15]), [t] "=&v"(t)
-                : [v] "v"(v), [bx] "v"(b.x), [by] "v"(b.y), [mk] "v"(mk)
-                : "vcc");
+        uint64_t x0, x1, x2, x3, x4, x5, x6, x7;
+#define CRP_NARROW_TMP [t] "=&v"(t), [x0] "=&s"(x0), [x1] "=&s"(x1), [x2] "=&s"(x2), [x3] "=&s"(x3), [x4] "=&s"(x4), [x5] "=&s"(x5), \
+                       [x6] "=&s"(x6), [x7] "=&s"(x7)
+        if constexpr (NP == 1)
+            asm volatile(CRP_NARROW_STEP_NP1 : CRP_NARROW_ACC_NP1(a), CRP_NARROW_TMP : [v] "v"(v), [b0x] "v"(b[0].x), [b0y] "v"(b[0].y), [mk] "v"(mk));
+        else
+            asm volatile(CRP_NARROW_STEP_NP2 : CRP_NARROW_ACC_NP2(a), CRP_NARROW_TMP
+                         : [v] "v"(v), [b0x] "v"(b[0].x), [b0y] "v"(b[0].y), [b1x] "v"(b[NP - 1].x), [b1y] "v"(b[NP - 1].y), [mk] "v"(mk));
+#undef CRP_NARROW_TMP
     };
     for (int base = 0; base < nent; base += 64)
     {
@@ -130,27 +116,29 @@ __global__ __launch_bounds__(256) void spmm_narrow_f64_kernel(
         if constexpr (OFF32) mycol = (int) ((uint32_t) mycol * ld32);
         const int mymask = (lane < ce) ? (int) pmask[e0 + base + lane] : 0;
         const int nstep = ce / G;                                          // even
-        // two steps per iteration: their loads are in flight together (the compiler's wait before an asm statement
-        // is vmcnt(0), so a deeper software pipeline across iterations would not overlap anything)
-        for (int s = 0; s < nstep; s += 2)
+        // NP = 1: two steps per iteration, their loads in flight together (the compiler's wait before an asm statement
+        // cannot be counted across the loop's back edge, so a deeper software pipeline would not overlap anything);
+        // NP = 2: one step (twice the bytes per step already, and two would spill at four waves per SIMD)
+        for (int s = 0; s < nstep; s += (NP == 1 ? 2 : 1))
         {
             double v0, v1;
-            d2 b0, b1;
+            d2 b0[NP], b1[NP];
             int m0, m1;
             fetch(mycol, mymask, e0 + base, s, v0, b0, m0);
-            fetch(mycol, mymask, e0 + base, s + 1, v1, b1, m1);
+            if constexpr (NP == 1) fetch(mycol, mymask, e0 + base, s + 1, v1, b1, m1);
             rows(v0, b0, m0);
-            rows(v1, b1, m1);
+            if constexpr (NP == 1) rows(v1, b1, m1);
         }
     }
-    // the G partial sums of every row: lanes l, l + LPG, ... -> all of them hold the total
+    // the G partial sums of every row: lanes l, l + 16, l + 32, l + 48 -> all of them hold the total
 #pragma unroll
-    for (int i = 0; i < 16; i++)
+    for (int i = 0; i < 16 * NP; i++)
     {
-        if constexpr (G == 4) a[i] += __shfl_xor(a[i], 16);
+        a[i] += __shfl_xor(a[i], 16);
         a[i] += __shfl_xor(a[i], 32);
+        if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);                // a few sums at a time: scheduled in bulk, their temporaries spill
     }
-    if (q == 0 && ok)
+    if (q == 0)
     {
 #pragma unroll
         for (int r = 0; r < 8; r++)
@@ -158,9 +146,14 @@ __global__ __launch_bounds__(256) void spmm_narrow_f64_kernel(
             const int row = panel * 8 + r;
             if (row < nrow)
             {
-                d2 t2 = {a[2 * r], a[2 * r + 1]};
                 double *crow = C + (int64_t) (rowmap ? rowmap[row] : row) * ldC;
-                __builtin_nontemporal_store(t2, reinterpret_cast<d2 *>(crow + 2 * l));
+#pragma unroll
+                for (int p = 0; p < NP; p++)
+                    if (ok[p])
+                    {
+                        d2 t2 = {a[(r * NP + p) * 2], a[(r * NP + p) * 2 + 1]};
+                        __builtin_nontemporal_store(t2, reinterpret_cast<d2 *>(crow + 32 * p + 2 * l));
+                    }
             }
         }
     }
@@ -170,8 +163,9 @@ __global__ __launch_bounds__(256) void spmm_narrow_f64_kernel(
 bool spmm_narrow_applicable(const PanelArgs &p, const SpmmArgs &a)
 {
     static const bool on = getenv("CRPSPMM_NARROW") == NULL || atoi(getenv("CRPSPMM_NARROW")) != 0;
-    // (LPG = 32, i.e. 32 < n <= 64, is built but not chosen: two entries per instruction pay the row overhead for
-    //  half the lanes' worth of work -- pwtk stand-in n = 64: 0.159 ms against 0.117 for the row-panel kernel)
+    // (NP = 2, i.e. 32 < n <= 64, is built but not chosen: 128 VGPRs leave four waves per SIMD with one step in flight
+    //  each -- pwtk stand-in n = 64: 0.168 ms against 0.117 for the row-panel kernel; with 32 lanes per entry and two
+    //  entries per instruction it was 0.115: no gain either.  CRPSPMM_NARROW_MAX=64 selects it.)
     static const int nmax = getenv("CRPSPMM_NARROW_MAX") ? atoi(getenv("CRPSPMM_NARROW_MAX")) : 32;
     return on && p.R == 8 && p.team_waves == 4 && a.n >= 24 && a.n <= nmax && a.n <= 64 && (a.n % 2 == 0) && (a.ldB0 % 2 == 0) && (a.ldC % 2 == 0) &&
            (a.B1 == nullptr || a.ldB1 % 2 == 0) && (((uintptr_t) a.B0 | (uintptr_t) a.B1 | (uintptr_t) a.C) % 16 == 0);
@@ -184,11 +178,11 @@ hipError_t spmm_rm_f64_narrow(const PanelArgs &p, const SpmmArgs &a, hipStream_t
     const bool has_b1 = a.B1 != nullptr && p.b1_rows > 0;
     // 32-bit byte offsets: B0 alone, every addressed byte below 4 GiB
     const bool off32 = !has_b1 && (uint64_t) p.b0_rows * (uint64_t) a.ldB0 * 8ull < (1ull << 32);
-#define CRP_NARROW_GO(LPG_, HB1_, O32_)                                                                                          \
-    hipLaunchKernelGGL((spmm_narrow_f64_kernel<LPG_, HB1_, O32_>), grid, dim3(256), 0, s, p.norder, a.nrow, a.n, p.porder, p.pcol, \
+#define CRP_NARROW_GO(NP_, HB1_, O32_)                                                                                           \
+    hipLaunchKernelGGL((spmm_narrow_f64_kernel<NP_, HB1_, O32_>), grid, dim3(256), 0, s, p.norder, a.nrow, a.n, p.porder, p.pcol, \
                        p.pmask4, p.pval, a.B0, a.ldB0, a.B1, a.ldB1, a.C, a.ldC, a.rowmap)
-    if (a.n <= 32) { if (has_b1) CRP_NARROW_GO(16, true, false); else if (off32) CRP_NARROW_GO(16, false, true); else CRP_NARROW_GO(16, false, false); }
-    else           { if (has_b1) CRP_NARROW_GO(32, true, false); else if (off32) CRP_NARROW_GO(32, false, true); else CRP_NARROW_GO(32, false, false); }
+    if (a.n <= 32) { if (has_b1) CRP_NARROW_GO(1, true, false); else if (off32) CRP_NARROW_GO(1, false, true); else CRP_NARROW_GO(1, false, false); }
+    else           { if (has_b1) CRP_NARROW_GO(2, true, false); else if (off32) CRP_NARROW_GO(2, false, true); else CRP_NARROW_GO(2, false, false); }
 #undef CRP_NARROW_GO
     return hipGetLastError();
 }
