@@ -1,9 +1,7 @@
 set -o pipefail
-mkdir -p gpurun_out/b34
-timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "not child_process" > gpurun_out/b34/pytest.txt 2>&1 || { tail -30 gpurun_out/b34/pytest.txt; exit 1; }
-tail -1 gpurun_out/b34/pytest.txt
-for cfg in "pwtk 32" "pwtk 64" "pwtk 48" "pwtk_shell 64" "fem3d 64" "kkt 64"; do
-  set -- $cfg
-  timeout -k 10 300 python bench.py --steps 100 --no-cpu-baseline --no-also --matrix $1 --n $2 > gpurun_out/b34/bench_$1_$2.json 2> gpurun_out/b34/bench_$1_$2.err || { tail -3 gpurun_out/b34/bench_$1_$2.err; exit 1; }
-  echo "$1 n=$2: $(python3 -c "import json;d=json.load(open('gpurun_out/b34/bench_$1_$2.json'));print(d['roofline']['kernel'][-44:], 'frac %.3f'%d['roofline']['frac'])")"
+bash tools/prof_r02.sh bench || exit 1
+OUT=gpurun_out/r02
+for v in 0 3 2 1; do
+  timeout -k 10 300 python bench.py --steps 50 --no-cpu-baseline --no-also --matrix kkt --n 32 --variant $v 2>/dev/null | python3 -c "import json,sys;d=json.loads(sys.stdin.read());print('kkt n=32 variant $v:', d['ms_per_step'], d['config']['kernel_variant_resolved'])"
 done
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.txt 2>&1; rc=$?; tail -3 $OUT/pytest_gpu.txt; [ $rc -eq 0 ] || exit 1
