@@ -221,9 +221,11 @@ static int ensure_team2(crp_csr_dev *A)
 {
     Team2Dev &t = A->team2;
     if (t.built) return 0;
+    crp::PhaseClock clk;
     crp::PanelHost h;
     crp::build_panels(A->nrow, fmt_rowptr(A), fmt_colidx(A), fmt_val(A), 8, &h, false);
     fmt_slotmap_to_caller(A, &h.pmap);
+    clk.lap("ensure_team2: build_panels (R = 8)");
     crp::Team2Host th;
     th.T = team2_waves();
     t.tw = th.T;
@@ -234,6 +236,7 @@ static int ensure_team2(crp_csr_dev *A)
         for (size_t i = 0; i < A->perm.size(); i++) colpos[(size_t) A->perm[i]] = (int) i;
     }
     crp::build_team2(h, A->nrow, fmt_rowptr(A), fmt_colidx(A), &th, colpos.empty() ? nullptr : colpos.data());
+    clk.lap("ensure_team2: build_team2");
     t.nteam = th.nteam;
     t.entries = th.real_entries;
     t.lattice = th.lattice;
@@ -255,6 +258,7 @@ static int ensure_team2(crp_csr_dev *A)
     if (e == hipSuccess) e = up((void **) &t.tval, th.tval.data(), sizeof(double) * th.tval.size(), 4096);
     if (e == hipSuccess) e = up((void **) &t.tmap, th.vmap.data(), sizeof(uint32_t) * th.vmap.size(), 4);
     if (e != hipSuccess) return (int) e;
+    clk.lap("ensure_team2: upload");
     t.built = true;
     return 0;
 }

@@ -9,22 +9,6 @@
 #include "par.h"
 #include <time.h>
 
-// CRPSPMM_TIMING=1: phase times of the format builders on stderr
-namespace {
-struct PhaseClock
-{
-    bool on = getenv("CRPSPMM_TIMING") != NULL && atoi(getenv("CRPSPMM_TIMING")) != 0;
-    double t0 = now();
-    static double now() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double) ts.tv_sec + 1e-9 * (double) ts.tv_nsec; }
-    void lap(const char *what)
-    {
-        if (!on) return;
-        const double t = now();
-        fprintf(stderr, "[crpspmm timing] %-44s %8.3f s\n", what, t - t0);
-        t0 = t;
-    }
-};
-}  // namespace
 
 namespace crp {
 
@@ -1130,10 +1114,11 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
         for (int q = 0; q < 8; q++)
             for (int i = cut[(size_t) q]; i < cut[(size_t) q + 1]; i++) out->tgrid[(size_t) q * cpx + (size_t) (i - cut[(size_t) q])] = out->torder[(size_t) i];
     }
-    out->trec.assign((size_t) blk0[(size_t) nteam] * blkw + blkw, 0u);
-    out->tval.assign((size_t) run * 8, 0.0);
+    parallel_fill(out->trec, (size_t) blk0[(size_t) nteam] * blkw + blkw, 0u);
+    parallel_fill(out->tval, (size_t) run * 8, 0.0);
     // vmap through the panel format's slot map: pmap[nz] = q * 8 + row of the panel format
-    std::vector<uint32_t> slot_of(p.pcol.size() * 8, 0xFFFFFFFFu);       // panel-format value slot -> tval slot
+    big_vector<uint32_t> slot_of;                                          // panel-format value slot -> tval slot
+    parallel_fill(slot_of, p.pcol.size() * 8, 0xFFFFFFFFu);
     parallel_chunks(nteam, 32, [&](long long b, long long e, int) {
         for (long long g = b; g < e; g++)
         {
@@ -1188,8 +1173,10 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
         }
     });
     clk.lap("build_team2: records, value streams");
-    out->vmap.assign(p.pmap.size(), 0u);
-    for (size_t nz = 0; nz < p.pmap.size(); nz++) out->vmap[nz] = slot_of[(size_t) p.pmap[nz]];
+    out->vmap.resize(p.pmap.size());
+    parallel_chunks((long long) p.pmap.size(), 1 << 18, [&](long long b, long long e, int) {
+        for (long long nz = b; nz < e; nz++) out->vmap[(size_t) nz] = slot_of[(size_t) p.pmap[(size_t) nz]];
+    });
     clk.lap("build_team2: value-update map");
 }
 

@@ -14,9 +14,29 @@
 // and fetches index / mask groups with aligned scalar loads.
 #pragma once
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <time.h>
 #include <vector>
+#include "par.h"
 
 namespace crp {
+
+// CRPSPMM_TIMING=1: phase times of the format builders on stderr
+struct PhaseClock
+{
+    bool on = getenv("CRPSPMM_TIMING") != NULL && atoi(getenv("CRPSPMM_TIMING")) != 0;
+    double t0 = now();
+    static double now() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double) ts.tv_sec + 1e-9 * (double) ts.tv_nsec; }
+    void lap(const char *what)
+    {
+        if (!on) return;
+        const double t = now();
+        fprintf(stderr, "[crpspmm timing] %-44s %8.3f s\n", what, t - t0);
+        t0 = t;
+    }
+};
+
 
 constexpr int PANEL_PAD = 8;   // = PANEL_RING of the kernels (spmm_kernels.hip)
 
@@ -133,9 +153,9 @@ struct Team2Host
                                      // order (a contiguous piece of torder; -1 = no team); the pieces carry equal ROUNDS
     std::vector<int>       tinfo;    // 4 * nteam: rounds, first record block, parts of all waves, filled slots
     std::vector<int>       tpro;     // nteam * TEAM2_D * 8 * 2: {column, value offset} wave w fetches for round d < TEAM2_D
-    std::vector<uint32_t>  trec;     // record blocks: 256 words each
+    big_vector<uint32_t>   trec;     // record blocks: 32 T words each (8 rounds x T waves x 4)
     std::vector<long long> tvoff;    // 8 * nteam + 1: first value group of wave w's stream
-    std::vector<double>    tval;     // value groups (8 doubles each)
+    big_vector<double>     tval;     // value groups (8 doubles each)
     std::vector<uint32_t>  vmap;     // per CSR nonzero (panel format's own order of pmap): its slot in tval
     long long real_entries = 0;      // union entries (filled slots)
     long long slots = 0;             // slots including the empty ones of partly filled rounds

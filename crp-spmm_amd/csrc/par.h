@@ -5,7 +5,9 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
+#include <memory>
 #include <thread>
+#include <utility>
 #include <vector>
 
 namespace crp {
@@ -48,6 +50,27 @@ void parallel_chunks(long long n, long long chunk, F fn)
     for (int t = 1; t < nthr; t++) pool.emplace_back(worker, t);
     worker(0);
     for (auto &th : pool) th.join();
+}
+
+// std::vector whose resize() leaves new elements uninitialised (for arrays of hundreds of MB that are filled by
+// parallel_fill / by all threads afterwards: a value-initialising resize touches every page from ONE thread first)
+template <typename T>
+struct default_init_allocator : std::allocator<T>
+{
+    template <typename U> struct rebind { typedef default_init_allocator<U> other; };
+    default_init_allocator() = default;
+    template <typename U> default_init_allocator(const default_init_allocator<U> &) {}
+    template <typename U> void construct(U *p) { ::new (static_cast<void *>(p)) U; }
+    template <typename U, typename... A> void construct(U *p, A &&...a) { ::new (static_cast<void *>(p)) U(std::forward<A>(a)...); }
+};
+template <typename T> using big_vector = std::vector<T, default_init_allocator<T>>;
+
+template <typename V, typename T>
+void parallel_fill(V &v, size_t n, T value)
+{
+    v.resize(n);
+    auto *p = v.data();
+    parallel_chunks((long long) n, 1 << 20, [&](long long b, long long e, int) { std::fill(p + b, p + e, value); });
 }
 
 }  // namespace crp
