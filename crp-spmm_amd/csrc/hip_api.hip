@@ -90,10 +90,10 @@ static const int *fmt_rowptr(const crp_csr_dev *A) { return A->perm.empty() ? A-
 static const int *fmt_colidx(const crp_csr_dev *A) { return A->perm.empty() ? A->h_colidx.data() : A->f_colidx.data(); }
 static const double *fmt_val(const crp_csr_dev *A) { return A->perm.empty() ? A->h_val.data() : A->f_val.data(); }
 // slot map of a derived format, built on the processing order, re-indexed by the caller's nonzero positions
-static void fmt_slotmap_to_caller(const crp_csr_dev *A, std::vector<uint32_t> *pmap)
+static void fmt_slotmap_to_caller(const crp_csr_dev *A, crp::big_vector<uint32_t> *pmap)
 {
     if (A->perm.empty()) return;
-    std::vector<uint32_t> out(pmap->size());
+    crp::big_vector<uint32_t> out(pmap->size());
     for (size_t pz = 0; pz < pmap->size(); pz++) out[(size_t) A->f_nz[pz]] = (*pmap)[pz];
     pmap->swap(out);
 }
@@ -156,7 +156,7 @@ static int ensure_panel(crp_csr_dev *A, int idx)
     {
         // the kernels read column indices up to three rounds past a panel: the tail of the array
         // repeats the last real column (an addressable row), never an arbitrary value
-        std::vector<int> padded(h.pcol);
+        std::vector<int> padded(h.pcol.begin(), h.pcol.end());
         padded.resize(h.pcol.size() + 64, h.pcol.back());
         e = hipMemcpy(d.pcol, padded.data(), sizeof(int) * padded.size(), hipMemcpyHostToDevice);
     }
@@ -223,7 +223,7 @@ static int ensure_team2(crp_csr_dev *A)
     if (t.built) return 0;
     crp::PhaseClock clk;
     crp::PanelHost h;
-    crp::build_panels(A->nrow, fmt_rowptr(A), fmt_colidx(A), fmt_val(A), 8, &h, false);
+    crp::build_panels(A->nrow, fmt_rowptr(A), fmt_colidx(A), fmt_val(A), 8, &h, false, false);
     fmt_slotmap_to_caller(A, &h.pmap);
     clk.lap("ensure_team2: build_panels (R = 8)");
     crp::Team2Host th;

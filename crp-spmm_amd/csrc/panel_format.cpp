@@ -120,7 +120,7 @@ long long count_block_union(int nrow, const int *rowptr, const int *colidx, int 
 }
 
 void build_panels(int nrow, const int *rowptr, const int *colidx, const double *val, int R, PanelHost *out,
-                  bool team_schedule)
+                  bool team_schedule, bool need_order)
 {
     const int npanel = (nrow + R - 1) / R;
     out->R = R;
@@ -147,10 +147,10 @@ void build_panels(int nrow, const int *rowptr, const int *colidx, const double *
     }
     out->real_entries = real;
     const size_t total = (size_t) out->pptr[npanel];
-    out->pcol.assign(total, 0);
-    out->pmask4.assign(total / 4 + 2, 0u);
-    out->pval.assign(total * (size_t) R, 0.0);
-    out->pmap.assign((size_t) rowptr[nrow], 0u);
+    parallel_fill(out->pcol, total, 0);
+    parallel_fill(out->pmask4, total / 4 + 2, 0u);
+    parallel_fill(out->pval, total * (size_t) R, 0.0);
+    parallel_fill(out->pmap, (size_t) rowptr[nrow], 0u);
     // pass 2: fill
     parallel_chunks(npanel, 512, [&](long long b, long long e, int) {
         std::vector<Trip> tmp;
@@ -179,6 +179,9 @@ void build_panels(int nrow, const int *rowptr, const int *colidx, const double *
     // 3 team schedule (2 and 3 only when the matrix has a stride lattice, else natural); unset = team
     // schedule (R = 8) or panel lattice (R = 4) when a lattice is detected, else breadth-first groups.
     // CRPSPMM_PANEL_GROUP = panels per breadth-first group.
+    out->porder.clear();
+    out->psync.clear();
+    if (!need_order) return;
     const char *eo = getenv("CRPSPMM_PANEL_ORDER"), *eg = getenv("CRPSPMM_PANEL_GROUP");
     const int group = (eg && atoi(eg) > 0) ? atoi(eg) : 16;
     const int mode = eo ? atoi(eo) : -1;
@@ -543,6 +546,39 @@ static void greedy_cluster(int n, const std::vector<long long> &iptr, const std:
     *ngroups = base[(size_t) nrange];
 }
 
+
+// CSR of sorted distinct keys per item, built in parallel: raw(i, buf) appends item i's keys to buf.
+template <typename F>
+static void build_key_csr(int n, F raw, std::vector<long long> *iptr, std::vector<uint32_t> *ikey)
+{
+    constexpr int CH = 2048;
+    const int nch = (n + CH - 1) / CH;
+    iptr->assign((size_t) n + 1, 0);
+    std::vector<std::vector<uint32_t>> cbuf((size_t) nch);
+    parallel_chunks(nch, 1, [&](long long cb, long long ce, int) {
+        for (long long c = cb; c < ce; c++)
+        {
+            std::vector<uint32_t> &buf = cbuf[(size_t) c];
+            const int i0 = (int) c * CH, i1 = std::min(n, i0 + CH);
+            for (int i = i0; i < i1; i++)
+            {
+                const size_t at = buf.size();
+                raw(i, buf);
+                std::sort(buf.begin() + (long) at, buf.end());
+                buf.erase(std::unique(buf.begin() + (long) at, buf.end()), buf.end());
+                (*iptr)[(size_t) i + 1] = (long long) (buf.size() - at);
+            }
+        }
+    });
+    for (int i = 0; i < n; i++) (*iptr)[(size_t) i + 1] += (*iptr)[(size_t) i];
+    ikey->resize((size_t) (*iptr)[(size_t) n]);
+    parallel_chunks(nch, 1, [&](long long cb, long long ce, int) {
+        for (long long c = cb; c < ce; c++)
+            if (!cbuf[(size_t) c].empty())
+                memcpy(ikey->data() + (*iptr)[(size_t) c * CH], cbuf[(size_t) c].data(), sizeof(uint32_t) * cbuf[(size_t) c].size());
+    });
+}
+
 void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *colidx, TeamHost *out, int T)
 {
     constexpr int TMAX = 16;
@@ -594,18 +630,12 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
     std::vector<int> team_of, slot_of;
     if (clustered)
     {
-        std::vector<long long> iptr((size_t) np + 1, 0);
+        std::vector<long long> iptr;
         std::vector<uint32_t> ikey;
-        ikey.reserve(p.pcol.size());
-        for (int q = 0; q < np; q++)
-        {
+        build_key_csr(np, [&](int q, std::vector<uint32_t> &buf) {
             const int e0 = p.pptr[q], e1 = e0 + real_count(q);
-            const size_t at = ikey.size();
-            for (int e = e0; e < e1; e++) ikey.push_back(col_key(p.pcol[(size_t) e]));
-            std::sort(ikey.begin() + (long) at, ikey.end());
-            ikey.erase(std::unique(ikey.begin() + (long) at, ikey.end()), ikey.end());
-            iptr[(size_t) q + 1] = (long long) ikey.size();
-        }
+            for (int e = e0; e < e1; e++) buf.push_back(col_key(p.pcol[(size_t) e]));
+        }, &iptr, &ikey);
         int ng = 0;
         greedy_cluster(np, iptr, ikey, T, 1 << 15, &team_of, &slot_of, &ng);
         if (lattice)
@@ -867,17 +897,11 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
         // their unions by the same phase key, so rows shared INSIDE such a generation are requested together and
         // served by the XCD's L2 once.  Generations = super-teams of 64 teams clustered by shared columns, again
         // greedily; the kernel deals the order to the XCDs in eight contiguous runs.
-        std::vector<long long> iptr((size_t) nteam + 1, 0);
+        std::vector<long long> iptr;
         std::vector<uint32_t> ikey;
-        ikey.reserve((size_t) real);
-        for (int g = 0; g < nteam; g++)
-        {
-            const size_t at = ikey.size();
-            for (int c : ucol[(size_t) g]) ikey.push_back(col_key(c));
-            std::sort(ikey.begin() + (long) at, ikey.end());
-            ikey.erase(std::unique(ikey.begin() + (long) at, ikey.end()), ikey.end());
-            iptr[(size_t) g + 1] = (long long) ikey.size();
-        }
+        build_key_csr(nteam, [&](int g, std::vector<uint32_t> &buf) {
+            for (int c : ucol[(size_t) g]) buf.push_back(col_key(c));
+        }, &iptr, &ikey);
         std::vector<int> super_of, sslot;
         int ns = 0;
         greedy_cluster(nteam, iptr, ikey, T == 16 ? 32 : 64, 1 << 13, &super_of, &sslot, &ns);   // the workgroups resident on an XCD
@@ -886,26 +910,52 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
         // so that an XCD's L2 sees one compact region and consecutive generations are neighbours
         std::vector<int> srank((size_t) ns);
         {
-            std::vector<std::pair<uint32_t, int>> ks;
-            ks.reserve(ikey.size());
-            for (int g = 0; g < nteam; g++)
-                for (long long q = iptr[(size_t) g]; q < iptr[(size_t) g + 1]; q++) ks.push_back({ikey[(size_t) q], super_of[(size_t) g]});
-            std::sort(ks.begin(), ks.end());
-            ks.erase(std::unique(ks.begin(), ks.end()), ks.end());
+            // (key, super-team) pairs are sorted per range of teams, in parallel -- the ranges greedy_cluster() worked on, so a
+            // super-team lies inside one; edges between super-teams of different ranges are left out except for a link
+            // between the last of a range and the first of the next, which keeps the slabs in range order
+            const int span = 1 << 13;
+            const int nrange = (nteam + span - 1) / span;
             std::vector<int> weight((size_t) ns, 0);
-            std::vector<std::pair<int, int>> edges;
-            for (size_t a = 0; a < ks.size();)
-            {
-                size_t b = a;
-                while (b < ks.size() && ks[b].first == ks[a].first) b++;
-                for (size_t x = a; x < b; x++)
+            std::vector<std::vector<std::pair<int, int>>> redges((size_t) nrange);
+            parallel_chunks(nrange, 1, [&](long long rb, long long re, int) {
+                for (long long rg = rb; rg < re; rg++)
                 {
-                    weight[(size_t) ks[x].second]++;
-                    for (size_t y = a; y < b; y++)
-                        if (x != y) edges.push_back({ks[x].second, ks[y].second});
+                    const int g0 = (int) rg * span, g1 = std::min(nteam, g0 + span);
+                    std::vector<std::pair<uint32_t, int>> ks;
+                    ks.reserve((size_t) (iptr[(size_t) g1] - iptr[(size_t) g0]));
+                    for (int g = g0; g < g1; g++)
+                        for (long long q = iptr[(size_t) g]; q < iptr[(size_t) g + 1]; q++) ks.push_back({ikey[(size_t) q], super_of[(size_t) g]});
+                    std::sort(ks.begin(), ks.end());
+                    ks.erase(std::unique(ks.begin(), ks.end()), ks.end());
+                    std::vector<std::pair<int, int>> &edges = redges[(size_t) rg];
+                    for (size_t a = 0; a < ks.size();)
+                    {
+                        size_t b = a;
+                        while (b < ks.size() && ks[b].first == ks[a].first) b++;
+                        for (size_t x = a; x < b; x++)
+                        {
+                            weight[(size_t) ks[x].second]++;            // (a super-team belongs to one range: no race)
+                            for (size_t y = a; y < b; y++)
+                                if (x != y) edges.push_back({ks[x].second, ks[y].second});
+                        }
+                        a = b;
+                        if (edges.size() > (size_t) 1 << 22) { std::sort(edges.begin(), edges.end()); edges.erase(std::unique(edges.begin(), edges.end()), edges.end()); }
+                    }
+                    std::sort(edges.begin(), edges.end());
+                    edges.erase(std::unique(edges.begin(), edges.end()), edges.end());
                 }
-                a = b;
-                if (edges.size() > (size_t) 1 << 24) { std::sort(edges.begin(), edges.end()); edges.erase(std::unique(edges.begin(), edges.end()), edges.end()); }
+            });
+            std::vector<std::pair<int, int>> edges;
+            for (int rg = 0; rg < nrange; rg++)
+            {
+                edges.insert(edges.end(), redges[(size_t) rg].begin(), redges[(size_t) rg].end());
+                if (rg + 1 < nrange)
+                {
+                    const int last = super_of[(size_t) std::min(nteam, (rg + 1) * span) - 1], first = super_of[(size_t) (rg + 1) * span];
+                    if (last != first) { edges.push_back({last, first}); edges.push_back({first, last}); }
+                }
+                redges[(size_t) rg].clear();
+                redges[(size_t) rg].shrink_to_fit();
             }
             std::sort(edges.begin(), edges.end());
             edges.erase(std::unique(edges.begin(), edges.end()), edges.end());
@@ -977,8 +1027,11 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
     struct TeamOut
     {
         int nr = 0, filled = 0, nparts = 0;
-        std::vector<int> col;                       // nr * 8 slot columns
-        std::vector<std::vector<Part>> own;         // nr * 8: parts of wave w in round r
+        std::vector<int> col;                       // nr * T slot columns
+        // parts of wave w in round r: ownp[(r * T + w) * CAP .. + ownc[r * T + w])  (flat: one small vector per
+        // (round, wave) was 126 M heap allocations on the nlpkkt240-size matrix)
+        std::vector<Part> ownp;
+        std::vector<unsigned char> ownc;
     };
     std::vector<TeamOut> res((size_t) nteam);
     parallel_chunks(nteam, 32, [&](long long b, long long e, int) {
@@ -1028,7 +1081,8 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
                 int nslot = 0;
                 const size_t base_col = to.col.size();
                 to.col.resize(base_col + (size_t) T, last_col);
-                to.own.resize(to.own.size() + (size_t) T);
+                to.ownp.resize(to.ownp.size() + (size_t) T * CAP);
+                to.ownc.resize(to.ownc.size() + (size_t) T, 0);
                 while (head < nodes.size() && taken[head]) head++;
                 int seen = 0;
                 for (size_t t = head; t < nodes.size() && nslot < T && seen < 4 * T; t++)
@@ -1052,7 +1106,8 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
                             Part pt = tmp[w][i];
                             pt.slot = nslot;
                             pt.src = th.tsrc[(size_t) q * T + (size_t) w];
-                            to.own[(size_t) to.nr * T + (size_t) w].push_back(pt);
+                            to.ownp[((size_t) to.nr * T + (size_t) w) * CAP + (size_t) cnt[w]] = pt;
+                            to.ownc[(size_t) to.nr * T + (size_t) w]++;
                             cnt[w]++;
                             to.nparts++;
                         }
@@ -1089,7 +1144,7 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
         for (int w = 0; w < T; w++)
         {
             out->tvoff[(size_t) g * T + (size_t) w] = run;
-            for (int r = 0; r < to.nr; r++) run += (long long) to.own[(size_t) r * T + (size_t) w].size();
+            for (int r = 0; r < to.nr; r++) run += (long long) to.ownc[(size_t) r * T + (size_t) w];
         }
     }
     out->tvoff[(size_t) nteam * T] = run;
@@ -1129,9 +1184,10 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
                 const long long k0 = k;
                 for (int r = 0; r < to.nr; r++)
                 {
-                    const std::vector<Part> &ow = to.own[(size_t) r * T + (size_t) w];
-                    uint32_t x = (uint32_t) ow.size(), y = 0;
-                    for (size_t i = 0; i < ow.size(); i++)
+                    const Part *ow = &to.ownp[((size_t) r * T + (size_t) w) * CAP];
+                    const size_t nown = to.ownc[(size_t) r * T + (size_t) w];
+                    uint32_t x = (uint32_t) nown, y = 0;
+                    for (size_t i = 0; i < nown; i++)
                     {
                         const Part &pt = ow[i];
                         x |= (uint32_t) pt.slot << (4 + sbits * (int) i);
@@ -1149,7 +1205,7 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
                 }
                 // value offsets and columns fetched D rounds ahead
                 std::vector<long long> voff((size_t) to.nr + 1, 0);
-                for (int r = 0; r < to.nr; r++) voff[(size_t) r + 1] = voff[(size_t) r] + (long long) to.own[(size_t) r * T + (size_t) w].size();
+                for (int r = 0; r < to.nr; r++) voff[(size_t) r + 1] = voff[(size_t) r] + (long long) to.ownc[(size_t) r * T + (size_t) w];
                 (void) k0;
                 for (int r = 0; r < to.nr; r++)
                 {
@@ -1184,9 +1240,9 @@ void apply_team_schedule(PanelHost *p, const TeamHost &t)
 {
     const int R = p->R, T = t.T;
     p->team_waves = T;
-    std::vector<int> ncol(p->pcol.size());
-    std::vector<uint32_t> nmask4(p->pmask4.size(), 0u);
-    std::vector<double> nval(p->pval.size(), 0.0);
+    big_vector<int> ncol(p->pcol.size(), 0);
+    big_vector<uint32_t> nmask4(p->pmask4.size(), 0u);
+    big_vector<double> nval(p->pval.size(), 0.0);
     std::vector<long long> moved(p->pcol.size(), -1);        // old entry -> new entry
     auto mask_of = [&](size_t q) { return (p->pmask4[q >> 2] >> (8 * (q & 3))) & 0xFFu; };
     for (int g = 0; g < t.nteam; g++)

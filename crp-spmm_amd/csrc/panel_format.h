@@ -45,10 +45,10 @@ struct PanelHost
     int R = 0;
     int npanel = 0;
     std::vector<int>      pptr;    // npanel + 1, entry offsets (multiples of PANEL_PAD)
-    std::vector<int>      pcol;    // entries: two-source column index
-    std::vector<uint32_t> pmask4;  // entries / 4 words: byte u of word g = mask of entry 4g + u
-    std::vector<double>   pval;    // entries * R, value of row r of entry q at q*R + r
-    std::vector<uint32_t> pmap;    // nnz: slot (q*R + r) in pval of CSR nonzero p (for value updates)
+    big_vector<int>       pcol;    // entries: two-source column index
+    big_vector<uint32_t>  pmask4;  // entries / 4 words: byte u of word g = mask of entry 4g + u
+    big_vector<double>    pval;    // entries * R, value of row r of entry q at q*R + r
+    big_vector<uint32_t>  pmap;    // nnz: slot (q*R + r) in pval of CSR nonzero p (for value updates)
     std::vector<int>      porder;  // processing order of the panels (npanel positions; team schedule: 4 per team, -1 = none)
     std::vector<int>      psync;   // team schedule only: per workgroup, the rounds its waves start together
     int team_waves = 4;            // waves per workgroup the processing order is laid out for (4, or 6 under the team schedule)
@@ -176,8 +176,9 @@ long long count_panel_entries(int nrow, const int *rowptr, const int *colidx, in
 long long count_block_union(int nrow, const int *rowptr, const int *colidx, int block);
 
 // team_schedule = false keeps the entries of every panel in column order whatever CRPSPMM_PANEL_ORDER
-// says (the team format is built on that order).
+// says (the team format is built on that order).  need_order = false skips the processing order (porder stays empty):
+// the team formats bring their own.
 void build_panels(int nrow, const int *rowptr, const int *colidx, const double *val, int R, PanelHost *out,
-                  bool team_schedule = true);
+                  bool team_schedule = true, bool need_order = true);
 
 }  // namespace crp
