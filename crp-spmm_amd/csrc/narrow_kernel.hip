@@ -165,7 +165,8 @@ bool spmm_narrow_applicable(const PanelArgs &p, const SpmmArgs &a)
     static const bool on = getenv("CRPSPMM_NARROW") == NULL || atoi(getenv("CRPSPMM_NARROW")) != 0;
     // (NP = 2, i.e. 32 < n <= 64, is built but not chosen: 128 VGPRs leave four waves per SIMD with one step in flight
     //  each -- pwtk stand-in n = 64: 0.168 ms against 0.117 for the row-panel kernel; with 32 lanes per entry and two
-    //  entries per instruction it was 0.115: no gain either.  CRPSPMM_NARROW_MAX=64 selects it.)
+    //  entries per instruction it was 0.115: no gain either; at five waves per SIMD (96 VGPRs, the epilogue's sums
+    //  spilled) 0.209.  CRPSPMM_NARROW_MAX=64 selects it.)
     static const int nmax = getenv("CRPSPMM_NARROW_MAX") ? atoi(getenv("CRPSPMM_NARROW_MAX")) : 32;
     return on && p.R == 8 && p.team_waves == 4 && a.n >= 24 && a.n <= nmax && a.n <= 64 && (a.n % 2 == 0) && (a.ldB0 % 2 == 0) && (a.ldC % 2 == 0) &&
            (a.B1 == nullptr || a.ldB1 % 2 == 0) && (((uintptr_t) a.B0 | (uintptr_t) a.B1 | (uintptr_t) a.C) % 16 == 0);
