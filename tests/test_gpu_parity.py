@@ -656,6 +656,83 @@ def test_fp32_two_source_and_update(crp, orc, gpu):
     A.free()
 
 
+@pytest.mark.parametrize("n", [24, 26, 30, 32])
+def test_narrow_kernel(crp, orc, gpu, n):
+    """The narrow-operand kernel (csrc/narrow_kernel.hip: row-panel format, four entries per instruction; variant 3 at
+    24 <= n <= 32, even n, 16-byte aligned operands): random / banded / empty-row matrices with padded leading dimensions,
+    the two-source column index (general addressing path), non-finite B rows next to absent pairs, value updates,
+    bit-identical repeats, and B rows past 4 GiB (64-bit addressing path)."""
+    import torch
+    from crp_spmm_amd import gen, hip
+    lib = crp.load()
+    cases = [gen.random_csr(777, 1234, 70, seed=n, empty_every=13), gen.banded_fem(5000, offsets=(1, 2, 3, 40, 41, 900), seed=n),
+             gen.random_csr(13, 40, 5, seed=1)]
+    for rp, ci, va in cases:
+        m = len(rp) - 1
+        k = max(int(ci.max()) + 1, 1) if ci.size else 1
+        B = np.random.default_rng(n).uniform(-2, 2, size=(k, n))
+        ref = orc.spmm_csr(rp, ci, va, B)
+        for ldpad in (0, 2, 6):
+            got = _spmm(crp, gpu, rp, ci, va, k, B, n, ldpad=ldpad, variant=3)
+            assert orc.rel_fro_err(ref, got) <= FP64_TOL, (m, ldpad)
+    # two-source column index
+    m, k = 500, 900
+    rp, ci, va = gen.random_csr(m, k, 30, seed=2)
+    lo, hi = 300, 650
+    remote_rows = np.concatenate([np.arange(0, lo), np.arange(hi, k)])
+    pos = np.full(k, -1)
+    pos[remote_rows] = np.arange(remote_rows.size)
+    c2 = np.where((ci >= lo) & (ci < hi), ci - lo, ~pos[ci]).astype(np.int32)
+    B = np.random.default_rng(n + 1).normal(size=(k, n))
+    got = _spmm(crp, gpu, rp, c2, va, hi - lo, B[lo:hi], n, B1=B[remote_rows], variant=3)
+    assert orc.rel_fro_err(orc.spmm_csr(rp, ci, va, B), got) <= FP64_TOL
+    # non-finite B rows: an Inf that a panel-mate reads must not leak NaNs into rows without that column
+    used = np.unique(ci)
+    B[used[::17]] = np.inf
+    B[used[5::29]] = np.nan
+    ref = orc.spmm_csr(rp, ci, va, B)
+    got = _spmm(crp, gpu, rp, ci, va, k, B, n, variant=3)
+    assert np.array_equal(np.isnan(ref), np.isnan(got)) and np.array_equal(np.isinf(ref), np.isinf(got))
+    fin = np.isfinite(ref)
+    assert np.abs(ref[fin] - got[fin]).max() <= 1e-12 * np.abs(ref[fin]).max()
+    # repeats are bit-identical; value updates reach the panel format
+    A = hip.CsrDev(m, k, rp, ci, va)
+    Bf = np.random.default_rng(6).normal(size=(k, n))
+    Bd = _t(Bf, gpu)
+    Cd = torch.empty((m, n), dtype=torch.float64, device=gpu)
+    hip.spmm_csr(A, Bd, Cd, n=n, variant=3)
+    torch.cuda.synchronize()
+    first = Cd.clone()
+    hip.spmm_csr(A, Bd, Cd, n=n, variant=3)
+    torch.cuda.synchronize()
+    assert torch.equal(first, Cd)
+    v2 = -2.5 * va
+    assert lib.crp_csr_dev_update_values(A.handle, v2.ctypes.data, None) == 0
+    hip.spmm_csr(A, Bd, Cd, n=n, variant=3)
+    torch.cuda.synchronize()
+    assert orc.rel_fro_err(orc.spmm_csr(rp, ci, v2, Bf), Cd.cpu().numpy()) <= FP64_TOL
+    A.free()
+    if n == 32:
+        # B rows addressed past 4 GiB: the 64-bit addressing path
+        kb, ld = 1100, 1 << 19
+        rpb, cib, vab = gen.random_csr(1500, kb, 40, seed=21)
+        cib = cib.copy()
+        cib[::5] = kb - 1 - (cib[::5] % 7)
+        for r in range(1500):
+            cib[rpb[r]:rpb[r + 1]] = np.sort(cib[rpb[r]:rpb[r + 1]])
+        Bb = np.random.default_rng(3).uniform(-1, 1, size=(kb, n))
+        Bbig = torch.empty((kb, ld), dtype=torch.float64, device=gpu)
+        Bbig[:, :n] = _t(Bb, gpu)
+        Ab = hip.CsrDev(1500, kb, rpb, cib, vab)
+        Cb = torch.full((1500, n), float("nan"), dtype=torch.float64, device=gpu)
+        hip.spmm_csr(Ab, Bbig[:, :n], Cb, n=n, variant=3)
+        torch.cuda.synchronize()
+        assert orc.rel_fro_err(orc.spmm_csr(rpb, cib, vab, Bb), Cb.cpu().numpy()) <= FP64_TOL
+        Ab.free()
+        del Bbig
+        torch.cuda.empty_cache()
+
+
 def test_team2_sixteen_panel_teams_in_a_child_process(crp, orc, gpu):
     """CRPSPMM_TEAM2_WAVES=16 (teams of 16 panels, 1024-thread workgroups; read once per process, hence the child):
     the team2 and fp32 parity tests of this file again, in one pytest child process on the same GPU."""
