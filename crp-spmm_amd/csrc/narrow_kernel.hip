@@ -117,7 +117,11 @@ __global__ __launch_bounds__(256, NP == 2 ? 4 : 7) void spmm_narrow_f64_kernel(
         const int mymask = (lane < ce) ? (int) pmask[e0 + base + lane] : 0;
         const int nstep = ce / G;                                          // even
         // NP = 1: two steps per iteration, their loads in flight together (the compiler's wait before an asm statement
-        // cannot be counted across the loop's back edge, so a deeper software pipeline would not overlap anything);
+        // cannot be counted across the loop's back edge, so a deeper software pipeline would not overlap anything).
+        // (Tried: the block's 16 steps spelled out with a three-step prefetch -- it needs the operand pointers without
+        //  __restrict__ and a "memory" clobber on the step, or the optimiser sinks every prefetch to its use; then the
+        //  waits are vmcnt(6) as intended, at 80-88 VGPRs: 0.063 ms against 0.062 -- the kernel is bound by its vector
+        //  instructions, not by exposed latency.)
         // NP = 2: one step (twice the bytes per step already, and two would spill at four waves per SIMD)
         for (int s = 0; s < nstep; s += (NP == 1 ? 2 : 1))
         {
