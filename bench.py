@@ -257,6 +257,8 @@ def measure(args, matrix, mtx, steps, lib, torch, dist, comm, dev, world, rank, 
     if distributed:
         if args.grid == "reference":
             pl = planner.calc_spmm_part2d_from_1d(world, m, n, k, rb, rp, ci, rA=1)
+        elif args.grid == "timed":
+            pl = planner.spmm_part2d_timed(world, m, n, k, rb, rp, ci, max(1, steps + args.warmup))
         else:
             pl = planner.spmm_part2d_amortized(world, m, n, k, rb, rp, ci, max(1, steps + args.warmup))
         pm, pn = pl["pm"], pl["pn"]
@@ -416,7 +418,7 @@ def main():
     ap.add_argument("--mtx", default=None, help="Matrix-Market file to multiply instead of a generated matrix")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--dtype", default="f64", choices=("f64", "f32"), help="f32: the fp32 value path (one GPU, device-level API)")
-    ap.add_argument("--grid", default="amortized", choices=("amortized", "reference"),
+    ap.add_argument("--grid", default="amortized", choices=("amortized", "reference", "timed"),
                     help="N > 1: planner rule for the process grid (see module docstring)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the irregular pwtk-class stand-in of the default run")

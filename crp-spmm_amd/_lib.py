@@ -214,6 +214,8 @@ SIGNATURES = {
     "crp_spmm_part2d_amortized": (None, [_I, _I, _I, _I, c_int_p, c_int_p, c_int_p, _I, c_int_p, c_int_p, c_sz_p,
                                          C.POINTER(c_int_p), C.POINTER(c_int_p), C.POINTER(c_int_p),
                                          C.POINTER(c_int_p)]),
+    "crp_spmm_part2d_timed": (None, [_I, _I, _I, _I, c_int_p, c_int_p, c_int_p, _I, c_dbl_p, c_int_p, c_int_p, c_dbl_p,
+                                     C.POINTER(c_int_p), C.POINTER(c_int_p), C.POINTER(c_int_p), C.POINTER(c_int_p)]),
     "crp_csr_cache_write": (_I, [C.c_char_p, _I, _I, c_int_p, c_int_p, c_dbl_p]),
     "crp_csr_cache_read": (_I, [C.c_char_p, c_int_p, c_int_p, C.POINTER(c_int_p), C.POINTER(c_int_p), C.POINTER(c_dbl_p)]),
     "crp_crpspmm_plan_grid": (None, [_I, _I, _I, _I, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p]),

@@ -237,4 +237,112 @@ void crp_spmm_part2d_amortized(const int nproc, const int m, const int n, const 
     part2d_emit(nproc, m, n, k, rowptr, gm, gn, best_rows.data(), A0_rowptr, B_rowptr, AC_rowptr, BC_colptr);
 }
 
+// Fraction of the HBM roofline (algorithmic bytes) the local kernels reach at a given operand width, measured on
+// MI355X (profiles/r02_sweep_n32_256_1024.jsonl and DESIGN.md section 4): the width a grid leaves every GPU with is
+// part of its price.
+static double kernel_fraction(const int n_local)
+{
+    if (n_local >= 256) return 0.45;
+    if (n_local >= 112) return 0.40;
+    if (n_local > 32) return 0.38;
+    if (n_local >= 24) return 0.50;
+    return 0.13;
+}
+
+// Grid choice by a TIME model of one node of point-to-point links (the reference prices bytes,
+// src/spmat_part.c:113-159; xGMI is not a switch, every pair of GPUs has its own link).  For every pm x pn:
+//   one-time   t_rep  = largest piece of a replicated panel (12 bytes per nonzero) / link rate: the pn - 1 pieces a rank
+//                       receives arrive over different links at once (the engines' device all-gather is a fan-out);
+//   per exec   t_exch = the largest number of B rows one rank needs from ONE peer x n_local x 8 / link rate: pairs
+//                       exchange in parallel, the slowest pair ends the step (exact per-pair row counts);
+//              t_comp = the largest per-rank algorithmic bytes / (HBM rate x the kernels' measured fraction at n_local);
+//              the exchange runs beside the interior rows' product: t_exec = max(t_comp, t_exch);
+//   price      t_rep / rA + t_exec.
+// Grids whose panel replicas or operands do not fit `hbm_bytes` per GPU are skipped.  times[0..2] (optional) = t_rep,
+// t_exch, t_comp of the winner in seconds.  mm (optional): {link GB/s per direction, HBM GB/s, HBM bytes per GPU}.
+void crp_spmm_part2d_timed(const int nproc, const int m, const int n, const int k, const int *rb_displs0, const int *rowptr,
+                           const int *colidx, const int rA, const double *mm, int *pm, int *pn, double *times,
+                           int **A0_rowptr, int **B_rowptr, int **AC_rowptr, int **BC_colptr)
+{
+    const double link = (mm && mm[0] > 0 ? mm[0] : 64.0) * 1e9;            // xGMI: 153 GB/s per link both ways, ~64 one way in practice
+    const double hbm = (mm && mm[1] > 0 ? mm[1] : 8000.0) * 1e9;
+    const double cap = (mm && mm[2] > 0 ? mm[2] : 288e9) * 0.9;
+    std::vector<int> rows((size_t) nproc + 1), xd((size_t) nproc + 1), best_rows;
+    double best = 1e300, bt[3] = {0, 0, 0};
+    int gm = nproc, gn = 1, tmp;
+    const int reuse = rA > 0 ? rA : 1;
+    for (int tn = 1; tn <= nproc; tn++)
+    {
+        if (nproc % tn != 0 || (tn > 1 && tn > n)) continue;
+        const int tm = nproc / tn;
+        for (int i = 0; i <= tm; i++) rows[(size_t) i] = rb_displs0[i * tn];
+        if (m == k) memcpy(xd.data(), rows.data(), sizeof(int) * (size_t) (tm + 1));
+        else for (int i = 0; i <= tm; i++) calc_block_spos_size(k, tm, i, xd.data() + i, &tmp);
+        const int nl = (n + tn - 1) / tn;
+        // per panel: nonzeros, distinct B rows, and B rows needed from every single peer
+        double t_rep = 0, t_exch = 0, t_comp = 0;
+        bool fits = true;
+        std::vector<std::vector<int>> stamps((size_t) crp::host_threads());
+        std::vector<double> p_rep((size_t) tm, 0.0), p_exch((size_t) tm, 0.0), p_comp((size_t) tm, 0.0);
+        std::vector<char> p_fit((size_t) tm, 1);
+        crp::parallel_chunks(tm, 1, [&](long long b0, long long b1, int tid) {
+            std::vector<int> &stamp = stamps[(size_t) tid];
+            if (stamp.empty()) stamp.assign((size_t) (k > 0 ? k : 1), 0);
+            std::vector<long long> from((size_t) tm);
+            for (int b = (int) b0; b < (int) b1; b++)
+            {
+                const int tag = b + 1;
+                std::fill(from.begin(), from.end(), 0LL);
+                long long distinct = 0;
+                for (int p = rowptr[rows[(size_t) b]]; p < rowptr[rows[(size_t) b + 1]]; p++)
+                {
+                    const int c = colidx[p];
+                    if (stamp[(size_t) c] == tag) continue;
+                    stamp[(size_t) c] = tag;
+                    distinct++;
+                    const int q = (int) (std::upper_bound(xd.begin(), xd.begin() + tm + 1, c) - xd.begin()) - 1;
+                    if (q != b && q >= 0 && q < tm) from[(size_t) q]++;
+                }
+                const double pnnz = (double) (rowptr[rows[(size_t) b + 1]] - rowptr[rows[(size_t) b]]);
+                const double prow = (double) (rows[(size_t) b + 1] - rows[(size_t) b]);
+                long long worst = 0;
+                for (long long v : from) worst = std::max(worst, v);
+                p_rep[(size_t) b] = tn > 1 ? 12.0 * pnnz / tn / link : 0.0;
+                p_exch[(size_t) b] = 8.0 * (double) worst * nl / link;
+                const double alg = 12.0 * pnnz + 4.0 * (prow + 1) + 8.0 * nl * (double) distinct + 8.0 * nl * prow;
+                p_comp[(size_t) b] = alg / (hbm * kernel_fraction(nl));
+                // device memory: CSR + derived formats (~3 x the CSR), local B / C blocks, receive buffer
+                const double mem = 4.0 * 12.0 * pnnz + 8.0 * nl * (2.0 * prow + (double) distinct);
+                if (mem > cap) p_fit[(size_t) b] = 0;
+            }
+        });
+        for (int b = 0; b < tm; b++)
+        {
+            t_rep = std::max(t_rep, p_rep[(size_t) b]);
+            t_exch = std::max(t_exch, p_exch[(size_t) b]);
+            t_comp = std::max(t_comp, p_comp[(size_t) b]);
+            fits = fits && p_fit[(size_t) b];
+        }
+        if (!fits) continue;
+        const double price = t_rep / reuse + std::max(t_comp, t_exch);
+        if (price < best)
+        {
+            best = price;
+            gm = tm;
+            gn = tn;
+            bt[0] = t_rep; bt[1] = t_exch; bt[2] = t_comp;
+            best_rows.assign(rows.begin(), rows.begin() + tm + 1);
+        }
+    }
+    if (best_rows.empty())              // nothing fits by the model: the pure 1D row partition (least memory per GPU)
+    {
+        gm = nproc; gn = 1;
+        best_rows.assign(rb_displs0, rb_displs0 + nproc + 1);
+    }
+    *pm = gm;
+    *pn = gn;
+    if (times) { times[0] = bt[0]; times[1] = bt[1]; times[2] = bt[2]; }
+    part2d_emit(nproc, m, n, k, rowptr, gm, gn, best_rows.data(), A0_rowptr, B_rowptr, AC_rowptr, BC_colptr);
+}
+
 }  // extern "C"

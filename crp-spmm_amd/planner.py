@@ -81,6 +81,20 @@ def spmm_part2d_amortized(nproc, m, n, k, rb_displs0, rowptr, colidx, rA):
                 BC_colptr=_take(bc, pn.value + 1))
 
 
+def spmm_part2d_timed(nproc, m, n, k, rb_displs0, rowptr, colidx, rA, link_GBs=None, hbm_GBs=None, hbm_bytes=None):
+    """Grid by the time model of crp_spmm_part2d_timed (include/crp_engine.h): point-to-point links, the kernels'
+    measured roofline fraction at n / pn columns, HBM capacity.  -> the planner dict + times = (t_rep, t_exch, t_comp) s."""
+    rb, rowptr, colidx = _i32(rb_displs0), _i32(rowptr), _i32(colidx)
+    pm, pn = C.c_int(), C.c_int()
+    a0, br, ac, bc = L.c_int_p(), L.c_int_p(), L.c_int_p(), L.c_int_p()
+    mm = np.array([link_GBs or 0.0, hbm_GBs or 0.0, hbm_bytes or 0.0], dtype=np.float64)
+    times = np.zeros(3)
+    L.load().crp_spmm_part2d_timed(nproc, m, n, k, _ip(rb), _ip(rowptr), _ip(colidx), rA, mm.ctypes.data_as(L.c_dbl_p), C.byref(pm),
+                                   C.byref(pn), times.ctypes.data_as(L.c_dbl_p), C.byref(a0), C.byref(br), C.byref(ac), C.byref(bc))
+    return dict(pm=pm.value, pn=pn.value, times=tuple(times), A0_rowptr=_take(a0, nproc + 1),
+                B_rowptr=_take(br, pm.value + 1), AC_rowptr=_take(ac, pm.value + 1), BC_colptr=_take(bc, pn.value + 1))
+
+
 def crpspmm_plan_grid(nproc, m, n, k, rowptr, colidx):
     """Grid rule of the older all-in-one engine (/root/reference/deprecated/src/crpspmm.c:136-195):
     returns (np_row, np_col, m_split_idx).  rowptr / colidx: the global CSR pattern."""

@@ -214,6 +214,16 @@ void crp_spmm_part2d_amortized(int nproc, int m, int n, int k, const int *rb_dis
                                const int *colidx, int rA, int *pm, int *pn, size_t *comm_cost, int **A0_rowptr,
                                int **B_rowptr, int **AC_rowptr, int **BC_colptr);
 
+/* Extension: grid choice by a TIME model of one node of point-to-point links instead of a byte
+ * count -- one-time replication of the A panels (fan-out: the pn - 1 pieces arrive over different links), per multiply
+ * max(local product at the kernels' measured roofline fraction for n / pn columns, slowest PAIR of the B exchange), priced
+ * as t_rep / rA + t_exec; grids that do not fit a GPU's HBM are skipped.  mm = NULL or {link GB/s one way (64), HBM GB/s
+ * (8000), HBM bytes per GPU (288e9)}; times (optional) = {t_rep, t_exch, t_comp} of the winner, seconds.  Output arrays as
+ * calc_spmm_part2d_from_1d.  Host only. */
+void crp_spmm_part2d_timed(int nproc, int m, int n, int k, const int *rb_displs0, const int *rowptr, const int *colidx,
+                           int rA, const double *mm, int *pm, int *pn, double *times, int **A0_rowptr, int **B_rowptr,
+                           int **AC_rowptr, int **BC_colptr);
+
 /* ---- binary CSR cache (ingest extension) ---------------------------------------------------------
  * A converted matrix kept beside its .mtx so that later runs skip the text parse
  * (examples/mmio_utils.c:11-190 takes 3 s for pwtk, minutes for nlpkkt240).  One little-endian file:

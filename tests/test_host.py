@@ -505,6 +505,62 @@ def test_amortized_planner_is_exhaustive_minimum(crp, orc):
     assert (got["pm"], got["pn"]) == (1, 8)
 
 
+def test_timed_planner_link_model(crp, orc):
+    """crp_spmm_part2d_timed: grid by a time model of point-to-point links.  Checked against a
+    restatement of the model in numpy for every candidate grid, and on three regimes: a far-banded matrix reused often
+    (replicate A, exchange nothing: 1 x P), a block-diagonal matrix multiplied once (nothing to exchange and nothing to
+    replicate: P x 1), and a capacity limit that rules out the replicating grids."""
+    from crp_spmm_amd import gen, planner
+
+    def frac(nl):
+        return 0.45 if nl >= 256 else 0.40 if nl >= 112 else 0.38 if nl > 32 else 0.50 if nl >= 24 else 0.13
+
+    def model(P, m, n, rp, ci, rb, rA, link=64e9, hbm=8000e9):
+        out = {}
+        for pn in [d for d in range(1, P + 1) if P % d == 0 and (d == 1 or d <= n)]:
+            pm = P // pn
+            rows = np.array([rb[i * pn] for i in range(pm + 1)])
+            nl = -(-n // pn)
+            t_rep = t_exch = t_comp = 0.0
+            for b in range(pm):
+                cols = np.unique(ci[rp[rows[b]]:rp[rows[b + 1]]])
+                owner = np.searchsorted(rows, cols, side="right") - 1
+                worst = max([int(np.sum(owner == q)) for q in range(pm) if q != b], default=0)
+                pnnz = float(rp[rows[b + 1]] - rp[rows[b]])
+                prow = float(rows[b + 1] - rows[b])
+                t_rep = max(t_rep, 12.0 * pnnz / pn / link if pn > 1 else 0.0)
+                t_exch = max(t_exch, 8.0 * worst * nl / link)
+                t_comp = max(t_comp, (12.0 * pnnz + 4.0 * (prow + 1) + 8.0 * nl * len(cols) + 8.0 * nl * prow) / (hbm * frac(nl)))
+            out[pn] = (t_rep / rA + max(t_comp, t_exch), t_rep, t_exch, t_comp)
+        return out
+
+    m = 6000
+    rp, ci, _ = gen.banded_fem(m, offsets=(1, 2, 3, 40, 41, 900), seed=2)
+    for P in (2, 4, 8):
+        rb = planner.csr_mat_row_partition(rp, P)
+        for n, rA in ((256, 1), (256, 500), (32, 3), (1024, 50)):
+            got = planner.spmm_part2d_timed(P, m, n, m, rb, rp, ci, rA)
+            mod = model(P, m, n, rp, ci, rb, rA)
+            best = min(mod, key=lambda d: (mod[d][0], d))
+            assert (got["pm"], got["pn"]) == (P // best, best), (P, n, rA, mod, got)
+            assert np.allclose(got["times"], mod[best][1:], rtol=1e-12, atol=0)
+    got = planner.spmm_part2d_timed(8, m, 256, m, planner.csr_mat_row_partition(rp, 8), rp, ci, 1000)
+    assert (got["pm"], got["pn"]) == (1, 8) and got["times"][1] == 0.0
+    # block diagonal, one multiply: rows split, nothing moves
+    blk = 512
+    rows = np.repeat(np.arange(4096), 8)
+    cols = (rows // blk) * blk + (np.arange(rows.size) * 37) % blk
+    order = np.lexsort((cols, rows))
+    ci2 = cols[order].astype(np.int32)
+    rp2 = np.arange(0, rows.size + 1, 8, dtype=np.int32)
+    got = planner.spmm_part2d_timed(8, 4096, 256, 4096, planner.csr_mat_row_partition(rp2, 8), rp2, ci2, 1)
+    assert (got["pm"], got["pn"]) == (8, 1) and got["times"][0] == 0.0 and got["times"][1] == 0.0
+    # a GPU too small for a replicated panel: only grids with pn = 1 remain
+    tiny = 4.0 * 12.0 * float(rp[-1]) / 8 * 1.5 / 0.9
+    got = planner.spmm_part2d_timed(8, m, 8, m, planner.csr_mat_row_partition(rp, 8), rp, ci, 1000, hbm_bytes=tiny)
+    assert got["pn"] == 1
+
+
 def test_parallel_ingest_and_cache(crp, orc, tmp_path):
     """Files above 200k entries take the line-parallel parser: same COO as the reference's reader
     (oracle/_ref) entry for entry; an entry spread over two lines or a line with extra tokens falls
