@@ -434,7 +434,11 @@ __device__ __forceinline__ void fmac_rows_exec8(double (&acc)[8][1][VW], const d
 {
     const uint64_t m64 = mask;
     if constexpr (VW == 1)
-        asm volatile("s_bfe_i64 exec, %[m], 0x10000\n\tv_fmac_f64 %0, %8, %16\n\t"
+        asm volatile("s_cmp_eq_u32 %[m32], 0xff\n\ts_cbranch_scc0 .Lpm1%=\n\t"
+                     "v_fmac_f64 %0, %8, %16\n\tv_fmac_f64 %1, %9, %16\n\tv_fmac_f64 %2, %10, %16\n\tv_fmac_f64 %3, %11, %16\n\t"
+                     "v_fmac_f64 %4, %12, %16\n\tv_fmac_f64 %5, %13, %16\n\tv_fmac_f64 %6, %14, %16\n\tv_fmac_f64 %7, %15, %16\n\t"
+                     "s_branch .Lpd1%=\n.Lpm1%=:\n\t"
+                     "s_bfe_i64 exec, %[m], 0x10000\n\tv_fmac_f64 %0, %8, %16\n\t"
                      "s_bfe_i64 exec, %[m], 0x10001\n\tv_fmac_f64 %1, %9, %16\n\t"
                      "s_bfe_i64 exec, %[m], 0x10002\n\tv_fmac_f64 %2, %10, %16\n\t"
                      "s_bfe_i64 exec, %[m], 0x10003\n\tv_fmac_f64 %3, %11, %16\n\t"
@@ -442,14 +446,20 @@ __device__ __forceinline__ void fmac_rows_exec8(double (&acc)[8][1][VW], const d
                      "s_bfe_i64 exec, %[m], 0x10005\n\tv_fmac_f64 %5, %13, %16\n\t"
                      "s_bfe_i64 exec, %[m], 0x10006\n\tv_fmac_f64 %6, %14, %16\n\t"
                      "s_bfe_i64 exec, %[m], 0x10007\n\tv_fmac_f64 %7, %15, %16\n\t"
-                     "s_mov_b64 exec, -1"
+                     "s_mov_b64 exec, -1\n.Lpd1%=:"
                      : "+v"(acc[0][0][0]), "+v"(acc[1][0][0]), "+v"(acc[2][0][0]), "+v"(acc[3][0][0]),
                        "+v"(acc[4][0][0]), "+v"(acc[5][0][0]), "+v"(acc[6][0][0]), "+v"(acc[7][0][0])
                      : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]),
-                       "v"(slot[0]), [m] "s"(m64)
+                       "v"(slot[0]), [m] "s"(m64), [m32] "s"(mask)
                      : "scc");
     else
-        asm volatile("s_bfe_i64 exec, %[m], 0x10000\n\tv_fmac_f64 %0, %16, %24\n\tv_fmac_f64 %1, %16, %25\n\t"
+        asm volatile("s_cmp_eq_u32 %[m32], 0xff\n\ts_cbranch_scc0 .Lpm2%=\n\t"
+                     "v_fmac_f64 %0, %16, %24\n\tv_fmac_f64 %1, %16, %25\n\tv_fmac_f64 %2, %17, %24\n\tv_fmac_f64 %3, %17, %25\n\t"
+                     "v_fmac_f64 %4, %18, %24\n\tv_fmac_f64 %5, %18, %25\n\tv_fmac_f64 %6, %19, %24\n\tv_fmac_f64 %7, %19, %25\n\t"
+                     "v_fmac_f64 %8, %20, %24\n\tv_fmac_f64 %9, %20, %25\n\tv_fmac_f64 %10, %21, %24\n\tv_fmac_f64 %11, %21, %25\n\t"
+                     "v_fmac_f64 %12, %22, %24\n\tv_fmac_f64 %13, %22, %25\n\tv_fmac_f64 %14, %23, %24\n\tv_fmac_f64 %15, %23, %25\n\t"
+                     "s_branch .Lpd2%=\n.Lpm2%=:\n\t"
+                     "s_bfe_i64 exec, %[m], 0x10000\n\tv_fmac_f64 %0, %16, %24\n\tv_fmac_f64 %1, %16, %25\n\t"
                      "s_bfe_i64 exec, %[m], 0x10001\n\tv_fmac_f64 %2, %17, %24\n\tv_fmac_f64 %3, %17, %25\n\t"
                      "s_bfe_i64 exec, %[m], 0x10002\n\tv_fmac_f64 %4, %18, %24\n\tv_fmac_f64 %5, %18, %25\n\t"
                      "s_bfe_i64 exec, %[m], 0x10003\n\tv_fmac_f64 %6, %19, %24\n\tv_fmac_f64 %7, %19, %25\n\t"
@@ -457,13 +467,13 @@ __device__ __forceinline__ void fmac_rows_exec8(double (&acc)[8][1][VW], const d
                      "s_bfe_i64 exec, %[m], 0x10005\n\tv_fmac_f64 %10, %21, %24\n\tv_fmac_f64 %11, %21, %25\n\t"
                      "s_bfe_i64 exec, %[m], 0x10006\n\tv_fmac_f64 %12, %22, %24\n\tv_fmac_f64 %13, %22, %25\n\t"
                      "s_bfe_i64 exec, %[m], 0x10007\n\tv_fmac_f64 %14, %23, %24\n\tv_fmac_f64 %15, %23, %25\n\t"
-                     "s_mov_b64 exec, -1"
+                     "s_mov_b64 exec, -1\n.Lpd2%=:"
                      : "+v"(acc[0][0][0]), "+v"(acc[0][0][1]), "+v"(acc[1][0][0]), "+v"(acc[1][0][1]),
                        "+v"(acc[2][0][0]), "+v"(acc[2][0][1]), "+v"(acc[3][0][0]), "+v"(acc[3][0][1]),
                        "+v"(acc[4][0][0]), "+v"(acc[4][0][1]), "+v"(acc[5][0][0]), "+v"(acc[5][0][1]),
                        "+v"(acc[6][0][0]), "+v"(acc[6][0][1]), "+v"(acc[7][0][0]), "+v"(acc[7][0][1])
                      : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]),
-                       "v"(slot[0].x), "v"(slot[0].y), [m] "s"(m64)
+                       "v"(slot[0].x), "v"(slot[0].y), [m] "s"(m64), [m32] "s"(mask)
                      : "scc");
 }
 
