@@ -39,7 +39,10 @@ struct TeamDev
     bool lattice = false;
 };
 
-constexpr int TEAM2_MIN_N = 112;      // fp64 columns from which auto picks variant 5 (fp32: twice that)
+constexpr int TEAM2_MIN_N = 112;      // fp64 columns from which auto picks variant 5
+// fp32: the only other fp32 kernel is the CSR row-group one, which the team kernel beats from 64 columns on (fem3d
+// stand-in, n = 64 / 128 / 192 / 256: 0.648 / 0.649 / 0.652 / 0.660 ms against 0.663 / 1.24 / 2.31 / 2.37)
+constexpr int TEAM2_MIN_N_F32 = 64;
 struct Team2Dev
 {
     bool built = false;
@@ -729,7 +732,7 @@ int crp_spmm_csr_f32(crp_csr_dev_p A, int n, const float *B0, long long ldB0, co
     crp::SpmmArgsF32 a;
     a.nrow = A->nrow; a.n = n; a.rowptr = A->rowptr; a.colidx = A->colidx; a.val = A->val32;
     a.B0 = B0; a.ldB0 = ldB0; a.B1 = B1; a.ldB1 = ldB1; a.C = C; a.ldC = ldC; a.rowmap = A->rowmap;
-    const bool team = (variant == 5 || (variant == 0 && A->team2_pays && n >= 2 * TEAM2_MIN_N)) && A->nnz > 0 && A->nrow >= 8 &&
+    const bool team = (variant == 5 || (variant == 0 && A->team2_pays && n >= TEAM2_MIN_N_F32)) && A->nnz > 0 && A->nrow >= 8 &&
                       crp::spmm_team2_applicable_f32(a);
     if (!team) return (int) crp::spmm_rm_f32_rowgroup(a, (hipStream_t) stream);
     const int rc = ensure_team2(A);
