@@ -522,6 +522,11 @@ int crp_csr_dev_create(int nrow, int ncol, const int *rowptr, const int *colidx,
         const long long e8 = crp::count_panel_entries(nrow, fmt_rowptr(A), fmt_colidx(A), 8);
         const double fill4 = (double) nnz / (4.0 * (double) e4);
         if (fill4 >= 0.45) A->auto_variant = ((double) e8 <= 0.72 * (double) e4) ? 3 : 2;
+        // R = 8 panels also when an entry serves 1.7 rows or more on average, whatever R = 4 would do: the nlpkkt stand-in
+        // (fill4 0.42, e8 / e4 0.89, e8 = 0.53 nnz) runs 0.63 / 1.04 / 1.32 ms at n = 32 / 64 / 96 on R = 8 panels against
+        // 0.73 / 1.34 / 1.95 through CSR and 1.00 / 1.10 / 1.45 on R = 4; the shell stand-in 0.106 / 0.129 against 0.135 / 0.144
+        // on R = 4.  Erdos-Renyi (e8 = nnz) stays with CSR.
+        if ((double) e8 <= 0.6 * (double) nnz) A->auto_variant = 3;
     }
     // The LDS-sharing team kernel fetches a B row once per team of 64 rows: it pays when those rows name far fewer
     // distinct columns than they have nonzeros (pwtk stand-in 0.10, shell 0.09, kkt 0.27, fem3d 0.13 of the nonzeros;

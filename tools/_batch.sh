@@ -1,6 +1,6 @@
 set -o pipefail
-for n in 64 128 192 256; do
-  for v in 1 5; do
-    timeout -k 10 300 python bench.py --steps 30 --no-cpu-baseline --no-also --matrix fem3d --n $n --dtype f32 --variant $v 2>/dev/null | python3 -c "import json,sys;d=json.loads(sys.stdin.read());print('fem3d f32 n=$n variant $v:', round(d['ms_per_step'],4), 'ms')"
-  done
+timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "not child_process" 2>&1 | tail -1
+for cfg in "kkt 32" "kkt 64" "kkt 96" "pwtk_shell 64" "er 64" "fem3d 64"; do
+  set -- $cfg
+  timeout -k 10 300 python bench.py --steps 30 --no-cpu-baseline --no-also --matrix $1 --n $2 2>/dev/null | python3 -c "import json,sys;d=json.loads(sys.stdin.read());print('$1 n=$2:', round(d['ms_per_step'],4), d['config']['kernel_variant_resolved'], 'frac %.3f'%d['roofline']['frac'])"
 done
