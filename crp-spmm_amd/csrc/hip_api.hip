@@ -535,16 +535,8 @@ int crp_csr_dev_create(int nrow, int ncol, const int *rowptr, const int *colidx,
         A->team2_pays = (double) crp::count_block_union(nrow, fmt_rowptr(A), fmt_colidx(A), 64) <= 0.6 * (double) nnz;
     const char *env = getenv("CRPSPMM_SPMM_VARIANT");
     if (env != NULL && atoi(env) >= 1 && atoi(env) <= 3) A->auto_variant = atoi(env);
-    if (A->auto_variant >= 2)
-    {
-        int rc = ensure_panel(A, A->auto_variant - 2);
-        if (rc != 0)
-        {
-            crp_csr_dev_p tmp = A;
-            crp_csr_dev_destroy(&tmp);
-            return rc;
-        }
-    }
+    // (the derived formats are built by the first product that uses them: a matrix multiplied by wide operands only never
+    //  needs its row-panel format -- 20 GB for the nlpkkt240-size stand-in)
     *out = A;
     return 0;
 }
