@@ -1,10 +1,6 @@
 set -o pipefail
-mkdir -p gpurun_out/drv
-timeout -k 10 1000 python -m pytest tests -m gpu -x -q 2>&1 | tail -2
-make -C examples > gpurun_out/drv/make.log 2>&1 || { tail -5 gpurun_out/drv/make.log; exit 1; }
-python tools/gen_mtx.py --kind banded_fem --m 217918 --out /tmp/pwtk_standin.mtx > gpurun_out/drv/gen.log 2>&1 || { tail -5 gpurun_out/drv/gen.log; exit 1; }
-export PATH=/opt/conda/bin:$PATH
-timeout -k 10 600 mpiexec -np 1 examples/test_rp_spmm.exe /tmp/pwtk_standin.mtx 256 5 0 1 > gpurun_out/drv/test_rp_spmm_np1.txt 2>&1 || { tail -20 gpurun_out/drv/test_rp_spmm_np1.txt; exit 1; }
-tail -12 gpurun_out/drv/test_rp_spmm_np1.txt
-timeout -k 10 600 mpiexec -np 2 examples/test_para2d_spmm.exe /tmp/pwtk_standin.mtx 256 5 0 1 > gpurun_out/drv/test_para2d_spmm_np2.txt 2>&1 || { tail -20 gpurun_out/drv/test_para2d_spmm_np2.txt; exit 1; }
-tail -6 gpurun_out/drv/test_para2d_spmm_np2.txt
+timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "fp32 or team2" 2>&1 | tail -2
+for cfg in "fem3d 1024" "fem3d 256" "fem3d 128" "pwtk 1024" "kkt 512"; do
+  set -- $cfg
+  timeout -k 10 300 python bench.py --steps 30 --no-cpu-baseline --no-also --matrix $1 --n $2 --dtype f32 2>/dev/null | python3 -c "import json,sys;d=json.loads(sys.stdin.read());print('$1 f32 n=$2:', round(d['ms_per_step'],4), 'ms', round(d['value']), 'GFLOP/s frac %.3f'%d['roofline']['frac'])"
+done

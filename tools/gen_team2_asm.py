@@ -30,7 +30,8 @@ ds_read_b64 (lane l holds value l & 7), call of sequence code_i: rows first..fir
     v_fmac_f64_dpp acc, values, slice row_newbcast:row   (NV * 2 of them)
 The reads of part i + 1 are issued before the wait for part i.
 fp32 instances (gen(..., f32=True)): the same loop with 128-byte value slots (8 floats per part: ds_read_b32, lane l
-holds value l & 7) and per row NV * 4 x v_fmac_f32_dpp on the four floats of the lane's 16-byte piece.
+holds value l & 7); per row one v_mov_b32_dpp broadcasts the value and NV * 2 x v_pk_fma_f32 take the four floats of the
+lane's 16-byte piece two at a time (accumulators are 64-bit pairs, as in fp64).
 T2_BPOL (environment, generation time) appends a cache policy to the B-row DMAs; measured on the pwtk stand-in:
 nt +35 % time, sc0 / sc1 / sc0 sc1 within +-2 %; the committed file uses none.
 
@@ -48,7 +49,7 @@ VSLOT = 256
 VBASE = 100          # fixed VGPRs: A0(4) A1(4) AV(2) B0(4) B1(4) BV(2) TA TV REC(4)
 SBASE = 84           # fixed SGPRs: pc(2) ret(2) tblA(2) tblB(2) t cnt rowbase(2) recsrc(2)
 NCODE = 36
-NVREG = 26
+NVREG = 28
 NSREG = 14
 
 
@@ -68,11 +69,13 @@ def gen(nv, has_b1, f32=False, tw=8):
     A = {"s0": b, "s1": b + 4, "v": b + 8}
     B = {"s0": b + 10, "s1": b + 14, "v": b + 18}
     TA, TV, REC = b + 20, b + 21, b + 22
+    TP = b + 26                                     # fp32: pair whose low register holds the row's broadcast value
     PC, RET, TBA, TBB, T, CNT, RB, RS = SBASE, SBASE + 2, SBASE + 4, SBASE + 6, SBASE + 8, SBASE + 9, SBASE + 10, SBASE + 12
     slotb = 1024 * nv
     setb = tw * slotb
     slot_shift = 11 if nv == 2 else 10
-    seq_align = {(1, False): 8, (2, False): 9, (1, True): 9, (2, True): 10}[(nv, f32)]   # 2^x >= 8 rows x nv * vw FMAs x 8 bytes + return
+    # 2^x >= the longest sequence: fp64 8 rows x nv * 2 FMAs x 8 bytes + return; fp32 8 rows x (1 + nv * 2) x 8 bytes + return
+    seq_align = {(1, False): 8, (2, False): 9, (1, True): 8, (2, True): 9}[(nv, f32)]
     opr = nv + 1                                    # DMAs a wave issues per round
     tag = "%s%d%d%s_%%=" % ("s" if f32 else "d", nv, 1 if has_b1 else 0, "w" if tw == 16 else "")
     L = []
@@ -219,12 +222,16 @@ def gen(nv, has_b1, f32=False, tw=8):
                 if code == 0:
                     emit(".Lt2tab%s%s:" % (name, tag))
                 for r in range(first, first + ln):
+                    if f32:
+                        # the row's value into every lane once, then PACKED FMAs (two floats per instruction: the fp32
+                        # instance is bound by its vector instructions, 56 % of the time with one v_fmac_f32_dpp per float)
+                        emit("v_mov_b32_dpp v%d, v%d row_newbcast:%d row_mask:0xf bank_mask:0xf" % (TP, X["v"], r))
                     for v in range(nv):
                         base = X["s0"] if v == 0 else X["s1"]
-                        for w in range(vw):
+                        for w in range(2):
                             if f32:
-                                emit("v_fmac_f32_dpp %%[a%d], v%d, v%d row_newbcast:%d row_mask:0xf bank_mask:0xf"
-                                     % ((r * nv + v) * vw + w, X["v"], base + w, r))
+                                emit("v_pk_fma_f32 %%[a%d], v[%d:%d], v[%d:%d], %%[a%d] op_sel_hi:[1,0,1]"
+                                     % ((r * nv + v) * 2 + w, base + 2 * w, base + 2 * w + 1, TP, TP + 1, (r * nv + v) * 2 + w))
                             else:
                                 emit("v_fmac_f64_dpp %%[a%d], v[%d:%d], v[%d:%d] row_newbcast:%d row_mask:0xf bank_mask:0xf"
                                      % ((r * nv + v) * 2 + w, X["v"], X["v"] + 1, base + 2 * w, base + 2 * w + 1, r))
