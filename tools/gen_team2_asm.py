@@ -46,7 +46,7 @@ BPOL = os.environ.get('T2_BPOL', '')
 D = 3
 NSET = 4
 VSLOT = 256
-VBASE = 100          # fixed VGPRs: A0(4) A1(4) AV(2) B0(4) B1(4) BV(2) TA TV REC(4)
+VBASE = 100          # fixed VGPRs: A0(4) A1(4) AV(2) B0(4) B1(4) BV(2) TA TV REC(4) TP(2: fp32 broadcast pair)
 SBASE = 84           # fixed SGPRs: pc(2) ret(2) tblA(2) tblB(2) t cnt rowbase(2) recsrc(2)
 NCODE = 36
 NVREG = 28
