@@ -118,11 +118,24 @@ class TorchComm:
             dist.broadcast(idbuf, src=self._glb_ranks[0], group=self.group)
             raw = (C.c_ubyte * 128)(*[int(v) for v in idbuf])
             h = C.c_void_p()
-            L.check(lib.crp_rccl_create(raw, self.nproc, self.rank, C.byref(h)), "crp_rccl_create")
-            self._rccl = h
-            s.ctx = h
-            s.alltoallv_dev_f64 = C.cast(lib.crp_rccl_comm_alltoallv_dev_f64, L.A2AV_DEV_FN)
-            s.allgatherv_dev = C.cast(lib.crp_rccl_comm_allgatherv_dev, L.AGV_DEV_FN)
+            rc = lib.crp_rccl_create(raw, self.nproc, self.rank, C.byref(h))
+            # every rank of the group must take the same transport: agree on the outcome over the control plane
+            ok = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+            if int(ok[0]) == 1:
+                self._rccl = h
+                s.ctx = h
+                s.alltoallv_dev_f64 = C.cast(lib.crp_rccl_comm_alltoallv_dev_f64, L.A2AV_DEV_FN)
+                s.allgatherv_dev = C.cast(lib.crp_rccl_comm_allgatherv_dev, L.AGV_DEV_FN)
+            else:
+                # (loud, but not fatal: the payloads then travel device -> host -> gloo -> device, the rehearsal path)
+                print("[crp_spmm_amd] RCCL communicator of %d ranks could not be created (rank %d: code %d); device payloads "
+                      "are staged through the host" % (self.nproc, self.rank, rc), file=sys.stderr, flush=True)
+                if rc == 0:
+                    lib.crp_rccl_destroy(C.byref(h))
+                self._staged_fallback = True
+                self._agv_dev_cb = L.AGV_DEV_FN(self._allgatherv_dev_staged)
+                s.allgatherv_dev = self._agv_dev_cb
         elif torch.cuda.is_available():
             # rehearsal mode (several ranks on one GPU): the device all-gather staged through the host, so that the
             # engines' device-replication branch runs on a 1-GPU box as well
