@@ -238,7 +238,12 @@ bool detect_stride_lattice(int nrow, const int *rowptr, const int *colidx, int R
 {
     if (nrow < 4096) return false;
     // histogram of |col - row| over the locally owned columns, 64-row buckets
-    const int SH = 6;
+    // 8-row buckets up to 2 M rows (the strides of a grid with short lines -- 56 nodes x 3 unknowns = 168 rows -- then
+    // separate from the near band: fem3d stand-in, lattice teams of 2 x 2 lines x 2 panels need 5.7 union entries per row
+    // against 6.95 for clusters, 0.913 -> 0.838 ms at n = 256), 64-row buckets beyond (one histogram per thread).
+    // CRPSPMM_LATTICE_SH = log2 of the bucket width.
+    static const int SH_env = getenv("CRPSPMM_LATTICE_SH") ? std::max(2, std::min(8, atoi(getenv("CRPSPMM_LATTICE_SH")))) : 0;
+    const int SH = SH_env ? SH_env : (nrow <= (1 << 21) ? 3 : 6);
     const size_t nb = ((size_t) nrow >> SH) + 2;
     const int nt = host_threads();
     std::vector<std::vector<long long>> cnt_t((size_t) nt, std::vector<long long>(nb, 0)), sum_t(cnt_t);
@@ -304,7 +309,8 @@ bool detect_stride_lattice(int nrow, const int *rowptr, const int *colidx, int R
     }
     const double ratio = D2 / D1;
     const int M = (int) (ratio + 0.5);
-    if (D1 < 32.0 * R || M < 2 || std::abs(ratio - M) > 0.02 * M || D2 * 2 > nrow) return false;
+    static const double d1min = getenv("CRPSPMM_LATTICE_D1MIN") ? atof(getenv("CRPSPMM_LATTICE_D1MIN")) : 8.0;      // teeth of >= 8 panels
+    if (D1 < d1min * R || M < 2 || std::abs(ratio - M) > 0.02 * M || D2 * 2 > nrow) return false;
     *D1_ = D1;
     *D2_ = D2;
     *M_ = M;
