@@ -77,6 +77,11 @@ def build_matrix(name, mtx=None):
         # (2 MiB at n = 256) so that B is always L2-resident
         rp, ci, va = gen.banded_fem(217918)
         return "pwtk stand-in with columns mod 1024 (L2-resident B; diagnostic)", "synthetic", 217918, 217918, rp, (ci % 1024).astype(np.int32), va
+    if name == "pwtk_mall":
+        # diagnostic only: the pwtk stand-in's structure at 48,000 rows -- A, B and C together (232 MB at n = 256) fit
+        # the 256 MiB Infinity Cache, so back-to-back launches never reach HBM
+        rp, ci, va = gen.banded_fem(48000)
+        return "pwtk stand-in structure, 48000 rows (Infinity-Cache-resident; diagnostic)", "synthetic", 48000, 48000, rp, ci, va
     if name == "small":
         rp, ci, va = gen.banded_fem(20000, offsets=(1, 2, 3, 4, 5, 6, 100, 101, 3000))
         return "banded_fem(20000) smoke-size", "synthetic", 20000, 20000, rp, ci, va

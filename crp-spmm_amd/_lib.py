@@ -141,6 +141,7 @@ SIGNATURES = {
     "crp_team_format_host": (_I, [_I, c_int_p, c_int_p, c_dbl_p, c_int_p, c_int_p, C.POINTER(c_int_p), C.POINTER(c_int_p),
                                   C.POINTER(c_int_p), C.POINTER(C.POINTER(C.c_uint)), C.POINTER(c_int_p)]),
     "crp_team2_waves": (_I, []),
+    "crp_team2_format_host_grid": (_I, [C.POINTER(c_int_p), c_int_p]),
     "crp_team2_format_host": (_I, [_I, c_int_p, c_int_p, c_dbl_p, c_int_p, c_int_p, C.POINTER(c_int_p), C.POINTER(c_int_p),
                                    C.POINTER(c_int_p), C.POINTER(C.POINTER(C.c_uint)), C.POINTER(_LL),
                                    C.POINTER(C.POINTER(_LL)), C.POINTER(c_dbl_p), C.POINTER(_LL), C.POINTER(c_int_p),

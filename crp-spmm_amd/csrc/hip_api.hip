@@ -87,6 +87,9 @@ struct crp_csr_dev
     std::vector<int>      h_rowmap;       // host copy of the caller's row map (empty: none)
     int      *rowmap_fmt = nullptr;
     int       c_nrow = 0;                 // rows of C the product writes into (nrow without a rowmap)
+    // crp_csr_dev_update_values() with a DEVICE pointer leaves the host copies (h_val / f_val) behind: formats built
+    // afterwards take their values from the device CSR through their fresh slot maps (refresh_values_after_build)
+    bool      host_vals_stale = false;
 };
 
 static const int *fmt_rowptr(const crp_csr_dev *A) { return A->perm.empty() ? A->h_rowptr.data() : A->f_rowptr.data(); }
@@ -109,7 +112,7 @@ static void fmt_slotmap_to_caller(const crp_csr_dev *A, crp::big_vector<uint32_t
     } while (0)
 
 // Build (once) and upload the row-panel format with R = 4 (idx 0) or 8 (idx 1). Blocking.
-static int ensure_panel(crp_csr_dev *A, int idx)
+static int ensure_panel(crp_csr_dev *A, int idx, hipStream_t stream)
 {
     PanelDev &d = A->pan[idx];
     if (d.built) return 0;
@@ -167,16 +170,17 @@ static int ensure_panel(crp_csr_dev *A, int idx)
     if (e == hipSuccess && !h.pval.empty())
         e = hipMemcpy(d.pval, h.pval.data(), sizeof(double) * h.pval.size(), hipMemcpyHostToDevice);
     if (e != hipSuccess) return (int) e;
+    if (A->host_vals_stale && A->nnz > 0) CRP_TRY(crp::scatter_vals_f64(A->nnz, d.pmap, A->val, d.pval, stream));
     d.built = true;
     return 0;
 }
 
 // Build (once) and upload the team format on top of the R = 8 panels. Blocking.
-static int ensure_team(crp_csr_dev *A)
+static int ensure_team(crp_csr_dev *A, hipStream_t stream)
 {
     TeamDev &t = A->team;
     if (t.built) return 0;
-    const int rc = ensure_panel(A, 1);
+    const int rc = ensure_panel(A, 1, stream);
     if (rc != 0) return rc;
     crp::PanelHost h;
     crp::build_panels(A->nrow, fmt_rowptr(A), fmt_colidx(A), fmt_val(A), 8, &h, false);
@@ -208,6 +212,7 @@ static int ensure_team(crp_csr_dev *A)
     if (e == hipSuccess) e = up((void **) &t.tval, tval.data(), sizeof(double) * tval.size(), 1024);
     if (e == hipSuccess) e = up((void **) &t.tmap, tmap.data(), sizeof(uint32_t) * tmap.size(), 4);
     if (e != hipSuccess) return (int) e;
+    if (A->host_vals_stale && A->nnz > 0) CRP_TRY(crp::scatter_vals_f64(A->nnz, t.tmap, A->val, t.tval, stream));
     t.built = true;
     return 0;
 }
@@ -220,7 +225,7 @@ static int team2_waves()
     return w;
 }
 
-static int ensure_team2(crp_csr_dev *A)
+static int ensure_team2(crp_csr_dev *A, hipStream_t stream)
 {
     Team2Dev &t = A->team2;
     if (t.built) return 0;
@@ -261,6 +266,7 @@ static int ensure_team2(crp_csr_dev *A)
     if (e == hipSuccess) e = up((void **) &t.tval, th.tval.data(), sizeof(double) * th.tval.size(), 4096);
     if (e == hipSuccess) e = up((void **) &t.tmap, th.vmap.data(), sizeof(uint32_t) * th.vmap.size(), 4);
     if (e != hipSuccess) return (int) e;
+    if (A->host_vals_stale && A->nnz > 0) CRP_TRY(crp::scatter_vals_f64(A->nnz, t.tmap, A->val, t.tval, stream));
     clk.lap("ensure_team2: upload");
     t.built = true;
     return 0;
@@ -600,7 +606,9 @@ int crp_csr_dev_update_values(crp_csr_dev_p A, const double *val, void *stream)
     {
         memcpy(A->h_val.data(), val, sizeof(double) * (size_t) A->nnz);   // formats built later see the new values
         for (size_t q = 0; q < A->f_val.size(); q++) A->f_val[q] = val[A->f_nz[q]];
+        A->host_vals_stale = false;
     }
+    else A->host_vals_stale = true;      // formats built later are refreshed from the device CSR (ensure_*)
     for (int i = 0; i < 2; i++)
         if (A->pan[i].built)
             CRP_TRY(crp::scatter_vals_f64(A->nnz, A->pan[i].pmap, A->val, A->pan[i].pval, (hipStream_t) stream));
@@ -675,10 +683,13 @@ int crp_spmm_csr_f64(crp_csr_dev_p A, int layout, int n, const double *B0, long 
     // 0.65 / 0.63; at n = 96 -- a tile of 128 columns three quarters used -- 1.17 / 1.00 / 0.94, at n = 32 1.6 x)
     if (variant == 0 && A->team2_pays && n >= TEAM2_MIN_N && crp::spmm_team2_applicable(a)) v = 5;
     if (v == 5 && (!crp::spmm_team2_applicable(a) || A->nnz == 0 || A->nrow < 8)) v = 3;
-    if (v >= 2 && A->rowmap_fmt != nullptr) a.rowmap = A->rowmap_fmt;      // derived formats hold the rows in processing order
+    // the derived formats hold the rows in processing order: their C row map is chosen per launch, AFTER every fallback has
+    // resolved (a re-ordered matrix that falls back to the CSR kernel writes through the caller's map)
+    int *const fmt_map = A->rowmap_fmt != nullptr ? A->rowmap_fmt : A->rowmap;
     if (v == 5)
     {
-        const int rc = ensure_team2(A);
+        a.rowmap = fmt_map;
+        const int rc = ensure_team2(A, (hipStream_t) stream);
         if (rc != 0) return rc;
         crp::Team2Args t;
         t.nteam = A->team2.nteam; t.ngrid = A->team2.ngrid; t.tw = A->team2.tw; t.torder = A->team2.torder; t.tpanel = A->team2.tpanel; t.tinfo = A->team2.tinfo;
@@ -689,7 +700,8 @@ int crp_spmm_csr_f64(crp_csr_dev_p A, int layout, int n, const double *B0, long 
     if (v >= 2 && (!crp::spmm_panel_applicable(a) || A->nnz == 0)) v = 1;   // narrow / unaligned operands
     if (v == 4)
     {
-        const int rc = ensure_team(A);
+        a.rowmap = fmt_map;
+        const int rc = ensure_team(A, (hipStream_t) stream);
         if (rc != 0) return rc;
         crp::TeamArgs t;
         t.nteam = A->team.nteam; t.torder = A->team.torder; t.tpanel = A->team.tpanel; t.tptr = A->team.tptr;
@@ -698,7 +710,8 @@ int crp_spmm_csr_f64(crp_csr_dev_p A, int layout, int n, const double *B0, long 
     }
     if (v >= 2)
     {
-        const int rc = ensure_panel(A, v - 2);       // no-op unless an explicit variant asks for a new format
+        a.rowmap = fmt_map;
+        const int rc = ensure_panel(A, v - 2, (hipStream_t) stream);       // no-op unless an explicit variant asks for a new format
         if (rc != 0) return rc;
         const PanelDev &d = A->pan[v - 2];
         crp::PanelArgs p;
@@ -732,7 +745,7 @@ int crp_spmm_csr_f32(crp_csr_dev_p A, int n, const float *B0, long long ldB0, co
     const bool team = (variant == 5 || (variant == 0 && A->team2_pays && n >= TEAM2_MIN_N_F32)) && A->nnz > 0 && A->nrow >= 8 &&
                       crp::spmm_team2_applicable_f32(a);
     if (!team) return (int) crp::spmm_rm_f32_rowgroup(a, (hipStream_t) stream);
-    const int rc = ensure_team2(A);
+    const int rc = ensure_team2(A, (hipStream_t) stream);
     if (rc != 0) return rc;
     if (A->team2.tval32 == nullptr)
     {
@@ -811,6 +824,16 @@ int crp_team_format_host(int nrow, const int *rowptr, const int *colidx, const d
 
 int crp_team2_waves(void) { return team2_waves(); }
 
+static std::vector<int> g_last_tgrid;       // launch grid of the last crp_team2_format_host() (planning / test helper)
+int crp_team2_format_host_grid(int **tgrid, int *ngrid)
+{
+    if (tgrid == NULL || ngrid == NULL) return -1;
+    *ngrid = (int) g_last_tgrid.size();
+    *tgrid = (int *) malloc(sizeof(int) * (g_last_tgrid.size() + 1));
+    if (!g_last_tgrid.empty()) memcpy(*tgrid, g_last_tgrid.data(), sizeof(int) * g_last_tgrid.size());
+    return 0;
+}
+
 int crp_team2_format_host(int nrow, const int *rowptr, const int *colidx, const double *val, int *nteam, int *lattice,
                           int **tpanel, int **tinfo, int **tpro, unsigned **trec, long long *nrecwords,
                           long long **tvoff, double **tval, long long *nvalent, int **torder, unsigned **vmap)
@@ -823,6 +846,7 @@ int crp_team2_format_host(int nrow, const int *rowptr, const int *colidx, const 
     crp::Team2Host th;
     th.T = team2_waves();
     crp::build_team2(h, nrow, rowptr, colidx, &th);
+    g_last_tgrid = th.tgrid;
     *nteam = th.nteam;
     if (lattice) *lattice = th.lattice ? 1 : 0;
     auto dup_i = [](const std::vector<int> &v) {

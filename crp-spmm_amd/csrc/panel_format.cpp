@@ -6,6 +6,7 @@
 #include <string.h>
 #include "locality.h"
 #include "panel_format.h"
+#include "team_order.h"
 #include "par.h"
 #include <time.h>
 
@@ -585,7 +586,7 @@ static void build_key_csr(int n, F raw, std::vector<long long> *iptr, std::vecto
     });
 }
 
-void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *colidx, TeamHost *out, int T)
+void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *colidx, TeamHost *out, int T, const int *colpos)
 {
     constexpr int TMAX = 16;
     if (T != 4 && T != 6 && T != 8 && T != 16) T = 4;
@@ -897,6 +898,90 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
     // else the natural order
     out->torder.resize((size_t) nteam);
     for (int g = 0; g < nteam; g++) out->torder[(size_t) g] = g;
+    // Teams of eight and more (the LDS-sharing kernel): recursive bisection of the team graph (team_order.h) -- two teams
+    // are adjacent when one reads a B row whose row of A the other owns, weight = such rows.  CRPSPMM_T2_ORDER=legacy keeps
+    // the round-2 orders (lattice: strips of team columns swept along the teeth; clusters: greedy super-teams in slab order).
+    static const bool legacy_order = getenv("CRPSPMM_T2_ORDER") != NULL && strcmp(getenv("CRPSPMM_T2_ORDER"), "legacy") == 0;
+    out->bisected = false;
+    if (T >= 8 && !legacy_order && nteam >= 2 * (T == 16 ? 32 : 64))
+    {
+        const int npanel_all = np;
+        std::vector<int> team_of_panel((size_t) npanel_all, -1);
+        for (int g = 0; g < nteam; g++)
+            for (int w = 0; w < T; w++)
+                if (out->tpanel[(size_t) g * T + w] >= 0) team_of_panel[(size_t) out->tpanel[(size_t) g * T + w]] = g;
+        // directed lists: team -> (owner team of a column it reads, rows)
+        std::vector<std::vector<std::pair<int, int>>> fwd((size_t) nteam);
+        parallel_chunks(nteam, 64, [&](long long b, long long e, int) {
+            std::vector<int> own;
+            for (long long g = b; g < e; g++)
+            {
+                own.clear();
+                for (int c : ucol[(size_t) g])
+                {
+                    if (c < 0) continue;                          // a row of the receive buffer: no row of A behind it
+                    const long long pos = colpos ? (c < nrow ? colpos[c] : -1) : c;
+                    if (pos < 0 || pos >= (long long) nrow) continue;
+                    const int h = team_of_panel[(size_t) (pos / R)];
+                    if (h >= 0 && h != (int) g) own.push_back(h);
+                }
+                std::sort(own.begin(), own.end());
+                std::vector<std::pair<int, int>> &f = fwd[(size_t) g];
+                for (size_t a = 0; a < own.size();)
+                {
+                    size_t z = a;
+                    while (z < own.size() && own[z] == own[a]) z++;
+                    f.push_back({own[a], (int) (z - a)});
+                    a = z;
+                }
+            }
+        });
+        // symmetric CSR: forward lists merged with their transpose (weights added)
+        std::vector<long long> tptr((size_t) nteam + 1, 0);
+        for (int g = 0; g < nteam; g++)
+            for (const auto &pr : fwd[(size_t) g]) tptr[(size_t) pr.first + 1]++;
+        for (int g = 0; g < nteam; g++) tptr[(size_t) g + 1] += tptr[(size_t) g];
+        std::vector<std::pair<int, int>> tr((size_t) tptr[(size_t) nteam]);
+        {
+            std::vector<long long> fillp(tptr.begin(), tptr.end() - 1);
+            for (int g = 0; g < nteam; g++)                      // (ascending g: every transposed list comes out sorted)
+                for (const auto &pr : fwd[(size_t) g]) tr[(size_t) fillp[(size_t) pr.first]++] = {g, pr.second};
+        }
+        std::vector<long long> gptr((size_t) nteam + 1, 0);
+        std::vector<std::vector<std::pair<int, int>>> sym((size_t) nteam);
+        parallel_chunks(nteam, 256, [&](long long b, long long e, int) {
+            for (long long g = b; g < e; g++)
+            {
+                const std::vector<std::pair<int, int>> &f = fwd[(size_t) g];
+                std::vector<std::pair<int, int>> &o = sym[(size_t) g];
+                size_t a = 0;
+                long long z = tptr[(size_t) g];
+                const long long ze = tptr[(size_t) g + 1];
+                while (a < f.size() || z < ze)
+                {
+                    if (z >= ze || (a < f.size() && f[a].first < tr[(size_t) z].first)) o.push_back(f[a++]);
+                    else if (a >= f.size() || tr[(size_t) z].first < f[a].first) o.push_back(tr[(size_t) z++]);
+                    else { o.push_back({f[a].first, f[a].second + tr[(size_t) z].second}); a++; z++; }
+                }
+                gptr[(size_t) g + 1] = (long long) o.size();
+            }
+        });
+        for (int g = 0; g < nteam; g++) gptr[(size_t) g + 1] += gptr[(size_t) g];
+        std::vector<int> gadj((size_t) gptr[(size_t) nteam]), gw((size_t) gptr[(size_t) nteam]), work((size_t) nteam);
+        parallel_chunks(nteam, 256, [&](long long b, long long e, int) {
+            for (long long g = b; g < e; g++)
+            {
+                long long q = gptr[(size_t) g];
+                for (const auto &pr : sym[(size_t) g]) { gadj[(size_t) q] = pr.first; gw[(size_t) q] = pr.second; q++; }
+                work[(size_t) g] = ((int) ucol[(size_t) g].size() + T - 1) / T + 4;
+            }
+        });
+        clk.lap("build_teams: team graph");
+        bisection_order(nteam, gptr, gadj, gw, work, T == 16 ? 32 : 64, &out->torder);
+        out->bisected = true;
+        clk.lap("build_teams: processing order (recursive bisection)");
+        return;
+    }
     if (clustered && nteam >= 128)
     {
         // Clustered teams: the workgroups resident on an XCD at one time (64: 32 CUs x 2) start together and walk
@@ -1011,7 +1096,7 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
     const size_t blkw = (size_t) 32 * T;                                    // words of a record block (8 rounds x T waves x 4)
     PhaseClock clk;
     TeamHost th;
-    build_teams(p, nrow, rowptr, colidx, &th, T);
+    build_teams(p, nrow, rowptr, colidx, &th, T, colpos);
     clk.lap("build_team2: build_teams total");
     // Phase key of a union entry: (position of its B row in the processing order) mod S, S = rows a team advances
     // along its sweep (8 x the consecutive panels of a lattice team, 64 for eight consecutive panels).  Teams are
@@ -1033,100 +1118,190 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
     struct TeamOut
     {
         int nr = 0, filled = 0, nparts = 0;
-        std::vector<int> col;                       // nr * T slot columns
+        int anycol = 0;                             // a column of the team (a valid row for the prologue's empty slots)
+        std::vector<int> col;                       // nr * T slot columns (TEAM2_NOCOL = empty slot)
         // parts of wave w in round r: ownp[(r * T + w) * CAP .. + ownc[r * T + w])  (flat: one small vector per
         // (round, wave) was 126 M heap allocations on the nlpkkt240-size matrix)
         std::vector<Part> ownp;
         std::vector<unsigned char> ownc;
     };
     std::vector<TeamOut> res((size_t) nteam);
-    parallel_chunks(nteam, 32, [&](long long b, long long e, int) {
-        std::vector<int> k8;
-        for (long long g = b; g < e; g++)
+    // real union entries of team g
+    auto team_nodes = [&](int g, std::vector<int> &nodes) {
+        nodes.clear();
+        for (int q = th.tptr[(size_t) g]; q < th.tptr[(size_t) g + 1]; q++)
         {
-            TeamOut &to = res[(size_t) g];
-            // real union entries of the team, in the team's schedule order
-            std::vector<int> nodes;
-            for (int q = th.tptr[(size_t) g]; q < th.tptr[(size_t) g + 1]; q++)
-            {
-                bool used = false;
-                for (int w = 0; w < T; w++) used = used || th.tsrc[(size_t) q * T + (size_t) w] >= 0;
-                if (used) nodes.push_back(q);
-            }
-            if (phase)
-            {
-                auto key = [&](int q) {
-                    const int c = th.tcol[(size_t) q];
-                    const long long ps = c >= 0 ? (colpos ? colpos[c] : c) : (long long) (~c);
-                    // clustered teams (square part): where the row of A with this number sits inside ITS team
-                    if (th.clustered && c >= 0 && ps / 8 < (long long) th.plocal.size()) return (int) (ps % 8) * 16 + th.plocal[(size_t) (ps / 8)];      // (row of the panel, slot): neighbours in the order belong to different waves
-                    return (int) (ps % S);
-                };
-                std::stable_sort(nodes.begin(), nodes.end(), [&](int x, int y) { return key(x) < key(y); });
-            }
-            // contiguous row ranges of every (node, wave)
-            auto ranges = [&](unsigned m, Part *dst) {
-                int n = 0;
-                for (int r = 0; r < 8;)
-                {
-                    if (!((m >> r) & 1u)) { r++; continue; }
-                    int l = 1;
-                    while (r + l < 8 && ((m >> (r + l)) & 1u)) l++;
-                    dst[n].first = r; dst[n].len = l; n++;
-                    r += l;
-                }
-                return n;
-            };
-            std::vector<char> taken(nodes.size(), 0);
-            size_t head = 0, left = nodes.size();
-            const int last_col = nodes.empty() ? 0 : th.tcol[(size_t) nodes[0]];
-            while (left > 0)
-            {
-                int cnt[TMAX];
-                for (int w = 0; w < TMAX; w++) cnt[w] = 0;
-                int nslot = 0;
-                const size_t base_col = to.col.size();
-                to.col.resize(base_col + (size_t) T, last_col);
-                to.ownp.resize(to.ownp.size() + (size_t) T * CAP);
-                to.ownc.resize(to.ownc.size() + (size_t) T, 0);
-                while (head < nodes.size() && taken[head]) head++;
-                int seen = 0;
-                for (size_t t = head; t < nodes.size() && nslot < T && seen < 4 * T; t++)
-                {
-                    if (taken[t]) continue;
-                    seen++;
-                    const int q = nodes[t];
-                    Part tmp[TMAX][4];
-                    int kk[TMAX];
-                    bool fits = true;
-                    for (int w = 0; w < T; w++)
-                    {
-                        const int src = th.tsrc[(size_t) q * T + (size_t) w];
-                        kk[w] = src >= 0 ? ranges(mask_of((size_t) src), tmp[w]) : 0;
-                        if (cnt[w] + kk[w] > CAP) fits = false;
-                    }
-                    if (!fits) continue;
-                    for (int w = 0; w < T; w++)
-                        for (int i = 0; i < kk[w]; i++)
-                        {
-                            Part pt = tmp[w][i];
-                            pt.slot = nslot;
-                            pt.src = th.tsrc[(size_t) q * T + (size_t) w];
-                            to.ownp[((size_t) to.nr * T + (size_t) w) * CAP + (size_t) cnt[w]] = pt;
-                            to.ownc[(size_t) to.nr * T + (size_t) w]++;
-                            cnt[w]++;
-                            to.nparts++;
-                        }
-                    to.col[base_col + (size_t) nslot] = th.tcol[(size_t) q];
-                    nslot++;
-                    taken[t] = 1;
-                    left--;
-                }
-                to.filled += nslot;
-                to.nr++;
-            }
+            bool used = false;
+            for (int w = 0; w < T; w++) used = used || th.tsrc[(size_t) q * T + (size_t) w] >= 0;
+            if (used) nodes.push_back(q);
         }
-    });
+    };
+    auto key = [&](int q) {
+        const int c = th.tcol[(size_t) q];
+        const long long ps = c >= 0 ? (colpos ? colpos[c] : c) : (long long) (~c);
+        // clustered teams (square part): where the row of A with this number sits inside ITS team
+        if (th.clustered && c >= 0 && ps / 8 < (long long) th.plocal.size()) return (int) (ps % 8) * 16 + th.plocal[(size_t) (ps / 8)];      // (row of the panel, slot): neighbours in the order belong to different waves
+        return (int) (ps % S);
+    };
+    // contiguous row ranges of every (node, wave)
+    auto ranges = [&](unsigned m, Part *dst) {
+        int n = 0;
+        for (int r = 0; r < 8;)
+        {
+            if (!((m >> r) & 1u)) { r++; continue; }
+            int l = 1;
+            while (r + l < 8 && ((m >> (r + l)) & 1u)) l++;
+            dst[n].first = r; dst[n].len = l; n++;
+            r += l;
+        }
+        return n;
+    };
+    // List scheduler of one team: `nodes` in the order they are to be met; target (optional) = the earliest round of
+    // every node (absolute schedule: a round takes only nodes whose target has come, and stays partly or wholly empty
+    // otherwise); <= T slots per round, <= CAP parts per wave and round, look-ahead 4 T nodes.
+    // Empty slots carry TEAM2_NOCOL: the kernel fetches nothing for them.
+    auto schedule_team = [&](int g, const std::vector<int> &nodes, const int *target) {
+        TeamOut &to = res[(size_t) g];
+        to.anycol = nodes.empty() ? 0 : th.tcol[(size_t) nodes[0]];
+        std::vector<char> taken(nodes.size(), 0);
+        size_t head = 0, left = nodes.size();
+        while (left > 0)
+        {
+            int cnt[TMAX];
+            for (int w = 0; w < TMAX; w++) cnt[w] = 0;
+            int nslot = 0;
+            const size_t base_col = to.col.size();
+            to.col.resize(base_col + (size_t) T, TEAM2_NOCOL);
+            to.ownp.resize(to.ownp.size() + (size_t) T * CAP);
+            to.ownc.resize(to.ownc.size() + (size_t) T, 0);
+            while (head < nodes.size() && taken[head]) head++;
+            int seen = 0;
+            for (size_t t = head; t < nodes.size() && nslot < T && seen < 4 * T; t++)
+            {
+                if (taken[t]) continue;
+                if (target != nullptr && target[t] > to.nr) break;         // (targets ascend with t)
+                seen++;
+                const int q = nodes[t];
+                Part tmp[TMAX][4];
+                int kk[TMAX];
+                bool fits = true;
+                for (int w = 0; w < T; w++)
+                {
+                    const int src = th.tsrc[(size_t) q * T + (size_t) w];
+                    kk[w] = src >= 0 ? ranges(mask_of((size_t) src), tmp[w]) : 0;
+                    if (cnt[w] + kk[w] > CAP) fits = false;
+                }
+                if (!fits) continue;
+                for (int w = 0; w < T; w++)
+                    for (int i = 0; i < kk[w]; i++)
+                    {
+                        Part pt = tmp[w][i];
+                        pt.slot = nslot;
+                        pt.src = th.tsrc[(size_t) q * T + (size_t) w];
+                        to.ownp[((size_t) to.nr * T + (size_t) w) * CAP + (size_t) cnt[w]] = pt;
+                        to.ownc[(size_t) to.nr * T + (size_t) w]++;
+                        cnt[w]++;
+                        to.nparts++;
+                    }
+                to.col[base_col + (size_t) nslot] = th.tcol[(size_t) q];
+                nslot++;
+                taken[t] = 1;
+                left--;
+            }
+            to.filled += nslot;
+            to.nr++;
+        }
+    };
+    // ---- the launch grid: the order cut into 8 contiguous pieces of equal work (union entries / T + a fixed cost per
+    // team), one per XCD -- pieces of equal team COUNT leave XCDs idle when the teams differ (KKT systems: 27-point primal
+    // rows, short dual rows).  Under the bisection order the cuts fall on multiples of a generation.
+    const int WGS = T == 16 ? 32 : 64;                                  // workgroups resident on an XCD = a generation
+    static const bool abs_env = getenv("CRPSPMM_T2_ABS") == NULL || atoi(getenv("CRPSPMM_T2_ABS")) != 0;
+    const bool absolute = th.bisected && abs_env && phase;
+    std::vector<int> cut(9, nteam);
+    {
+        std::vector<int> nn((size_t) nteam, 0);
+        parallel_chunks(nteam, 256, [&](long long b, long long e, int) {
+            std::vector<int> nodes;
+            for (long long g = b; g < e; g++) { team_nodes((int) g, nodes); nn[(size_t) g] = (int) nodes.size(); }
+        });
+        long long total = 0;
+        for (int g = 0; g < nteam; g++) total += (nn[(size_t) g] + T - 1) / T + 4;
+        cut[0] = 0;
+        long long acc = 0;
+        int x = 1;
+        for (int i = 0; i < nteam && x < 8; i++)
+        {
+            acc += (nn[(size_t) out->torder[(size_t) i]] + T - 1) / T + 4;
+            while (x < 8 && acc * 8 >= total * x) cut[(size_t) x++] = i + 1;
+        }
+        if (th.bisected)
+            for (int q = 1; q < 8; q++)
+            {
+                const int c = (cut[(size_t) q] + WGS / 2) / WGS * WGS;
+                cut[(size_t) q] = std::max(cut[(size_t) q - 1], std::min(nteam, c));
+            }
+    }
+    if (!absolute)
+        parallel_chunks(nteam, 32, [&](long long b, long long e, int) {
+            std::vector<int> nodes;
+            for (long long g = b; g < e; g++)
+            {
+                team_nodes((int) g, nodes);
+                if (phase) std::stable_sort(nodes.begin(), nodes.end(), [&](int x, int y) { return key(x) < key(y); });
+                schedule_team((int) g, nodes, nullptr);
+            }
+        });
+    else
+    {
+        // Absolute schedule.  A generation = WGS consecutive teams of an XCD's piece: they become resident together and
+        // must meet a B row they share within the few rounds a line survives in L2.  All of them therefore walk ONE
+        // list: the generation's distinct rows in key order, dealt evenly over R rounds (R = what the team with the
+        // largest union needs); a team fetches its rows in the rounds the list gives them and idles in between, so
+        // teams of different length (27-point primal rows next to 7-point dual rows) stay aligned to the last round.
+        struct Gen { int first, count; };
+        std::vector<Gen> gens;
+        for (int q = 0; q < 8; q++)
+            for (int i = cut[(size_t) q]; i < cut[(size_t) q + 1]; i += WGS) gens.push_back({i, std::min(WGS, cut[(size_t) q + 1] - i)});
+        parallel_chunks((long long) gens.size(), 1, [&](long long b, long long e, int) {
+            std::vector<std::vector<int>> nodes;
+            std::vector<std::pair<uint64_t, int>> all;             // (key << 32 | column key, slot in `where`)
+            std::vector<int> target;
+            for (long long gi = b; gi < e; gi++)
+            {
+                const Gen &G = gens[(size_t) gi];
+                nodes.assign((size_t) G.count, std::vector<int>());
+                all.clear();
+                int R = 1;
+                for (int i = 0; i < G.count; i++)
+                {
+                    const int g = out->torder[(size_t) (G.first + i)];
+                    team_nodes(g, nodes[(size_t) i]);
+                    R = std::max(R, ((int) nodes[(size_t) i].size() + T - 1) / T);
+                    for (int q : nodes[(size_t) i]) all.push_back({((uint64_t) (uint32_t) key(q) << 32) | (uint64_t) col_key(th.tcol[(size_t) q]), 0});
+                }
+                std::sort(all.begin(), all.end());
+                all.erase(std::unique(all.begin(), all.end()), all.end());
+                const size_t U = all.size();
+                for (int i = 0; i < G.count; i++)
+                {
+                    const int g = out->torder[(size_t) (G.first + i)];
+                    std::vector<int> &nd = nodes[(size_t) i];
+                    std::vector<std::pair<int, int>> tn(nd.size());       // (target round, union entry)
+                    for (size_t t = 0; t < nd.size(); t++)
+                    {
+                        const uint64_t k = ((uint64_t) (uint32_t) key(nd[t]) << 32) | (uint64_t) col_key(th.tcol[(size_t) nd[t]]);
+                        const size_t rank = (size_t) (std::lower_bound(all.begin(), all.end(), std::make_pair(k, 0)) - all.begin());
+                        tn[t] = {(int) (rank * (size_t) R / U), nd[t]};
+                    }
+                    std::stable_sort(tn.begin(), tn.end(), [](const std::pair<int, int> &x, const std::pair<int, int> &y) { return x.first < y.first; });
+                    target.resize(nd.size());
+                    for (size_t t = 0; t < nd.size(); t++) { target[t] = tn[t].first; nd[t] = tn[t].second; }
+                    schedule_team(g, nd, target.data());
+                }
+            }
+        });
+    }
 
     clk.lap("build_team2: rounds (phase sort, list scheduler)");
     // ---- layout: record blocks, value streams
@@ -1154,21 +1329,8 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
         }
     }
     out->tvoff[(size_t) nteam * T] = run;
-    // launch grid: the order cut into 8 contiguous pieces of equal work (rounds + a fixed cost per team), one per
-    // XCD -- pieces of equal team COUNT leave XCDs idle when the teams differ (KKT systems: 27-point primal rows,
-    // short dual rows; 73 % of the wave slots busy on the nlpkkt stand-in)
+    // launch grid: run x of tgrid = what XCD x processes, in order (the cuts computed above)
     {
-        long long total = 0;
-        for (int g = 0; g < nteam; g++) total += res[(size_t) g].nr + 4;
-        std::vector<int> cut(9, nteam);
-        cut[0] = 0;
-        long long acc = 0;
-        int x = 1;
-        for (int i = 0; i < nteam && x < 8; i++)
-        {
-            acc += res[(size_t) out->torder[(size_t) i]].nr + 4;
-            while (x < 8 && acc * 8 >= total * x) cut[(size_t) x++] = i + 1;
-        }
         int cpx = 1;
         for (int q = 0; q < 8; q++) cpx = std::max(cpx, cut[(size_t) q + 1] - cut[(size_t) q]);
         out->tgrid.assign((size_t) cpx * 8, -1);
@@ -1218,9 +1380,10 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
                     const int rd = r + D;
                     uint32_t *rec = &out->trec[((size_t) blk0[(size_t) g] + (size_t) (r >> 3)) * blkw + (size_t) (r & 7) * 4 * T + (size_t) w * 4];
                     rec[2] = (uint32_t) (rd < to.nr ? voff[(size_t) rd] : voff[(size_t) to.nr]);
-                    rec[3] = (uint32_t) (rd < to.nr ? to.col[(size_t) rd * T + (size_t) w] : to.col[0]);
+                    rec[3] = (uint32_t) (rd < to.nr ? to.col[(size_t) rd * T + (size_t) w] : TEAM2_NOCOL);
                     // flags that steer the kernel's round (tools/gen_team2_asm.py)
                     if (rd < to.nr) rec[0] |= 1u << fbase;                                   // ISSUE: fetch for round r + D
+                    if (rd < to.nr && to.ownc[(size_t) rd * T + (size_t) w] == 0) rec[0] |= 1u << (fbase + 4);   // NOVAL: no parts there, no values to fetch
                     if (r + D - 1 >= to.nr) rec[0] |= 1u << (fbase + 1);                           // TAIL: fewer than D-1 younger rounds in flight
                     if (r == to.nr - 1) rec[0] |= 1u << (fbase + 2);                               // LAST
                     if (w == 0 && (r & 7) == 0 && (r >> 3) + 1 < (to.nr + 7) / 8) rec[0] |= 1u << (fbase + 3);   // RECS: fetch the next record block
@@ -1228,7 +1391,8 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
                 for (int d = 0; d < D; d++)
                 {
                     int *pr = &out->tpro[(((size_t) g * D + (size_t) d) * T + (size_t) w) * 2];
-                    pr[0] = (d < to.nr) ? to.col[(size_t) d * T + (size_t) w] : (to.nr > 0 ? to.col[0] : 0);
+                    // (the prologue's fetches are compiled code with a fixed DMA count: an empty slot fetches a valid row)
+                    pr[0] = (d < to.nr && to.col[(size_t) d * T + (size_t) w] != TEAM2_NOCOL) ? to.col[(size_t) d * T + (size_t) w] : to.anycol;
                     pr[1] = (int) ((d < to.nr) ? voff[(size_t) d] : voff[(size_t) to.nr]);
                 }
             }

@@ -110,8 +110,10 @@ struct TeamHost
     std::vector<long long> tq;     // per panel-format entry: its entry index in the value streams, or -1
     std::vector<int>      tsrc;    // T per union entry: the panel-format entry of wave w behind it, or -1
     long long real_entries = 0;    // union entries before padding
+    bool bisected = false;         // torder = recursive bisection of the team graph (team_order.h): a generation = 64 (T = 16: 32) consecutive teams
 };
-void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *colidx, TeamHost *out, int T = 4);
+// colpos (optional, matrices in a locality order): position of row c of A in the order the panels were built on.
+void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *colidx, TeamHost *out, int T = 4, const int *colpos = nullptr);
 
 // Team schedule for the row-panel kernel itself (no LDS sharing): the entries of every panel are
 // re-ordered to the order in which its wave meets them in the team's balanced schedule, and the
@@ -142,6 +144,7 @@ void apply_team_schedule(PanelHost *p, const TeamHost &t);
 constexpr int TEAM2_T = 8;
 constexpr int TEAM2_D = 3;
 constexpr int TEAM2_CAP = 4;
+constexpr int TEAM2_NOCOL = (int) 0x80000000;   // column word of an empty slot: the wave fetches no B row for it
 struct Team2Host
 {
     int T = TEAM2_T;                 // panels (= waves = slots of a round) per team: 8, or 16 (set before build_team2)

@@ -139,7 +139,7 @@ def team_format_host(rowptr, colidx, val):
 
 def team2_format_host(rowptr, colidx, val):
     """crp_team2_format_host -> dict(nteam, waves W (8 or 16), lattice, tpanel[nteam, W], tinfo[nteam, 4], tpro[nteam, 3, W, 2],
-    trec (uint32 words), tvoff, tval[groups, 8], torder, vmap)."""
+    trec (uint32 words), tvoff, tval[groups, 8], torder, vmap, tgrid[8, entries per XCD])."""
     lib = L.load()
     rp = np.ascontiguousarray(rowptr, dtype=np.int32)
     ci = np.ascontiguousarray(colidx, dtype=np.int32)
@@ -159,6 +159,8 @@ def team2_format_host(rowptr, colidx, val):
                                       C.byref(to), C.byref(vm)), "crp_team2_format_host")
     nt = nteam.value
     W = int(lib.crp_team2_waves())
+    tg, ng = L.c_int_p(), C.c_int()
+    L.check(lib.crp_team2_format_host_grid(C.byref(tg), C.byref(ng)), "crp_team2_format_host_grid")
 
     def take(ptr, cnt, dt):
         out = np.ctypeslib.as_array(ptr, (max(cnt, 1),))[:cnt].astype(dt).copy()
@@ -168,7 +170,7 @@ def team2_format_host(rowptr, colidx, val):
                 tinfo=take(ti, 4 * nt, np.int32).reshape(nt, 4), tpro=take(tpr, 6 * W * nt, np.int32).reshape(nt, 3, W, 2),
                 trec=take(tr, nrw.value, np.uint32), tvoff=take(tv, W * nt + 1, np.int64),
                 tval=take(tval, 8 * nve.value, np.float64).reshape(-1, 8), torder=take(to, nt, np.int32),
-                vmap=take(vm, nnz, np.uint32))
+                vmap=take(vm, nnz, np.uint32), tgrid=take(tg, ng.value, np.int32).reshape(8, -1))
 
 
 def locality_order_host(rowptr, colidx, ncol=None, nparts=8):

@@ -169,6 +169,11 @@ int crp_team2_waves(void);
 int crp_team2_format_host(int nrow, const int *rowptr, const int *colidx, const double *val, int *nteam, int *lattice,
                           int **tpanel, int **tinfo, int **tpro, unsigned **trec, long long *nrecwords,
                           long long **tvoff, double **tval, long long *nvalent, int **torder, unsigned **vmap);
+/* The launch grid of the streams crp_team2_format_host() built last (process-wide, planning / test helper only): 8 runs
+ * of *ngrid / 8 entries, run x = the teams XCD x processes, in order (-1 = none); a generation = 64 (W = 16: 32)
+ * consecutive entries of a run.  Slots of a round that hold no B row carry the column 0x80000000 (the kernel fetches
+ * nothing for them); record word 0 bit 20 (W = 16: 24) = the wave has no values to fetch for round r + 3. */
+int crp_team2_format_host_grid(int **tgrid, int *ngrid);
 
 /* Host-only: the processing order of the rows of a square A that crp_csr_dev_create() applies for B-row
  * locality (csrc/locality.cpp: row groups with identical column lists, `nparts` slabs by breadth-first

@@ -600,6 +600,79 @@ def test_locality_order_all_variants(crp, orc, gpu, monkeypatch):
     A.free()
 
 
+@pytest.mark.parametrize("n", [1, 8, 16, 23])
+def test_locality_order_narrow_fallback_keeps_row_order(crp, orc, gpu, monkeypatch, n):
+    """A re-ordered matrix multiplied by fewer than 24 columns falls back to the CSR kernel on the caller's row order:
+    the C row map of the derived formats must not be applied to it (round-2 advisor finding, hip_api.hip).  auto and
+    forced variants 2/3/4/5, with and without a caller row map."""
+    import ctypes as C
+    import torch
+    from crp_spmm_amd import gen, hip
+    lib = crp.load()
+    _IP = C.POINTER(C.c_int)
+    rp, ci, va = gen.shell_fem(nc=24, nl=40, m=24 * 40 * 6 - 3, seam_to=30)
+    m = len(rp) - 1
+    B = np.random.default_rng(10 + n).normal(size=(m, n))
+    ref = orc.spmm_csr(rp, ci, va, B)
+    monkeypatch.setenv("CRPSPMM_REORDER", "1")
+    A = hip.CsrDev(m, m, rp, ci, va)
+    assert lib.crp_csr_dev_reordered(A.handle) == 1
+    Bd = _t(B, gpu)
+    for variant in (0, 2, 3, 4, 5, 1):
+        Cd = torch.full((m, n), float("nan"), dtype=torch.float64, device=gpu)
+        hip.spmm_csr(A, Bd, Cd, n=n, variant=variant)
+        torch.cuda.synchronize()
+        assert orc.rel_fro_err(ref, Cd.cpu().numpy()) <= FP64_TOL, variant
+    rowmap = (np.arange(m, dtype=np.int32)[::-1] * 2).copy()
+    assert lib.crp_csr_dev_set_rowmap(A.handle, rowmap.ctypes.data_as(_IP), 2 * m) == 0
+    for variant in (0, 3, 5):
+        Cd = torch.full((2 * m, n), 7.0, dtype=torch.float64, device=gpu)
+        hip.spmm_csr(A, Bd, Cd, n=n, variant=variant)
+        torch.cuda.synchronize()
+        out = Cd.cpu().numpy()
+        assert orc.rel_fro_err(ref, out[rowmap]) <= FP64_TOL, variant
+        assert (out[1::2] == 7.0).all()
+    A.free()
+
+
+@pytest.mark.parametrize("reorder", ["0", "1"])
+def test_update_values_device_pointer_before_first_product(crp, orc, gpu, monkeypatch, reorder):
+    """crp_csr_dev_update_values with a DEVICE pointer before the (lazily built) derived formats exist: every variant's
+    first product must see the new values (round-2 advisor finding: the formats were built from the stale host copy)."""
+    import torch
+    from crp_spmm_amd import gen, hip
+    lib = crp.load()
+    monkeypatch.setenv("CRPSPMM_REORDER", reorder)
+    rp, ci, va = gen.shell_fem(nc=24, nl=40, m=24 * 40 * 6 - 3, seam_to=30)
+    m = len(rp) - 1
+    n = 136
+    B = np.random.default_rng(21).normal(size=(m, n))
+    v2 = np.cos(np.arange(len(va))) + 2.0
+    ref2 = orc.spmm_csr(rp, ci, v2, B)
+    ref1 = orc.spmm_csr(rp, ci, va, B)
+    Bd = _t(B, gpu)
+    v2d = _t(v2, gpu)
+    for variant in (0, 3, 5, 2, 4, 1):
+        A = hip.CsrDev(m, m, rp, ci, va)
+        assert lib.crp_csr_dev_update_values(A.handle, v2d.data_ptr(), None) == 0
+        Cd = torch.full((m, n), float("nan"), dtype=torch.float64, device=gpu)
+        hip.spmm_csr(A, Bd, Cd, n=n, variant=variant)
+        torch.cuda.synchronize()
+        assert orc.rel_fro_err(ref2, Cd.cpu().numpy()) <= FP64_TOL, variant
+        if variant in (0, 5):
+            # ... and the fp32 value streams derived afterwards
+            Cf = torch.empty((m, n), dtype=torch.float32, device=gpu)
+            hip.spmm_csr_f32(A, Bd.to(torch.float32), Cf, n=n, variant=5)
+            torch.cuda.synchronize()
+            assert orc.rel_fro_err(ref2, Cf.cpu().numpy().astype(np.float64)) <= 1e-5
+        # a host update afterwards is authoritative again
+        assert lib.crp_csr_dev_update_values(A.handle, va.ctypes.data, None) == 0
+        hip.spmm_csr(A, Bd, Cd, n=n, variant=variant)
+        torch.cuda.synchronize()
+        assert orc.rel_fro_err(ref1, Cd.cpu().numpy()) <= FP64_TOL, variant
+        A.free()
+
+
 FP32_TOL = 1e-5      # fp32 path vs the fp64 oracle: relative Frobenius error (there is no fp32 reference: src/rowpara_spmm.h:28)
 
 

@@ -644,6 +644,9 @@ def _replay_team2(t, m, B, va=None):
                 # flags: ISSUE while a round r + 3 exists, TAIL near the end, LAST on the last round
                 assert bool(x >> fbase & 1) == (r + 3 < nr) and bool(x >> (fbase + 2) & 1) == (r == nr - 1)
                 assert bool(x >> (fbase + 1) & 1) == (r + 2 >= nr)
+                # NOVAL: the wave has no parts in round r + 3, so it fetches no values for it
+                cnt3 = int(rec[blk0 + ((r + 3) >> 3), (r + 3) & 7, w, 0]) & 7 if r + 3 < nr else 1
+                assert bool(x >> (fbase + 4) & 1) == (cnt3 == 0), (g, w, r)
                 if panel < 0:
                     assert cnt == 0
                 if cnt:
@@ -684,6 +687,9 @@ def test_team2_streams_replay(crp, orc):
     nx, ny, nz = 300, 5, 3
     cases.append(("clustered",) + gen.banded_fem(nx * ny * nz, offsets=(1, 2, 3, nx, nx + 1, nx * ny, nx * ny + 1), seed=3))
     cases.append(("random",) + gen.random_csr(611, 611, 14, seed=5, empty_every=9))
+    # enough clustered teams (>= 128) for the bisection order and the generation-wide absolute schedule; primal rows
+    # of 34 and dual rows of 7 nonzeros give teams of very different length (rounds with empty slots, idle waves)
+    cases.append(("kkt",) + gen.kkt3d(16))
     cases.append(("tiny",) + gen.random_csr(13, 40, 5, seed=1))
     rp, ci, va = gen.random_csr(200, 64, 6, seed=8)
     ci2 = ci.copy()

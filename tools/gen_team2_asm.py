@@ -23,6 +23,8 @@ Record of (round r, wave w), 4 words (panel_format.h, Team2Host):
     w0 : bits 0-2 part count c (0..4) | bits 4+3i.. ring slot of part i | bit 16 ISSUE (fetch for round r + D)
          | bit 17 TAIL (fewer than D-1 younger rounds in flight at the top of round r: wait vmcnt(0))
          | bit 18 LAST round of the team | bit 19 RECS (this wave fetches the next record block now)
+         | bit 20 NOVAL (the wave has no parts in round r + D: the value DMA is issued with EXEC = 0)
+    w3 = 0x80000000 (TEAM2_NOCOL): the wave's slot of round r + D is empty, the row DMAs are issued with EXEC = 0
     w1 : bits 6i.. range code of part i        w2 : value-stream offset of round r + D        w3 : column of round r + D
 Per round: [wait own DMAs of the round; s_barrier] -> issue (values: 16-lane LDS-DMA of 256 bytes; row: NV DMAs of 1
 KiB) -> read the next record -> parts: B row slice by ds_read_b128 per 16-byte piece, the part's 8 values by ONE
@@ -129,11 +131,14 @@ def gen(nv, has_b1, f32=False, tw=8):
         emit("s_bitcmp1_b32 %%[w0], %d" % fbase)
         emit("s_cbranch_scc0 .Lt2ni%d%s" % (k, tag))
         emit("v_lshl_add_u32 v%d, %%[w2], %d, %%[lane16]" % (TV, 5 if f32 else 6))
-        emit("s_mov_b64 exec, 0x%x" % ((1 << (vslot // 16)) - 1))
+        # (a DMA whose EXEC is zero moves nothing but still counts in vmcnt: the wait counts of the loop stay fixed)
+        emit("s_bitcmp1_b32 %%[w0], %d" % (fbase + 4))                       # NOVAL: no parts in round r + D
+        emit("s_cselect_b64 exec, 0, 0x%x" % ((1 << (vslot // 16)) - 1))
         emit("s_add_u32 m0, %%[vringw], %d" % (kd * vslot))
         emit("s_nop 0")
         emit("global_load_lds_dwordx4 v%d, %%[vbase]" % TV)
-        emit("s_mov_b64 exec, -1")
+        emit("s_cmp_lg_u32 %[w3], 0x80000000")                                 # TEAM2_NOCOL: empty slot, no row
+        emit("s_cselect_b64 exec, -1, 0")
         if has_b1:
             # c < 0: row ~c of B1
             emit("s_cmp_lt_i32 %[w3], 0")
@@ -156,6 +161,7 @@ def gen(nv, has_b1, f32=False, tw=8):
         emit("global_load_lds_dwordx4 %%[voffa], s[%d:%d]%s" % (RB, RB + 1, BPOL))
         if nv == 2:
             emit("global_load_lds_dwordx4 %%[voffb], s[%d:%d] offset:1024%s" % (RB, RB + 1, BPOL))
+        emit("s_mov_b64 exec, -1")
         emit(".Lt2ni%d%s:" % (k, tag))
         # -- next record block (one wave, every 8 rounds)
         emit("s_bitcmp1_b32 %%[w0], %d" % (fbase + 3))

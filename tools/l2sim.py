@@ -16,6 +16,9 @@ import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 
 
+NOCOL = -(1 << 31)
+
+
 def team_rounds(t):
     """cols[g] = int array [rounds, 8] of the B rows team g fetches, in issue order."""
     W = t.get("waves", 8)
@@ -46,9 +49,11 @@ def xcd_queues(rounds, order, nxcd=8):
     return [list(order[cuts[q]:cuts[q + 1]]) for q in range(nxcd)]
 
 
-def simulate(rounds, order, rows, wgs, nxcd=8):
+def simulate(rounds, order, rows, wgs, nxcd=8, grid=None):
+    """grid (the format's tgrid: one run per XCD, -1 = none) when given, else the order cut by xcd_queues()."""
     miss = req = 0
-    for queue in xcd_queues(rounds, list(order), nxcd):
+    queues = [[int(g) for g in run if g >= 0] for run in grid] if grid is not None else xcd_queues(rounds, list(order), nxcd)
+    for queue in queues:
         lru = OrderedDict()
         active = []                                       # [team, next round]
         qi = 0
@@ -61,6 +66,8 @@ def simulate(rounds, order, rows, wgs, nxcd=8):
                 cols = rounds[a[0]]
                 for c in cols[a[1]]:
                     c = int(c)
+                    if c == NOCOL:                        # empty slot (TEAM2_NOCOL): nothing is fetched
+                        continue
                     req += 1
                     if c in lru:
                         lru.move_to_end(c)
@@ -104,7 +111,7 @@ def main():
         a.wgs = 32                                     # one 1024-thread workgroup per CU
     print("%s: %d rows, %d teams of %d, %d rounds, %.2f slots/row, distinct B rows %d" % (a.matrix, m, t["nteam"], W, tot, float(W) * tot / m, uniq))
     for rows in a.rows:
-        req, miss = simulate(rounds, list(t["torder"]), rows, a.wgs)
+        req, miss = simulate(rounds, list(t["torder"]), rows, a.wgs, grid=t.get("tgrid"))
         print("  L2 rows %5d wgs/xcd %d: requests %.3f GB, misses %.3f GB (%.2f x B), hit rate %.3f"
               % (rows, a.wgs, req * a.n * 8 / 1e9, miss * a.n * 8 / 1e9, miss / uniq, 1 - miss / req))
 
