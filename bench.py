@@ -94,6 +94,17 @@ def build_matrix(name, mtx=None):
         rp, ci, va = kkt240_cached()
         m = len(rp) - 1
         return "nlpkkt240-size stand-in kkt3d(241): %d rows" % m, "synthetic", m, m, rp, ci, va
+    if name == "kkt240d":
+        rp, ci, va = big_cached("kkt3d_241_c13", lambda: gen.kkt3d_big(241, coupling=gen._OFF13))
+        m = len(rp) - 1
+        return "nlpkkt240-size stand-in kkt3d(241), 13-point coupling: %d rows, %.1f nnz per row" % (m, rp[-1] / m), "synthetic", m, m, rp, ci, va
+    if name == "fem3d_queen":
+        rp, ci, va = big_cached("fem3d_111", lambda: gen.fem3d_big(111))
+        m = len(rp) - 1
+        return "Queen_4147-size stand-in fem3d(111, dof 3): %d rows" % m, "synthetic", m, m, rp, ci, va
+    if name == "er16m":
+        rp, ci, va = big_cached("er_2p24_32", lambda: gen.erdos_renyi(1 << 24, 1 << 24, 32, seed=1))
+        return "Erdos-Renyi 2^24 x 2^24, 32 nnz/row", "synthetic", 1 << 24, 1 << 24, rp, ci, va
     if name == "fem3d":
         rp, ci, va = gen.fem3d(56)
         m = len(rp) - 1
@@ -102,6 +113,19 @@ def build_matrix(name, mtx=None):
         rp, ci, va = gen.erdos_renyi(1 << 20, 1 << 20, 32, seed=1)
         return "Erdos-Renyi 2^20 x 2^20, 32 nnz/row", "synthetic", 1 << 20, 1 << 20, rp, ci, va
     raise SystemExit("unknown --matrix %s" % name)
+
+
+def big_cached(tag, make):
+    """A large generated matrix through the library's binary CSR cache (generated once per box)."""
+    from crp_spmm_amd import mmio
+    path = os.path.join(os.environ.get("CRPSPMM_CACHE_DIR", tempfile.gettempdir()), "crpspmm_%s.csrbin" % tag)
+    got = mmio.csr_cache_read(path)
+    if got is not None:
+        return got[2], got[3], got[4]
+    rp, ci, va = make()
+    m = len(rp) - 1
+    mmio.csr_cache_write(path, m, int(ci.max()) + 1 if ci.size else m, rp, ci, va)
+    return rp, ci, va
 
 
 def kkt240_cached():
@@ -118,7 +142,7 @@ def kkt240_cached():
     return rp, ci, va
 
 
-def cpu_baseline(rp, ci, va, k, n, budget_s=12.0):
+def cpu_baseline(rp, ci, va, k, n, budget_s=20.0):
     """The reference's CPU path on this box's host cores: mkl_sparse_d_create_csr + mkl_sparse_d_mm +
     mkl_sparse_destroy PER CALL, as /root/reference/src/rowpara_spmm.c:398-408 does (kind "mkl"; run in a fresh
     process with MKL_THREADING_LAYER=GNU and all cores, oracle/mkl_baseline.py).  When libmkl_rt does not load:
@@ -128,17 +152,27 @@ def cpu_baseline(rp, ci, va, k, n, budget_s=12.0):
     with tempfile.TemporaryDirectory() as td:
         path = os.path.join(td, "a.npz")
         np.savez(path, rp=rp, ci=ci, va=va, k=k, n=n)
-        env = dict(os.environ, MKL_THREADING_LAYER="GNU", OMP_NUM_THREADS=str(cores), MKL_NUM_THREADS=str(cores),
-                   OMP_PLACES="cores", OMP_PROC_BIND="close")
-        try:
-            r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "mkl_baseline.py"), path, str(budget_s)],
-                               capture_output=True, text=True, env=env, timeout=240)
-            if r.returncode == 0 and r.stdout.strip():
-                res = json.loads(r.stdout.strip().splitlines()[-1])
-                res["cores"] = cores
-                return res
-        except Exception:
-            pass
+        # thread counts swept (the 256-thread run of round 2 was slower than the survey's 8-vCPU probe: NUMA / affinity
+        # bound); the best one is reported, the sweep is named in "sample"
+        sweep = sorted({c for c in (cores, cores // 2, cores // 4, 64, 32, 16) if 1 <= c <= cores}, reverse=True)
+        best, tried = None, []
+        for thr in sweep:
+            env = dict(os.environ, MKL_THREADING_LAYER="GNU", OMP_NUM_THREADS=str(thr), MKL_NUM_THREADS=str(thr),
+                       OMP_PLACES="cores", OMP_PROC_BIND="close")
+            try:
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "mkl_baseline.py"), path, str(max(2.0, budget_s / len(sweep)))],
+                                   capture_output=True, text=True, env=env, timeout=240)
+                if r.returncode == 0 and r.stdout.strip():
+                    res = json.loads(r.stdout.strip().splitlines()[-1])
+                    res["cores"] = thr
+                    tried.append("%d: %.1f" % (thr, res["value"]))
+                    if best is None or res["value"] > best["value"]:
+                        best = res
+            except Exception:
+                pass
+        if best is not None:
+            best["sample"] += "; thread counts swept (threads: GFLOP/s) %s of %d hardware threads, best reported" % (", ".join(tried), cores)
+            return best
     import oracle
     oracle.lib()
     B = oracle.fill_B(0, k, 0, n)

@@ -140,6 +140,9 @@ SIGNATURES = {
                                    C.POINTER(c_int_p), c_int_p]),
     "crp_team_format_host": (_I, [_I, c_int_p, c_int_p, c_dbl_p, c_int_p, c_int_p, C.POINTER(c_int_p), C.POINTER(c_int_p),
                                   C.POINTER(c_int_p), C.POINTER(C.POINTER(C.c_uint)), C.POINTER(c_int_p)]),
+    "crp_probe_copy": (_I, [C.c_longlong, _V, _V, _I, _V, _V]),
+    "crp_probe_stamp": (_I, [_V, _V]),
+    "crp_stream_create_cu_mask": (_I, [C.POINTER(_V), _I, C.POINTER(C.c_uint)]),
     "crp_team2_waves": (_I, []),
     "crp_team2_format_host_grid": (_I, [C.POINTER(c_int_p), c_int_p]),
     "crp_team2_format_host": (_I, [_I, c_int_p, c_int_p, c_dbl_p, c_int_p, c_int_p, C.POINTER(c_int_p), C.POINTER(c_int_p),
@@ -173,6 +176,7 @@ SIGNATURES = {
     "crp_rccl_create": (_I, [_V, _I, _I, C.POINTER(_V)]),
     "crp_rccl_destroy": (_I, [C.POINTER(_V)]),
     "crp_rccl_nranks": (_I, [_V]),
+    "crp_rccl_create_seconds": (C.c_double, [_V]),
     "crp_rccl_rank": (_I, [_V]),
     "crp_rccl_alltoallv_f64": (_I, [_V, _V, c_ll_p, c_ll_p, _V, c_ll_p, c_ll_p, _V]),
     "crp_rccl_allgatherv": (_I, [_V, _V, C.c_size_t, _V, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), _V]),

@@ -110,15 +110,21 @@ class TorchComm:
         self._rccl = None
         if torch.cuda.is_available() and exchange_mode() == "nccl":
             lib = L.load()
-            idbuf = torch.zeros(128, dtype=torch.uint8)
+            # byte 128 = "rank 0 has an id": a failure there must reach the peers through this broadcast, not leave
+            # them waiting in it (the MPI facade does the same, csrc/mpi_facade.cpp)
+            idbuf = torch.zeros(129, dtype=torch.uint8)
             if self.rank == 0:
                 raw = (C.c_ubyte * 128)()
-                L.check(lib.crp_rccl_get_unique_id(raw), "crp_rccl_get_unique_id")
-                idbuf = torch.tensor(list(raw), dtype=torch.uint8)
+                if lib.crp_rccl_get_unique_id(raw) == 0:
+                    idbuf = torch.tensor(list(raw) + [1], dtype=torch.uint8)
             dist.broadcast(idbuf, src=self._glb_ranks[0], group=self.group)
-            raw = (C.c_ubyte * 128)(*[int(v) for v in idbuf])
             h = C.c_void_p()
-            rc = lib.crp_rccl_create(raw, self.nproc, self.rank, C.byref(h))
+            rc = -1
+            if int(idbuf[128]) == 1:
+                raw = (C.c_ubyte * 128)(*[int(v) for v in idbuf[:128]])
+                # (non-blocking creation under a deadline, csrc/crp_rccl.cpp: a peer that never arrives makes this
+                #  return an error instead of blocking inside ncclCommInitRank)
+                rc = lib.crp_rccl_create(raw, self.nproc, self.rank, C.byref(h))
             # every rank of the group must take the same transport: agree on the outcome over the control plane
             ok = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
@@ -167,6 +173,10 @@ class TorchComm:
     def device_ranks(self):
         """Ranks of the native RCCL communicator behind the device collectives, or None (host-staged / CPU)."""
         return int(L.load().crp_rccl_nranks(self._rccl)) if self._rccl else None
+
+    def device_create_seconds(self):
+        """Wall time the creation of that communicator took on this rank, or None."""
+        return float(L.load().crp_rccl_create_seconds(self._rccl)) if self._rccl else None
 
     # ---- host control plane ---------------------------------------------------
     @_fatal_on_error

@@ -9,11 +9,49 @@
 
 static_assert(sizeof(ncclUniqueId) <= CRP_RCCL_ID_BYTES, "unique id does not fit CRP_RCCL_ID_BYTES");
 
+#include <time.h>
+
 struct crp_rccl
 {
     ncclComm_t comm = nullptr;
     int nranks = 0, rank = 0;
+    double create_s = 0.0;          // wall time of the communicator's creation
 };
+
+static double now_s()
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double) ts.tv_sec + 1e-9 * (double) ts.tv_nsec;
+}
+
+// The communicators are NON-BLOCKING (ncclConfig_t::blocking = 0): ncclCommInitRank is itself a collective, and a blocking
+// one leaves every healthy rank inside it for good when one peer fails before or during its own call -- the control plane's
+// "did everybody succeed" vote is then never reached.  Non-blocking calls return ncclInProgress and are polled here under a
+// deadline (CRPSPMM_RCCL_TIMEOUT seconds, default 120 for the creation; the hot-path collectives poll without one, like a
+// blocking call would).
+static double rccl_deadline_s()
+{
+    const char *e = getenv("CRPSPMM_RCCL_TIMEOUT");
+    const double v = e ? atof(e) : 120.0;
+    return v > 0.0 ? v : 120.0;
+}
+
+// waits until the communicator's pending call has finished; deadline_s <= 0: no deadline
+static ncclResult_t wait_comm(ncclComm_t comm, double deadline_s)
+{
+    const double t0 = now_s();
+    for (;;)
+    {
+        ncclResult_t st = ncclSuccess;
+        const ncclResult_t r = ncclCommGetAsyncError(comm, &st);
+        if (r != ncclSuccess) return r;
+        if (st != ncclInProgress) return st;
+        if (deadline_s > 0.0 && now_s() - t0 > deadline_s) return ncclInProgress;
+        struct timespec nap = {0, 200000};          // 0.2 ms
+        nanosleep(&nap, NULL);
+    }
+}
 
 #define RCCL_TRY(expr)                                                                              \
     do                                                                                              \
@@ -25,6 +63,33 @@ struct crp_rccl
             return -(int) r__ - 1000;                                                               \
         }                                                                                           \
     } while (0)
+
+// inside ncclGroupStart .. ncclGroupEnd: a failing call closes the group before the function returns (an open group would
+// swallow every later RCCL call of the process); in-progress is not a failure of a non-blocking communicator
+#define RCCL_TRY_IN_GROUP(expr)                                                                     \
+    do                                                                                              \
+    {                                                                                               \
+        ncclResult_t r__ = (expr);                                                                  \
+        if (r__ != ncclSuccess && r__ != ncclInProgress)                                            \
+        {                                                                                           \
+            fprintf(stderr, "[crp_rccl] %s:%d %s -> %s\n", __FILE__, __LINE__, #expr, ncclGetErrorString(r__)); \
+            (void) ncclGroupEnd();                                                                  \
+            return -(int) r__ - 1000;                                                               \
+        }                                                                                           \
+    } while (0)
+
+// ncclGroupEnd of a non-blocking communicator: poll until the group has been issued to the stream
+static int group_end(crp_rccl *h)
+{
+    ncclResult_t r = ncclGroupEnd();
+    if (r == ncclInProgress) r = wait_comm(h->comm, 0.0);
+    if (r != ncclSuccess)
+    {
+        fprintf(stderr, "[crp_rccl] ncclGroupEnd -> %s\n", ncclGetErrorString(r));
+        return -(int) r - 1000;
+    }
+    return 0;
+}
 
 extern "C" {
 
@@ -47,23 +112,39 @@ int crp_rccl_create(const void *id, int nranks, int rank, crp_rccl_p *out)
     if (h == NULL) return -3;
     ncclUniqueId u;
     memcpy(&u, id, sizeof(u));
-    ncclResult_t r = ncclCommInitRank(&h->comm, nranks, u, rank);
+    const double t0 = now_s();
+    ncclConfig_t cfg = NCCL_CONFIG_INITIALIZER;
+    cfg.blocking = 0;
+    ncclResult_t r = ncclCommInitRankConfig(&h->comm, nranks, u, rank, &cfg);
+    if ((r == ncclSuccess || r == ncclInProgress) && h->comm != nullptr) r = wait_comm(h->comm, rccl_deadline_s());
     if (r != ncclSuccess)
     {
-        fprintf(stderr, "[crp_rccl] ncclCommInitRank(%d ranks, rank %d) -> %s\n", nranks, rank, ncclGetErrorString(r));
+        fprintf(stderr, "[crp_rccl] ncclCommInitRankConfig(%d ranks, rank %d) -> %s%s\n", nranks, rank, ncclGetErrorString(r),
+                r == ncclInProgress ? " (deadline passed: a peer never arrived)" : "");
+        if (h->comm != nullptr) (void) ncclCommAbort(h->comm);
         delete h;
         return -(int) r - 1000;
     }
     h->nranks = nranks;
     h->rank = rank;
+    h->create_s = now_s() - t0;
     *out = h;
     return 0;
 }
 
+double crp_rccl_create_seconds(crp_rccl_p h) { return h ? h->create_s : -1.0; }
+
 int crp_rccl_destroy(crp_rccl_p *h)
 {
     if (h == NULL || *h == NULL) return 0;
-    if ((*h)->comm) (void) ncclCommDestroy((*h)->comm);
+    if ((*h)->comm)
+    {
+        // (non-blocking communicator: finalize, wait for it, then destroy)
+        ncclResult_t r = ncclCommFinalize((*h)->comm);
+        if (r == ncclSuccess || r == ncclInProgress) r = wait_comm((*h)->comm, rccl_deadline_s());
+        if (r == ncclSuccess) (void) ncclCommDestroy((*h)->comm);
+        else (void) ncclCommAbort((*h)->comm);
+    }
     delete *h;
     *h = NULL;
     return 0;
@@ -92,12 +173,11 @@ int crp_rccl_alltoallv_f64(crp_rccl_p h, const double *send, const long long *sc
     for (int i = 1; i < P; i++)
     {
         const int q = (me + i) % P;         // ring order of the reference's p2p variant (src/rowpara_spmm.c:277-296)
-        if (rc[q] > 0) RCCL_TRY(ncclRecv(recv + rd[q], (size_t) rc[q], ncclDouble, q, h->comm, s));
+        if (rc[q] > 0) RCCL_TRY_IN_GROUP(ncclRecv(recv + rd[q], (size_t) rc[q], ncclDouble, q, h->comm, s));
         const int t = (me - i + P) % P;
-        if (sc[t] > 0) RCCL_TRY(ncclSend(send + sd[t], (size_t) sc[t], ncclDouble, t, h->comm, s));
+        if (sc[t] > 0) RCCL_TRY_IN_GROUP(ncclSend(send + sd[t], (size_t) sc[t], ncclDouble, t, h->comm, s));
     }
-    RCCL_TRY(ncclGroupEnd());
-    return 0;
+    return group_end(h);
 }
 
 int crp_rccl_alltoallv_bytes(crp_rccl_p h, const void *send, const size_t *sc, const size_t *sd, void *recv, const size_t *rc,
@@ -121,11 +201,10 @@ int crp_rccl_alltoallv_bytes(crp_rccl_p h, const void *send, const size_t *sc, c
     for (int i = 1; i < P; i++)
     {
         const int q = (me + i) % P, t = (me - i + P) % P;
-        if (rc[q] > 0) RCCL_TRY(ncclRecv(rb + rd[q], rc[q], ncclChar, q, h->comm, s));
-        if (sc[t] > 0) RCCL_TRY(ncclSend(sb + sd[t], sc[t], ncclChar, t, h->comm, s));
+        if (rc[q] > 0) RCCL_TRY_IN_GROUP(ncclRecv(rb + rd[q], rc[q], ncclChar, q, h->comm, s));
+        if (sc[t] > 0) RCCL_TRY_IN_GROUP(ncclSend(sb + sd[t], sc[t], ncclChar, t, h->comm, s));
     }
-    RCCL_TRY(ncclGroupEnd());
-    return 0;
+    return group_end(h);
 }
 
 int crp_rccl_allgatherv(crp_rccl_p h, const void *send, size_t sbytes, void *recv, const size_t *rbytes, const size_t *rdispls,
@@ -145,11 +224,10 @@ int crp_rccl_allgatherv(crp_rccl_p h, const void *send, size_t sbytes, void *rec
     for (int i = 1; i < P; i++)
     {
         const int q = (me + i) % P, t = (me - i + P) % P;
-        if (rbytes[q] > 0) RCCL_TRY(ncclRecv(rb + rdispls[q], rbytes[q], ncclChar, q, h->comm, s));
-        if (sbytes > 0) RCCL_TRY(ncclSend(send, sbytes, ncclChar, t, h->comm, s));
+        if (rbytes[q] > 0) RCCL_TRY_IN_GROUP(ncclRecv(rb + rdispls[q], rbytes[q], ncclChar, q, h->comm, s));
+        if (sbytes > 0) RCCL_TRY_IN_GROUP(ncclSend(send, sbytes, ncclChar, t, h->comm, s));
     }
-    RCCL_TRY(ncclGroupEnd());
-    return 0;
+    return group_end(h);
 }
 
 void crp_rccl_comm_alltoallv_dev_f64(void *ctx, const double *send, const long long *sc, const long long *sd, double *recv,

@@ -57,6 +57,10 @@ struct Team2Dev
     float    *tval32 = nullptr;    // fp32 copy of the value groups (fp32 path), built on first use
     long long entries = 0, value_entries = 0;
     bool lattice = false;
+    // generation start barrier of the kernel (absolute schedules only): counters [tile][run][generation], never reset
+    unsigned *gsync = nullptr;
+    int gsync_tiles = 0, gsync_ngen = 0, wgs = 64;
+    int nreal[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 struct crp_csr_dev
@@ -265,6 +269,26 @@ static int ensure_team2(crp_csr_dev *A, hipStream_t stream)
     // the kernel requests 256 bytes per wave and round: up to four groups past a wave's last part
     if (e == hipSuccess) e = up((void **) &t.tval, th.tval.data(), sizeof(double) * th.tval.size(), 4096);
     if (e == hipSuccess) e = up((void **) &t.tmap, th.vmap.data(), sizeof(uint32_t) * th.vmap.size(), 4);
+    t.wgs = th.wgs;
+    {
+        const int cpx = t.ngrid / 8;
+        for (int x = 0; x < 8; x++)
+        {
+            int c = 0;
+            for (int i = 0; i < cpx; i++) c += th.tgrid[(size_t) x * cpx + (size_t) i] >= 0;
+            t.nreal[x] = c;
+        }
+        // (off by default: see the measurements at CRPSPMM_T2_ORDER in panel_format.cpp)
+        const bool gsync_on = getenv("CRPSPMM_T2_GSYNC") != NULL && atoi(getenv("CRPSPMM_T2_GSYNC")) != 0;
+        if (e == hipSuccess && th.absolute && gsync_on && cpx > 0)
+        {
+            t.gsync_tiles = 16;                                     // operands up to 4096 fp64 columns; wider ones run without the barrier
+            t.gsync_ngen = (cpx + th.wgs - 1) / th.wgs;
+            const size_t bytes = sizeof(unsigned) * (size_t) t.gsync_tiles * 8 * (size_t) t.gsync_ngen;
+            e = hipMalloc((void **) &t.gsync, bytes);
+            if (e == hipSuccess) e = hipMemset(t.gsync, 0, bytes);
+        }
+    }
     if (e != hipSuccess) return (int) e;
     if (A->host_vals_stale && A->nnz > 0) CRP_TRY(crp::scatter_vals_f64(A->nnz, t.tmap, A->val, t.tval, stream));
     clk.lap("ensure_team2: upload");
@@ -395,6 +419,26 @@ int crp_stream_create(void **stream)
     hipStream_t s;
     CRP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     *stream = (void *) s;
+    return 0;
+}
+int crp_stream_create_cu_mask(void **stream, int nwords, const unsigned *mask32)
+{
+    if (stream == NULL || nwords <= 0 || mask32 == NULL) return -1;
+    hipStream_t s;
+    CRP_TRY(hipExtStreamCreateWithCUMask(&s, (uint32_t) nwords, mask32));
+    *stream = (void *) s;
+    return 0;
+}
+int crp_probe_copy(long long bytes, const void *src, void *dst, int blocks, unsigned long long *stamps, void *stream)
+{
+    if (bytes <= 0 || (bytes & 15) || src == NULL || dst == NULL || stamps == NULL) return -1;
+    CRP_TRY(crp::probe_copy(bytes, src, dst, blocks, stamps, (hipStream_t) stream));
+    return 0;
+}
+int crp_probe_stamp(unsigned long long *out, void *stream)
+{
+    if (out == NULL) return -1;
+    CRP_TRY(crp::probe_stamp(out, (hipStream_t) stream));
     return 0;
 }
 int crp_stream_destroy(void *stream) { if (stream) CRP_TRY(hipStreamDestroy((hipStream_t) stream)); return 0; }
@@ -578,6 +622,7 @@ int crp_csr_dev_destroy(crp_csr_dev_p *A_)
     if (A->team2.tval) (void) hipFree(A->team2.tval);
     if (A->team2.tmap) (void) hipFree(A->team2.tmap);
     if (A->team2.tval32) (void) hipFree(A->team2.tval32);
+    if (A->team2.gsync) (void) hipFree(A->team2.gsync);
     if (A->val32) (void) hipFree(A->val32);
     if (A->rowptr) (void) hipFree(A->rowptr);
     if (A->colidx) (void) hipFree(A->colidx);
@@ -694,6 +739,8 @@ int crp_spmm_csr_f64(crp_csr_dev_p A, int layout, int n, const double *B0, long 
         crp::Team2Args t;
         t.nteam = A->team2.nteam; t.ngrid = A->team2.ngrid; t.tw = A->team2.tw; t.torder = A->team2.torder; t.tpanel = A->team2.tpanel; t.tinfo = A->team2.tinfo;
         t.tpro = A->team2.tpro; t.trec = A->team2.trec; t.tvoff = A->team2.tvoff; t.tval = A->team2.tval; t.tval32 = nullptr;
+        t.gsync = A->team2.gsync; t.gsync_tiles = A->team2.gsync_tiles; t.gsync_ngen = A->team2.gsync_ngen; t.wgs = A->team2.wgs;
+        for (int x = 0; x < 8; x++) t.nreal[x] = A->team2.nreal[x];
         return (int) crp::spmm_rm_f64_team2(t, a, (hipStream_t) stream);
     }
     if (v == 4 && (!crp::spmm_team_applicable(a) || A->b1_rows > 0)) v = 3;   // team kernel: one B source, 256-column tile
@@ -757,6 +804,8 @@ int crp_spmm_csr_f32(crp_csr_dev_p A, int n, const float *B0, long long ldB0, co
     crp::Team2Args t;
     t.nteam = A->team2.nteam; t.ngrid = A->team2.ngrid; t.tw = A->team2.tw; t.torder = A->team2.torder; t.tpanel = A->team2.tpanel; t.tinfo = A->team2.tinfo;
     t.tpro = A->team2.tpro; t.trec = A->team2.trec; t.tvoff = A->team2.tvoff; t.tval = A->team2.tval; t.tval32 = A->team2.tval32;
+    t.gsync = A->team2.gsync; t.gsync_tiles = A->team2.gsync_tiles; t.gsync_ngen = A->team2.gsync_ngen; t.wgs = A->team2.wgs;
+    for (int x = 0; x < 8; x++) t.nreal[x] = A->team2.nreal[x];
     return (int) crp::spmm_rm_f32_team2(t, a, (hipStream_t) stream);
 }
 
@@ -808,7 +857,7 @@ int crp_team_format_host(int nrow, const int *rowptr, const int *colidx, const d
     crp::build_teams(h, nrow, rowptr, colidx, &th);
     *nteam = th.nteam;
     if (lattice) *lattice = th.lattice ? 1 : 0;
-    auto dup_i = [](const std::vector<int> &v) {
+    auto dup_i = [](const auto &v) {
         int *p = (int *) malloc(sizeof(int) * (v.size() + 1));
         if (!v.empty()) memcpy(p, v.data(), sizeof(int) * v.size());
         return p;
@@ -841,11 +890,14 @@ int crp_team2_format_host(int nrow, const int *rowptr, const int *colidx, const 
     if (nrow < 0 || rowptr == NULL || !nteam || !tpanel || !tinfo || !tpro || !trec || !nrecwords || !tvoff || !tval ||
         !nvalent || !torder)
         return -1;
+    crp::PhaseClock clk;
     crp::PanelHost h;
-    crp::build_panels(nrow, rowptr, colidx, val, 8, &h, false);
+    crp::build_panels(nrow, rowptr, colidx, val, 8, &h, false, false);
+    clk.lap("crp_team2_format_host: build_panels (R = 8)");
     crp::Team2Host th;
     th.T = team2_waves();
     crp::build_team2(h, nrow, rowptr, colidx, &th);
+    clk.lap("crp_team2_format_host: build_team2");
     g_last_tgrid = th.tgrid;
     *nteam = th.nteam;
     if (lattice) *lattice = th.lattice ? 1 : 0;

@@ -79,6 +79,12 @@ struct Team2Args          // panel_format.h, Team2Host
     const long long *tvoff;    // 8 * nteam
     const double   *tval;
     const float    *tval32;    // the same value groups in fp32 (fp32 path), or nullptr
+    // generation start barrier (team2_kernel.hip): counters [column tile][XCD run][generation], or nullptr = none
+    unsigned       *gsync;
+    int             gsync_tiles;   // column tiles the counter array covers
+    int             gsync_ngen;    // generations per run it covers
+    int             wgs;           // teams of a generation (workgroups resident on an XCD)
+    int             nreal[8];      // real teams of every run (the -1 entries sit at its end)
 };
 
 // narrow_kernel.hip: row-panel format, n <= 64 (several entries of a panel per instruction)
@@ -111,5 +117,7 @@ hipError_t scatter_vals_f64(int64_t n, const uint32_t *map, const double *src, d
 hipError_t convert_f64_f32(int64_t n, const double *src, float *dst, hipStream_t s);
 hipError_t transpose_f64(int nrow, int ncol, const double *src, int64_t lds, double *dst, int64_t ldd,
                          hipStream_t s);
+hipError_t probe_copy(int64_t bytes, const void *src, void *dst, int blocks, unsigned long long *stamps, hipStream_t s);
+hipError_t probe_stamp(unsigned long long *out, hipStream_t s);
 
 }  // namespace crp

@@ -450,8 +450,11 @@ void locality_order(const PanelHost &p, int group, std::vector<int> *order)
 // nearest index).  Work per group: the union's keys times the items per key.  Items are handled in independent
 // ranges of `span` items (threads), a group never crosses a range.  -> group of every item, in creation order;
 // slot = its position inside the group.
+// ratio = true: the item that has the largest FRACTION of its own keys in the union already (ties: more shared keys) --
+// an item whose keys are a subset of the group's costs the group nothing, however short its list (the 7-point dual
+// rows of a KKT system next to the 27-point primal rows of the same nodes).
 static void greedy_cluster(int n, const std::vector<long long> &iptr, const std::vector<uint32_t> &ikey, int G, int span,
-                           std::vector<int> *group_of, std::vector<int> *slot_of, int *ngroups)
+                           std::vector<int> *group_of, std::vector<int> *slot_of, int *ngroups, bool ratio = false)
 {
     group_of->assign((size_t) n, -1);
     slot_of->assign((size_t) n, 0);
@@ -521,11 +524,20 @@ static void greedy_cluster(int n, const std::vector<long long> &iptr, const std:
                 while (members < G)
                 {
                     int best = -1, bo = 0;
+                    long long bsz = 1;
                     for (int r : touched)
                     {
                         if (assigned[(size_t) r]) continue;
                         const int o = cc[(size_t) r];
-                        if (o > bo || (o == bo && best >= 0 && std::abs(r - seed) < std::abs(best - seed))) { best = r; bo = o; }
+                        if (!ratio)
+                        {
+                            if (o > bo || (o == bo && best >= 0 && std::abs(r - seed) < std::abs(best - seed))) { best = r; bo = o; }
+                            continue;
+                        }
+                        const long long sz = std::max<long long>(1, lptr[(size_t) r + 1] - lptr[(size_t) r]);
+                        // o / sz against bo / bsz
+                        const long long lhs = (long long) o * bsz, rhs = (long long) bo * sz;
+                        if (best < 0 || lhs > rhs || (lhs == rhs && (o > bo || (o == bo && std::abs(r - seed) < std::abs(best - seed))))) { best = r; bo = o; bsz = sz; }
                     }
                     if (best < 0)
                     {
@@ -639,12 +651,51 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
     {
         std::vector<long long> iptr;
         std::vector<uint32_t> ikey;
-        build_key_csr(np, [&](int q, std::vector<uint32_t> &buf) {
+        // The clustering works on ranges of consecutive items: the panels are taken in the order of their MEDIAN column,
+        // so that panels far apart in the row numbering that read the same B rows (the dual rows of a KKT system and the
+        // primal rows of the same nodes) fall into one range; for a mesh numbered along its own lines that is the row order.
+        // Taken when the panels are of two kinds -- at least 15 % of them hold under half the mean number of entries --;
+        // with panels of one size the rule changes nothing but the ties, and the row order is the better seed order
+        // (shell stand-in 0.264 -> 0.275 ms with it, nlpkkt stand-in 2.39 -> 2.12).  CRPSPMM_TEAM2_MIX=0|1 forces.
+        bool mix = false;
+        {
+            long long tot = 0;
+            std::vector<int> rc((size_t) np);
+            for (int q = 0; q < np; q++) { rc[(size_t) q] = real_count(q); tot += rc[(size_t) q]; }
+            long long small = 0;
+            for (int q = 0; q < np; q++) small += (2LL * rc[(size_t) q] * np < tot);
+            mix = small * 100 >= 15LL * np;
+            if (const char *em = getenv("CRPSPMM_TEAM2_MIX")) mix = atoi(em) != 0;
+        }
+        std::vector<int> pord((size_t) np);
+        for (int q = 0; q < np; q++) pord[(size_t) q] = q;
+        if (mix)
+        {
+            std::vector<uint32_t> med((size_t) np, 0);
+            parallel_chunks(np, 4096, [&](long long b, long long e, int) {
+                for (long long q = b; q < e; q++)
+                {
+                    const int e0 = p.pptr[(size_t) q], cnt = real_count((int) q);
+                    med[(size_t) q] = cnt > 0 ? col_key(p.pcol[(size_t) (e0 + cnt / 2)]) : 0xFFFFFFFFu;      // (entries are in column order)
+                }
+            });
+            std::stable_sort(pord.begin(), pord.end(), [&](int x, int y) { return med[(size_t) x] < med[(size_t) y]; });
+        }
+        build_key_csr(np, [&](int i, std::vector<uint32_t> &buf) {
+            const int q = pord[(size_t) i];
             const int e0 = p.pptr[q], e1 = e0 + real_count(q);
             for (int e = e0; e < e1; e++) buf.push_back(col_key(p.pcol[(size_t) e]));
         }, &iptr, &ikey);
         int ng = 0;
-        greedy_cluster(np, iptr, ikey, T, 1 << 15, &team_of, &slot_of, &ng);
+        {
+            std::vector<int> tof, sof;
+            greedy_cluster(np, iptr, ikey, T, 1 << 15, &tof, &sof, &ng, mix);
+            team_of.assign((size_t) np, 0);
+            slot_of.assign((size_t) np, 0);
+            for (int i = 0; i < np; i++) { team_of[(size_t) pord[(size_t) i]] = tof[(size_t) i]; slot_of[(size_t) pord[(size_t) i]] = sof[(size_t) i]; }
+        }
+        std::vector<int> pos_of((size_t) np);                 // panel -> its item in the key CSR
+        for (int i = 0; i < np; i++) pos_of[(size_t) pord[(size_t) i]] = i;
         if (lattice)
         {
             // A lattice has both: its tooth-shaped teams sweep in lockstep along the teeth and re-fetch less (pwtk
@@ -668,7 +719,7 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
                         keys.clear();
                         for (size_t t = gs[(size_t) g]; t < gs[(size_t) g + 1]; t++)
                         {
-                            const int q = ord[t].second;
+                            const int q = pos_of[(size_t) ord[t].second];
                             keys.insert(keys.end(), ikey.begin() + (long) iptr[(size_t) q], ikey.begin() + (long) iptr[(size_t) q + 1]);
                         }
                         std::sort(keys.begin(), keys.end());
@@ -854,30 +905,40 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
     }
     out->real_entries = real;
     const size_t total = (size_t) out->tptr[(size_t) nteam];
-    out->tcol.assign(total, 0);
-    out->tmask.assign(total, 0u);
-    for (int g = 0; g < nteam; g++)
-    {
-        size_t q = (size_t) out->tptr[(size_t) g];
-        int last = 0;
-        for (size_t t = 0; t < ucol[(size_t) g].size(); t++, q++)
+    // (filled by all threads: these arrays hold gigabytes on the nlpkkt240-size matrix, and the serial version of this stage
+    //  was the longest single piece of its format build)
+    out->tcol.resize(total);
+    out->tmask.resize(total);
+    out->tsrc.resize(total * (size_t) T);
+    parallel_chunks(nteam, 256, [&](long long b, long long e, int) {
+        for (long long g = b; g < e; g++)
         {
-            out->tcol[q] = ucol[(size_t) g][t];
-            out->tmask[q] = umask[(size_t) g][t];
-            last = out->tcol[q];
+            size_t q = (size_t) out->tptr[(size_t) g];
+            int last = 0;
+            for (size_t t = 0; t < ucol[(size_t) g].size(); t++, q++)
+            {
+                out->tcol[q] = ucol[(size_t) g][t];
+                out->tmask[q] = umask[(size_t) g][t];
+                last = out->tcol[q];
+            }
+            int *ts = &out->tsrc[(size_t) out->tptr[(size_t) g] * T];
+            if (!usrc[(size_t) g].empty()) memcpy(ts, usrc[(size_t) g].data(), sizeof(int) * usrc[(size_t) g].size());
+            for (; q < (size_t) out->tptr[(size_t) g + 1]; q++)
+            {
+                out->tcol[q] = last;      // padding: valid row, no reader
+                out->tmask[q] = 0u;
+                for (int w = 0; w < T; w++) out->tsrc[q * (size_t) T + (size_t) w] = -1;
+            }
         }
-        for (; q < (size_t) out->tptr[(size_t) g + 1]; q++) out->tcol[q] = last;      // padding: valid row, no reader
-    }
-
-    out->tsrc.assign(total * (size_t) T, -1);
-    for (int g = 0; g < nteam; g++)
-        memcpy(&out->tsrc[(size_t) out->tptr[(size_t) g] * T], usrc[(size_t) g].data(), sizeof(int) * usrc[(size_t) g].size());
+    });
 
     // value streams: wave w of team g reads 8 values per own entry from tvoff[4g + w] on, in the
-    // order it meets its entries; tq = where every entry of the panel format went
+    // order it meets its entries; tq = where every entry of the panel format went (teams of 4 / 6 only: the team2 streams
+    // of build_team2 have their own)
     out->tvoff.assign((size_t) nteam * T + 1, 0);
-    out->tq.assign(p.pcol.size(), -1);
+    if (T < 8)
     {
+        out->tq.assign(p.pcol.size(), -1);
         long long run = 0;
         for (int g = 0; g < nteam; g++)
             for (int w = 0; w < T; w++)
@@ -899,9 +960,15 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
     out->torder.resize((size_t) nteam);
     for (int g = 0; g < nteam; g++) out->torder[(size_t) g] = g;
     // Teams of eight and more (the LDS-sharing kernel): recursive bisection of the team graph (team_order.h) -- two teams
-    // are adjacent when one reads a B row whose row of A the other owns, weight = such rows.  CRPSPMM_T2_ORDER=legacy keeps
-    // the round-2 orders (lattice: strips of team columns swept along the teeth; clusters: greedy super-teams in slab order).
-    static const bool legacy_order = getenv("CRPSPMM_T2_ORDER") != NULL && strcmp(getenv("CRPSPMM_T2_ORDER"), "legacy") == 0;
+    // are adjacent when one reads a B row whose row of A the other owns, weight = such rows.  The other orders (lattice:
+    // strips of team columns swept along the teeth; clusters: greedy super-teams in slab order) are below.
+    // Measured (MI355X, profiles/r03_schedule_matrix.txt): with the generation-wide absolute rounds and the kernel's generation
+    // barrier the bisection order cuts the bytes fetched beyond L2 as the L2 model predicts (nlpkkt stand-in 10.3 -> 7.9 GB,
+    // pwtk stand-in 0.99 -> 0.94 GB) but the slots that wait for their generation cost more time than the bytes save
+    // (+13 % / +33 %); without the barrier the slots' chains of teams drift apart within a few generations and the alignment
+    // the schedule needs is gone (bytes -6 % / +8 %, time -2 % / +4 %).  So the round-2 orders stay the default and
+    // CRPSPMM_T2_ORDER=bisect selects this one.
+    const bool legacy_order = getenv("CRPSPMM_T2_ORDER") == NULL || strcmp(getenv("CRPSPMM_T2_ORDER"), "bisect") != 0;
     out->bisected = false;
     if (T >= 8 && !legacy_order && nteam >= 2 * (T == 16 ? 32 : 64))
     {
@@ -1160,6 +1227,9 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
     // every node (absolute schedule: a round takes only nodes whose target has come, and stays partly or wholly empty
     // otherwise); <= T slots per round, <= CAP parts per wave and round, look-ahead 4 T nodes.
     // Empty slots carry TEAM2_NOCOL: the kernel fetches nothing for them.
+    // CRPSPMM_T2_AHEAD: rounds a team may take a node before its target (fills the slots its own share of a round leaves
+    // empty; a line survives about four rounds in L2, so one round of slack costs no hit)
+    const int ahead = getenv("CRPSPMM_T2_AHEAD") ? atoi(getenv("CRPSPMM_T2_AHEAD")) : 1;
     auto schedule_team = [&](int g, const std::vector<int> &nodes, const int *target) {
         TeamOut &to = res[(size_t) g];
         to.anycol = nodes.empty() ? 0 : th.tcol[(size_t) nodes[0]];
@@ -1179,7 +1249,7 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
             for (size_t t = head; t < nodes.size() && nslot < T && seen < 4 * T; t++)
             {
                 if (taken[t]) continue;
-                if (target != nullptr && target[t] > to.nr) break;         // (targets ascend with t)
+                if (target != nullptr && target[t] > to.nr + ahead) break;         // (targets ascend with t)
                 seen++;
                 const int q = nodes[t];
                 Part tmp[TMAX][4];
@@ -1216,8 +1286,10 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
     // team), one per XCD -- pieces of equal team COUNT leave XCDs idle when the teams differ (KKT systems: 27-point primal
     // rows, short dual rows).  Under the bisection order the cuts fall on multiples of a generation.
     const int WGS = T == 16 ? 32 : 64;                                  // workgroups resident on an XCD = a generation
-    static const bool abs_env = getenv("CRPSPMM_T2_ABS") == NULL || atoi(getenv("CRPSPMM_T2_ABS")) != 0;
+    const bool abs_env = getenv("CRPSPMM_T2_ABS") == NULL || atoi(getenv("CRPSPMM_T2_ABS")) != 0;
     const bool absolute = th.bisected && abs_env && phase;
+    out->absolute = absolute;
+    out->wgs = WGS;
     std::vector<int> cut(9, nteam);
     {
         std::vector<int> nn((size_t) nteam, 0);
@@ -1273,16 +1345,22 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
                 nodes.assign((size_t) G.count, std::vector<int>());
                 all.clear();
                 int R = 1;
+                long long rsum = 0;
                 for (int i = 0; i < G.count; i++)
                 {
                     const int g = out->torder[(size_t) (G.first + i)];
                     team_nodes(g, nodes[(size_t) i]);
+                    rsum += ((long long) nodes[(size_t) i].size() + T - 1) / T;
                     R = std::max(R, ((int) nodes[(size_t) i].size() + T - 1) / T);
                     for (int q : nodes[(size_t) i]) all.push_back({((uint64_t) (uint32_t) key(q) << 32) | (uint64_t) col_key(th.tcol[(size_t) q]), 0});
                 }
                 std::sort(all.begin(), all.end());
                 all.erase(std::unique(all.begin(), all.end()), all.end());
                 const size_t U = all.size();
+                // rounds of the generation: what its mean team needs plus a margin, not what its largest needs -- a few
+                // large teams would make every other team idle; they run past R instead, late only in their own tail
+                const int rgen_pct = getenv("CRPSPMM_T2_RGEN") ? atoi(getenv("CRPSPMM_T2_RGEN")) : 8;
+                if (rgen_pct > 0) R = std::max(1, std::min(R, (int) ((rsum * (100 + rgen_pct) + 100LL * G.count - 1) / (100LL * G.count))));
                 for (int i = 0; i < G.count; i++)
                 {
                     const int g = out->torder[(size_t) (G.first + i)];

@@ -103,12 +103,12 @@ struct TeamHost
     std::vector<int>      plocal;
     std::vector<int>      tpanel;  // T * nteam: panel of wave w, or -1
     std::vector<int>      tptr;    // nteam + 1: union entry offsets (multiples of PANEL_PAD)
-    std::vector<int>      tcol;    // union entries: column index
-    std::vector<uint32_t> tmask;   // union entries: row masks of waves 0..3 (complete for T = 4 only)
+    big_vector<int>       tcol;    // union entries: column index
+    big_vector<uint32_t>  tmask;   // union entries: row masks of waves 0..3 (complete for T = 4 only)
     std::vector<int>      torder;  // processing order of the teams
     std::vector<long long> tvoff;  // T * nteam + 1: first entry of wave w's value stream
     std::vector<long long> tq;     // per panel-format entry: its entry index in the value streams, or -1
-    std::vector<int>      tsrc;    // T per union entry: the panel-format entry of wave w behind it, or -1
+    big_vector<int>       tsrc;    // T per union entry: the panel-format entry of wave w behind it, or -1
     long long real_entries = 0;    // union entries before padding
     bool bisected = false;         // torder = recursive bisection of the team graph (team_order.h): a generation = 64 (T = 16: 32) consecutive teams
 };
@@ -160,6 +160,8 @@ struct Team2Host
     std::vector<long long> tvoff;    // 8 * nteam + 1: first value group of wave w's stream
     big_vector<double>     tval;     // value groups (8 doubles each)
     std::vector<uint32_t>  vmap;     // per CSR nonzero (panel format's own order of pmap): its slot in tval
+    bool absolute = false;           // rounds are generation-wide absolute rounds (build_team2): the kernel's generation barrier applies
+    int wgs = 64;                    // teams of a generation: the workgroups resident on an XCD (T = 16: 32)
     long long real_entries = 0;      // union entries (filled slots)
     long long slots = 0;             // slots including the empty ones of partly filled rounds
     long long parts = 0;

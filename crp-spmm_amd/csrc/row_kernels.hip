@@ -167,4 +167,31 @@ hipError_t convert_f64_f32(int64_t n, const double *src, float *dst, hipStream_t
     return hipGetLastError();
 }
 
+// ---- exchange-overlap probe (tools/overlap_probe.py; SURVEY 8(e): does a transfer kernel make progress beside the product?)
+// A stand-in for the transport's copy kernels: `blocks` workgroups of 256 threads copy n16 16-byte words and stamp the
+// 100 MHz wall clock: stamps[0] = the earliest start of a workgroup, stamps[1] = the latest end.
+__global__ __launch_bounds__(256) void probe_copy_kernel(const int64_t n16, const uint4 *__restrict__ src, uint4 *__restrict__ dst,
+                                                          unsigned long long *__restrict__ stamps)
+{
+    if (threadIdx.x == 0) atomicMin(&stamps[0], (unsigned long long) wall_clock64());
+    for (int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t) gridDim.x * 256) dst[i] = src[i];
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(&stamps[1], (unsigned long long) wall_clock64());
+}
+
+__global__ void probe_stamp_kernel(unsigned long long *__restrict__ out) { *out = (unsigned long long) wall_clock64(); }
+
+hipError_t probe_copy(int64_t bytes, const void *src, void *dst, int blocks, unsigned long long *stamps, hipStream_t s)
+{
+    if (bytes <= 0 || blocks <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(probe_copy_kernel, dim3(blocks), dim3(256), 0, s, bytes / 16, (const uint4 *) src, (uint4 *) dst, stamps);
+    return hipGetLastError();
+}
+
+hipError_t probe_stamp(unsigned long long *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(probe_stamp_kernel, dim3(1), dim3(1), 0, s, out);
+    return hipGetLastError();
+}
+
 }  // namespace crp

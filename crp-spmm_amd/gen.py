@@ -105,17 +105,21 @@ def kkt3d(g, seed=3):
     return _stencil_csr(2 * N, [(0, g, 1, 0, 1, _OFF27), (0, g, 1, N, 1, _OFF7), (N, g, 1, 0, 1, _OFF7)], seed)
 
 
-def kkt3d_big(g, seed=3, chunk=1 << 21):
+_OFF13 = _OFF7 + [(1, 1, 0), (-1, -1, 0), (1, -1, 0), (-1, 1, 0), (0, 1, 1), (0, -1, -1)]
+
+
+def kkt3d_big(g, seed=3, chunk=1 << 21, coupling=None):
     """The same matrix as kkt3d(g), built without a global sort (kkt3d(241), the nlpkkt240-size stand-in, has 574 M
     nonzeros): the stencil offsets are taken in ascending linear order, so every row's columns come out ascending and
     the CSR is written chunk by chunk.  -> (rowptr int32, colidx int32, val float64); identical to kkt3d(g)."""
     N = g * g * g
-    assert 41 * N < 2 ** 31, "nnz must fit the int32 row pointer of the reference's CSR"
+    assert (27 + 2 * (7 if coupling is None else len(coupling))) * N < 2 ** 31, "nnz must fit the int32 row pointer of the reference's CSR"
 
     def offs(pattern):
         o = sorted(pattern, key=lambda d: d[0] + g * d[1] + g * g * d[2])
         return np.array(o, dtype=np.int64)
-    o27, o7 = offs(_OFF27), offs(_OFF7)
+    # coupling = the stencil of J (default 7 points: 20.4 nonzeros per row; _OFF13: 26.5, the density of nlpkkt240 -- SURVEY 8d)
+    o27, o7 = offs(_OFF27), offs(_OFF7 if coupling is None else coupling)
     lin27 = o27[:, 0] + g * o27[:, 1] + g * g * o27[:, 2]
     lin7 = o7[:, 0] + g * o7[:, 1] + g * g * o7[:, 2]
     rowptr = np.zeros(2 * N + 1, dtype=np.int64)
@@ -146,6 +150,36 @@ def kkt3d_big(g, seed=3, chunk=1 << 21):
     for n0 in range(0, N, chunk):
         nodes = np.arange(n0, min(N, n0 + chunk), dtype=np.int64)
         block(N + n0, nodes, [(o7, lin7, 0)])                              # [J  0]
+    return np.cumsum(rowptr).astype(np.int32), np.concatenate(cols_parts), np.concatenate(vals_parts)
+
+
+def fem3d_big(g, dof=3, seed=5, chunk=1 << 18):
+    """The same matrix as fem3d(g, dof), written chunk by chunk without a global sort (fem3d_big(111) is the Queen_4147-size
+    stand-in: 4,102,893 rows, ~327 M nonzeros): neighbour offsets in ascending linear order and unknowns in ascending
+    order give ascending columns.  -> (rowptr int32, colidx int32, val float64); identical to fem3d(g, dof)."""
+    N = g * g * g
+    o = np.array(sorted(_OFF27, key=lambda d: d[0] + g * d[1] + g * g * d[2]), dtype=np.int64)
+    lin = o[:, 0] + g * o[:, 1] + g * g * o[:, 2]
+    assert 27 * dof * dof * N < 2 ** 31, "nnz must fit the int32 row pointer of the reference's CSR"
+    rowptr = np.zeros(dof * N + 1, dtype=np.int64)
+    cols_parts, vals_parts = [], []
+    b = np.arange(dof, dtype=np.int64)
+    for n0 in range(0, N, chunk):
+        nodes = np.arange(n0, min(N, n0 + chunk), dtype=np.int64)
+        x, y, z = nodes % g, (nodes // g) % g, nodes // (g * g)
+        ok = ((x[:, None] + o[None, :, 0] >= 0) & (x[:, None] + o[None, :, 0] < g) & (y[:, None] + o[None, :, 1] >= 0) &
+              (y[:, None] + o[None, :, 1] < g) & (z[:, None] + o[None, :, 2] >= 0) & (z[:, None] + o[None, :, 2] < g))     # [node, offset]
+        nb = nodes[:, None] + lin[None, :]
+        cnt = ok.sum(axis=1) * dof                                        # nonzeros of every row of the node
+        rowptr[n0 * dof + 1:(n0 + nodes.size) * dof + 1] = np.repeat(cnt, dof)
+        # [node, a, offset, b] -> rows node*dof + a, cols nb*dof + b
+        okf = np.broadcast_to(ok[:, None, :, None], (nodes.size, dof, 27, dof))
+        rows = np.broadcast_to((nodes[:, None, None, None] * dof + b[None, :, None, None]), okf.shape)[okf]
+        cols = np.broadcast_to((nb[:, None, :, None] * dof + b[None, None, None, :]), okf.shape)[okf]
+        lo, hi = np.minimum(rows, cols), np.maximum(rows, cols)
+        u = _u01(lo * np.int64(1 << 26) + hi, seed)
+        cols_parts.append(cols.astype(np.int32))
+        vals_parts.append(np.where(rows == cols, 40.0 + u, 2.0 * u - 1.0))
     return np.cumsum(rowptr).astype(np.int32), np.concatenate(cols_parts), np.concatenate(vals_parts)
 
 

@@ -27,8 +27,13 @@ typedef struct crp_rccl *crp_rccl_p;
 
 /* rank 0: a fresh unique id (CRP_RCCL_ID_BYTES bytes) to hand to every rank */
 int crp_rccl_get_unique_id(void *id);
-/* collective: every rank passes the same id, its rank and the HIP device it has current */
+/* collective: every rank passes the same id, its rank and the HIP device it has current.  The communicator is created
+ * non-blocking and polled under a deadline (CRPSPMM_RCCL_TIMEOUT seconds, default 120): when a peer fails before or inside
+ * its own call, the others return an error instead of staying inside ncclCommInitRank, and the caller's control plane can
+ * agree on a fallback.  Replaces the MPI_Comm_split of /root/reference/src/para2d_spmm.c:41-43 for device payloads. */
 int crp_rccl_create(const void *id, int nranks, int rank, crp_rccl_p *out);
+/* wall time crp_rccl_create() took on this rank (reported by bench.py) */
+double crp_rccl_create_seconds(crp_rccl_p h);
 int crp_rccl_destroy(crp_rccl_p *h);
 int crp_rccl_nranks(crp_rccl_p h);
 int crp_rccl_rank(crp_rccl_p h);

@@ -217,6 +217,15 @@ int crp_scatter_rows_f64(int layout, int nidx, int n, const int *ridx,
 int crp_transpose_f64(int nrow, int ncol, const double *src, long long lds,
                       double *dst, long long ldd, void *stream);
 
+/* Diagnostics for the exchange / compute overlap (tools/overlap_probe.py): a stand-in for a transport's copy kernel --
+ * `blocks` workgroups of 256 threads copy `bytes` (a multiple of 16) between device buffers and record the 100 MHz device
+ * wall clock: stamps_dev[0] = earliest workgroup start (initialise to ~0), stamps_dev[1] = latest end (initialise to 0);
+ * crp_probe_stamp writes the clock to *out_dev from a one-thread kernel.  crp_stream_create_cu_mask creates a stream whose
+ * kernels run only on the compute units whose bit is set in mask32 (words of 32 CUs; hipExtStreamCreateWithCUMask). */
+int crp_probe_copy(long long bytes, const void *src_dev, void *dst_dev, int blocks, unsigned long long *stamps_dev, void *stream);
+int crp_probe_stamp(unsigned long long *out_dev, void *stream);
+int crp_stream_create_cu_mask(void **stream, int nwords, const unsigned *mask32);
+
 /* Library identification: "crpspmm-hip <version> gfx950". */
 const char *crp_hip_version(void);
 

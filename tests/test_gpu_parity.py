@@ -673,6 +673,92 @@ def test_update_values_device_pointer_before_first_product(crp, orc, gpu, monkey
         A.free()
 
 
+@pytest.mark.parametrize("n", [128, 512])
+def test_grid_2x4_rankwise(crp, orc, gpu, n):
+    """BASELINE configs[2] (nlpkkt240, n = 128, 2 x 4 grid on 8 GPUs) on the HIP path without eight processes on one
+    card: for each of the 8 ranks of a forced 2 x 4 grid on the nlpkkt stand-in kkt3d(20) the test builds what
+    para2d_spmm_init leaves on that rank (/root/reference/src/para2d_spmm.c:20-127: the replicated row panel of its grid
+    row, its n / 4 columns of B, the B rows it needs from the other grid row in owner-then-row order), assembles the
+    receive buffer on the host, runs crp_spmm_csr_f64 with the two-source column index on the GPU and compares the C
+    block with the oracle.  n = 128 gives the narrow-operand kernels (n_local = 32), n = 512 the team kernel with a
+    second B source (n_local = 128)."""
+    import torch
+    from crp_spmm_amd import gen, hip, planner
+    rp, ci, va = gen.kkt3d(20)
+    m = k = len(rp) - 1
+    B = np.random.default_rng(5).normal(size=(k, n))
+    C_ref = orc.spmm_csr(rp, ci, va, B)
+    P, pm, pn = 8, 2, 4
+    rb = planner.csr_mat_row_partition(rp, P)
+    ac = np.array([rb[i * pn] for i in range(pm + 1)], dtype=np.int64)       # (src/spmat_part.c:169-202 for a forced grid)
+    bc = planner.even_displs(n, pn)
+    for rank in range(P):
+        pi, pj = rank // pn, rank % pn
+        lo, hi = int(ac[pi]), int(ac[pi + 1])
+        c0, c1 = int(bc[pj]), int(bc[pj + 1])
+        prp = (rp[lo:hi + 1] - rp[lo]).astype(np.int32)
+        pci = ci[rp[lo]:rp[hi]].astype(np.int64)
+        pva = np.ascontiguousarray(va[rp[lo]:rp[hi]])
+        local = (pci >= lo) & (pci < hi)
+        remote = np.unique(pci[~local])                   # ascending global row = by owner, then by row
+        assert remote.size > 0                            # the KKT coupling crosses the two grid rows
+        two = np.empty(pci.size, dtype=np.int32)
+        two[local] = (pci[local] - lo).astype(np.int32)
+        two[~local] = ~np.searchsorted(remote, pci[~local]).astype(np.int32)
+        B0 = _t(B[lo:hi, c0:c1], gpu)
+        B1 = _t(B[remote][:, c0:c1], gpu)                 # the receive buffer, rows in final position
+        A = hip.CsrDev(hi - lo, hi - lo, prp, two, pva)
+        for variant in (0, 1, 3, 5):
+            Cd = torch.full((hi - lo, c1 - c0), float("nan"), dtype=torch.float64, device=gpu)
+            hip.spmm_csr(A, B0, Cd, n=c1 - c0, B1=B1, variant=variant)
+            torch.cuda.synchronize()
+            assert orc.rel_fro_err(C_ref[lo:hi, c0:c1], Cd.cpu().numpy()) <= FP64_TOL, (rank, variant)
+        A.free()
+
+
+@pytest.mark.parametrize("gsync", ["0", "1"])
+def test_team2_bisection_order_absolute_rounds(crp, orc, gpu, monkeypatch, gsync):
+    """CRPSPMM_T2_ORDER=bisect: recursive-bisection team order, generation-wide absolute rounds (rounds with empty
+    slots: row DMAs with EXEC = 0, NOVAL records), with and without the kernel's generation start barrier
+    (CRPSPMM_T2_GSYNC=1; bounded wait) -- on the nlpkkt stand-in (mixed primal / dual teams), a stride-lattice matrix
+    and with a second B source.  Same product as every other variant."""
+    import torch
+    from crp_spmm_amd import gen, hip
+    monkeypatch.setenv("CRPSPMM_T2_ORDER", "bisect")
+    monkeypatch.setenv("CRPSPMM_T2_GSYNC", gsync)
+    offs = tuple(range(1, 15)) + tuple(range(304, 310)) + tuple(range(3040, 3046))
+    for name, (rp, ci, va) in (("kkt", gen.kkt3d(24)), ("lattice", gen.banded_fem(9120 * 2, offsets=offs, seed=3))):
+        m = len(rp) - 1
+        for n in (256, 136):
+            B = np.random.default_rng(3).normal(size=(m, n))
+            ref = orc.spmm_csr(rp, ci, va, B)
+            A = hip.CsrDev(m, m, rp, ci, va)
+            Bd = _t(B, gpu)
+            for rep in range(3):                      # (the barrier's counters carry over from launch to launch)
+                Cd = torch.full((m, n), float("nan"), dtype=torch.float64, device=gpu)
+                hip.spmm_csr(A, Bd, Cd, n=n, variant=5)
+                torch.cuda.synchronize()
+                assert orc.rel_fro_err(ref, Cd.cpu().numpy()) <= FP64_TOL, (name, n, rep)
+            Cf = torch.empty((m, n), dtype=torch.float32, device=gpu)
+            hip.spmm_csr_f32(A, Bd.to(torch.float32), Cf, n=n, variant=5)
+            torch.cuda.synchronize()
+            assert orc.rel_fro_err(ref, Cf.cpu().numpy().astype(np.float64)) <= 1e-5, (name, n)
+            A.free()
+    # two-source index: the upper half of the columns comes from a receive buffer
+    rp, ci, va = gen.kkt3d(24)
+    m = len(rp) - 1
+    half = m // 2
+    two = np.where(ci < half, ci, ~(ci - half)).astype(np.int32)
+    B = np.random.default_rng(4).normal(size=(m, 256))
+    ref = orc.spmm_csr(rp, ci, va, B)
+    A = hip.CsrDev(m, half, rp, two, va)
+    Cd = torch.full((m, 256), float("nan"), dtype=torch.float64, device=gpu)
+    hip.spmm_csr(A, _t(B[:half], gpu), Cd, n=256, B1=_t(B[half:], gpu), variant=5)
+    torch.cuda.synchronize()
+    assert orc.rel_fro_err(ref, Cd.cpu().numpy()) <= FP64_TOL
+    A.free()
+
+
 FP32_TOL = 1e-5      # fp32 path vs the fp64 oracle: relative Frobenius error (there is no fp32 reference: src/rowpara_spmm.h:28)
 
 

@@ -673,11 +673,15 @@ def _replay_team2(t, m, B, va=None):
     return C_out
 
 
-def test_team2_streams_replay(crp, orc):
+@pytest.mark.parametrize("order", ["default", "bisect"])
+def test_team2_streams_replay(crp, orc, monkeypatch, order):
     """The streams of the LDS-sharing kernel (variant 5), replayed in numpy: every row is produced once and
     equals the oracle's product -- for a stride-lattice matrix (teams of 4 x 2 teeth), a random matrix (8
     consecutive panels per team; duplicates, empty rows), and sizes that leave ragged last panels / teams."""
     from crp_spmm_amd import gen, hip
+    if order == "bisect":
+        # the recursive-bisection team order with generation-wide absolute rounds (rounds with empty slots, NOVAL records)
+        monkeypatch.setenv("CRPSPMM_T2_ORDER", "bisect")
     rng = np.random.default_rng(2)
     cases = []
     # pwtk-like bands (a near band of 14, two far bands of 6): the tooth-shaped lattice teams are kept
