@@ -190,16 +190,17 @@ def cpu_baseline(rp, ci, va, k, n, budget_s=20.0):
                       % (m, len(ci), n, reps, dt)}
 
 
-def measured_traffic(matrix, data, n, world, kernel_name):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r02_traffic.json: 2 x FETCH_SIZE +
+def measured_traffic(matrix, data, n, world, kernel_name, dtype="f64"):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r03_traffic.json: 2 x FETCH_SIZE +
     WRITE_SIZE, gfx950 correction applied; tools/prof_pmc.sh) -- a pointer to that run, not a measurement of this one:
-    returned only for the configuration and kernel it was taken on, with its source; (None, None) otherwise."""
+    returned only for the configuration, dtype and kernel it was taken on, with its source; (None, None) otherwise."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r03_traffic.json")) as f:
             t = json.load(f)
         for e in t["entries"]:
-            if world == 1 and data == "synthetic" and e["matrix"] == matrix and e["n"] == n and e["kernel"] == kernel_name:
-                return float(e["traffic_bytes_per_launch"]), "profiles/r02_traffic.json: %s" % e["source"]
+            if world == 1 and data == "synthetic" and e["matrix"] == matrix and e["n"] == n and e["kernel"] == kernel_name and \
+               e.get("dtype", "f64") == dtype:
+                return float(e["traffic_bytes_per_launch"]), "profiles/r03_traffic.json: %s" % e["source"]
     except Exception:
         pass
     return None, None
@@ -267,11 +268,13 @@ def measure_f32(args, matrix, mtx, steps, lib, torch, dev):
     ki = {"variant": rv, "variant_name": vname, "reordered": bool(lib.crp_csr_dev_reordered(A.handle)), "lattice": bool(lib.crp_csr_dev_lattice(A.handle))}
     free_b, total_b = torch.cuda.mem_get_info()
     A.free()
+    f32_traffic = measured_traffic(matrix, data, n, 1, vname, dtype="f32")
     return {"hbm_in_use_GB": (total_b - free_b) / 1e9, "label": label, "data": data, "rows": m, "nnz": nnz, "n": n, "grid": "1x1",
             "value": 2.0 * nnz * n * steps / elapsed / 1e9, "ms_per_step": elapsed / steps * 1e3, "kern_ms": kern_ms, "alg_bytes": alg,
             "achieved": alg / (kern_ms * 1e-3) / 1e9, "kernel_info": ki,
             "kernel": {"team2-R8": "crp::spmm_team2_kernel<float,NV,HAS_B1>", "csr-rowgroup": "crp::spmm_rm_f32_kernel<LPR,VW>"}.get(vname, vname),
-            "traffic": None, "traffic_source": None, "first_exec_s": None, "check_rel_err": err}
+            "traffic": f32_traffic[0], "traffic_source": f32_traffic[1], "first_exec_s": None, "check_rel_err": err,
+            "step_ms_min": float(np.min(per_step)), "step_ms_max": float(np.max(per_step))}
 
 
 def measure(args, matrix, mtx, steps, lib, torch, dist, comm, dev, world, rank, with_cpu):
@@ -439,8 +442,26 @@ def measure(args, matrix, mtx, steps, lib, torch, dist, comm, dev, world, rank, 
         "achieved": achieved, "kernel_info": ki, "kernel": kname, "traffic": traffic, "traffic_source": tsrc,
         "first_exec_s": t_first, "check_rel_err": err,
     }
+    res["step_ms_min"], res["step_ms_max"] = float(np.min(per_step)), float(np.max(per_step))
+    res["host_pointer_exec_ms"] = None
+    if not distributed and args.host_exec and (c_r1 - c_r0) * n_loc <= (1 << 28):
+        # the reference's own calling convention: B and C are HOST arrays (src/rowpara_spmm.h:69-81); the engine stages
+        # them over PCIe.  One warm call, then the mean of three -- reported beside the device-resident rate, never as `value`.
+        Bh = B.cpu().numpy()
+        Ch = np.empty((c_r1 - c_r0, n_loc))
+        eng.exec(0, Bh, Ch)
+        t_h = time.perf_counter()
+        for _ in range(3):
+            eng.exec(0, Bh, Ch)
+        res["host_pointer_exec_ms"] = (time.perf_counter() - t_h) / 3 * 1e3
+        del Bh, Ch
     if with_cpu:
         res["cpu_baseline"] = cpu_baseline(rp, ci, va, k, n)
+    if distributed:
+        # every native RCCL communicator this rank holds (world, grid row, grid column): ranks and creation time
+        from crp_spmm_amd import comm as crp_comm
+        res["rccl"] = [{"ranks": c.device_ranks(), "create_s": c.device_create_seconds()} for c in list(crp_comm._live.values())
+                       if hasattr(c, "device_ranks")]
     eng.free()
     del B, Cmat
     torch.cuda.empty_cache()
@@ -462,6 +483,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the irregular pwtk-class stand-in of the default run")
     ap.add_argument("--check", type=int, default=1)
+    ap.add_argument("--host-exec", type=int, default=1, help="also time rp_spmm_exec with host B / C (config.host_pointer_exec_ms)")
     ap.add_argument("--sweep-variants", action="store_true", help="also time the other kernel variants (stderr)")
     args = ap.parse_args()
 
@@ -483,6 +505,7 @@ def main():
     dev = torch.device("cuda", torch.cuda.current_device())
     distributed = world > 1
     rccl_ranks = None
+    rccl_info = None
     if distributed:
         crp_comm.init_process_group(device=dev.index)
         comm = crp_comm.TorchComm()
@@ -499,6 +522,7 @@ def main():
     else:
         main_res = measure(args, args.matrix, mtx, args.steps, lib, torch, dist, comm, dev, world, rank,
                            with_cpu=(rank == 0 and world == 1 and not args.no_cpu_baseline))
+    rccl_info = main_res.get("rccl")
     also = None
     if world == 1 and mtx is None and args.matrix == "pwtk" and args.variant == 0 and not args.no_also:
         r2 = measure(args, "pwtk_shell", None, min(args.steps, 100), lib, torch, dist, comm, dev, world, rank, with_cpu=False)
@@ -519,7 +543,9 @@ def main():
                    "rows": r["rows"], "nnz": r["nnz"], "n": r["n"], "grid": r["grid"], "kernel_variant": args.variant,
                    "kernel_variant_resolved": r["kernel_info"]["variant_name"],
                    "locality_order": r["kernel_info"]["reordered"], "lattice_detected": r["kernel_info"]["lattice"],
-                   "rccl_ranks": rccl_ranks, "first_exec_s": r["first_exec_s"], "hbm_in_use_GB": r["hbm_in_use_GB"], "check_rel_err": r["check_rel_err"],
+                   "rccl_ranks": rccl_ranks, "rccl": rccl_info, "first_exec_s": r["first_exec_s"],
+                   "step_ms_min": r.get("step_ms_min"), "step_ms_max": r.get("step_ms_max"),
+                   "host_pointer_exec_ms": r.get("host_pointer_exec_ms"), "hbm_in_use_GB": r["hbm_in_use_GB"], "check_rel_err": r["check_rel_err"],
                    "achieved_hbm_GBs_alg": r["alg_bytes"] / (r["ms_per_step"] * 1e-3) / 1e9 if not distributed else None,
                    "also": also},
         "roofline": {"bound": "hbm", "achieved": r["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -144,6 +144,7 @@ SIGNATURES = {
     "crp_probe_stamp": (_I, [_V, _V]),
     "crp_stream_create_cu_mask": (_I, [C.POINTER(_V), _I, C.POINTER(C.c_uint)]),
     "crp_team2_waves": (_I, []),
+    "crp_team2_panels_per_wave": (_I, []),
     "crp_team2_format_host_grid": (_I, [C.POINTER(c_int_p), c_int_p]),
     "crp_team2_format_host": (_I, [_I, c_int_p, c_int_p, c_dbl_p, c_int_p, c_int_p, C.POINTER(c_int_p), C.POINTER(c_int_p),
                                    C.POINTER(c_int_p), C.POINTER(C.POINTER(C.c_uint)), C.POINTER(_LL),

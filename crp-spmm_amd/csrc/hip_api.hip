@@ -40,6 +40,10 @@ struct TeamDev
 };
 
 constexpr int TEAM2_MIN_N = 112;      // fp64 columns from which auto picks variant 5
+// ... when fewer than 35 % of the (row, entry) pairs of the R = 8 panels are present: the row-panel format then stores mostly
+// zeros (8 values per entry) while the team kernel's value streams are compact (nlpkkt stand-in, fill 0.23, n = 96: 1.26 ms
+// against 1.47; at n = 64 -- half of the kernel's 128-column tile idle -- 1.23 against 1.14, so not below 80)
+constexpr int TEAM2_MIN_N_SPARSE = 80;
 // fp32: the only other fp32 kernel is the CSR row-group one, which the team kernel beats from 64 columns on (fem3d
 // stand-in, n = 64 / 128 / 192 / 256: 0.648 / 0.649 / 0.652 / 0.660 ms against 0.663 / 1.24 / 2.31 / 2.37)
 constexpr int TEAM2_MIN_N_F32 = 64;
@@ -48,7 +52,8 @@ struct Team2Dev
     bool built = false;
     int  nteam = 0;
     int ngrid = 0;                 // entries of torder (= the launch grid, 8 equal runs, -1 = no team)
-    int tw = 8;                    // waves per team (Team2Host::T)
+    int tw = 8;                    // waves per team
+    int pw = 1;                    // panels per wave (Team2Host::P)
     int *torder = nullptr, *tpanel = nullptr, *tinfo = nullptr, *tpro = nullptr;
     uint32_t *trec = nullptr;
     long long *tvoff = nullptr;
@@ -77,8 +82,11 @@ struct crp_csr_dev
     PanelDev pan[2];          // [0]: R = 4, [1]: R = 8
     TeamDev  team;            // teams of four R = 8 panels (variant 4)
     Team2Dev team2;           // teams of eight R = 8 panels, LDS-shared B rows (variant 5)
+    Team2Dev team2p;          // teams of 16 panels on 8 waves, two panels per wave: variant 5 for operands of one 16-byte piece per
+                              // lane (fp64: n <= 128, fp32: n <= 256)
     int      auto_variant = 1; // what variant 0 resolves to below 96 columns (1 rowgroup, 2 panel R4, 3 panel R8)
-    bool     team2_pays = false;   // 64 consecutive rows (in format order) share columns: variant 0 takes team2 from 96 columns on
+    bool     team2_pays = false;   // 64 consecutive rows (in format order) share columns: variant 0 takes team2 from team2_min_n columns on
+    int      team2_min_n = TEAM2_MIN_N;    // or TEAM2_MIN_N_SPARSE when the R = 8 panels are mostly holes
     long long b0_rows = 0, b1_rows = 0;   // 1 + largest local / receive-buffer row a column index addresses
     float    *val32 = nullptr;            // fp32 copy of val (fp32 path), built on first use
     int      *rowmap = nullptr;           // row-subset matrices: C row of every row (device), else nullptr
@@ -229,9 +237,19 @@ static int team2_waves()
     return w;
 }
 
-static int ensure_team2(crp_csr_dev *A, hipStream_t stream)
+// Panels per wave of variant 5 for operands of `pieces` 16-byte pieces per lane and row: two (teams of 16 panels = 128
+// rows on 8 waves) when one piece covers the operand -- half the rounds, barriers and records per row and a B row fetched
+// once per 128 rows instead of 64; CRPSPMM_TEAM2_PW=1 keeps one panel per wave, teams of 16 waves (CRPSPMM_TEAM2_WAVES=16)
+// have no two-panel instance.
+static int team2_pw(int pieces)
 {
-    Team2Dev &t = A->team2;
+    static const int env = getenv("CRPSPMM_TEAM2_PW") ? atoi(getenv("CRPSPMM_TEAM2_PW")) : 2;
+    return (pieces == 1 && env == 2 && team2_waves() == 8) ? 2 : 1;
+}
+
+static int ensure_team2(crp_csr_dev *A, hipStream_t stream, int pw)
+{
+    Team2Dev &t = pw == 2 ? A->team2p : A->team2;
     if (t.built) return 0;
     crp::PhaseClock clk;
     crp::PanelHost h;
@@ -239,8 +257,10 @@ static int ensure_team2(crp_csr_dev *A, hipStream_t stream)
     fmt_slotmap_to_caller(A, &h.pmap);
     clk.lap("ensure_team2: build_panels (R = 8)");
     crp::Team2Host th;
-    th.T = team2_waves();
-    t.tw = th.T;
+    th.T = pw == 2 ? 16 : team2_waves();
+    th.P = pw;
+    t.tw = th.T / pw;
+    t.pw = pw;
     std::vector<int> colpos;                    // position of every row in the processing order (square, re-ordered matrices)
     if (!A->perm.empty())
     {
@@ -264,7 +284,7 @@ static int ensure_team2(crp_csr_dev *A, hipStream_t stream)
     if (e == hipSuccess) e = up((void **) &t.tinfo, th.tinfo.data(), sizeof(int) * th.tinfo.size(), 16);
     if (e == hipSuccess) e = up((void **) &t.tpro, th.tpro.data(), sizeof(int) * th.tpro.size(), 8);
     if (e == hipSuccess) e = up((void **) &t.trec, th.trec.data(), sizeof(uint32_t) * th.trec.size(), 1024);
-    t.value_entries = th.tvoff.back();
+    t.value_entries = th.nvalues;          // values of the compact streams
     if (e == hipSuccess) e = up((void **) &t.tvoff, th.tvoff.data(), sizeof(long long) * th.tvoff.size(), 8);
     // the kernel requests 256 bytes per wave and round: up to four groups past a wave's last part
     if (e == hipSuccess) e = up((void **) &t.tval, th.tval.data(), sizeof(double) * th.tval.size(), 4096);
@@ -577,6 +597,7 @@ int crp_csr_dev_create(int nrow, int ncol, const int *rowptr, const int *colidx,
         // 0.73 / 1.34 / 1.95 through CSR and 1.00 / 1.10 / 1.45 on R = 4; the shell stand-in 0.106 / 0.129 against 0.135 / 0.144
         // on R = 4.  Erdos-Renyi (e8 = nnz) stays with CSR.
         if ((double) e8 <= 0.6 * (double) nnz) A->auto_variant = 3;
+        if ((double) nnz < 0.35 * 8.0 * (double) e8) A->team2_min_n = TEAM2_MIN_N_SPARSE;
     }
     // The LDS-sharing team kernel fetches a B row once per team of 64 rows: it pays when those rows name far fewer
     // distinct columns than they have nonzeros (pwtk stand-in 0.10, shell 0.09, kkt 0.27, fem3d 0.13 of the nonzeros;
@@ -613,16 +634,19 @@ int crp_csr_dev_destroy(crp_csr_dev_p *A_)
     if (A->team.tvoff) (void) hipFree(A->team.tvoff);
     if (A->team.tval) (void) hipFree(A->team.tval);
     if (A->team.tmap) (void) hipFree(A->team.tmap);
-    if (A->team2.torder) (void) hipFree(A->team2.torder);
-    if (A->team2.tpanel) (void) hipFree(A->team2.tpanel);
-    if (A->team2.tinfo) (void) hipFree(A->team2.tinfo);
-    if (A->team2.tpro) (void) hipFree(A->team2.tpro);
-    if (A->team2.trec) (void) hipFree(A->team2.trec);
-    if (A->team2.tvoff) (void) hipFree(A->team2.tvoff);
-    if (A->team2.tval) (void) hipFree(A->team2.tval);
-    if (A->team2.tmap) (void) hipFree(A->team2.tmap);
-    if (A->team2.tval32) (void) hipFree(A->team2.tval32);
-    if (A->team2.gsync) (void) hipFree(A->team2.gsync);
+    for (Team2Dev *t2 : {&A->team2, &A->team2p})
+    {
+        if (t2->torder) (void) hipFree(t2->torder);
+        if (t2->tpanel) (void) hipFree(t2->tpanel);
+        if (t2->tinfo) (void) hipFree(t2->tinfo);
+        if (t2->tpro) (void) hipFree(t2->tpro);
+        if (t2->trec) (void) hipFree(t2->trec);
+        if (t2->tvoff) (void) hipFree(t2->tvoff);
+        if (t2->tval) (void) hipFree(t2->tval);
+        if (t2->tmap) (void) hipFree(t2->tmap);
+        if (t2->tval32) (void) hipFree(t2->tval32);
+        if (t2->gsync) (void) hipFree(t2->gsync);
+    }
     if (A->val32) (void) hipFree(A->val32);
     if (A->rowptr) (void) hipFree(A->rowptr);
     if (A->colidx) (void) hipFree(A->colidx);
@@ -642,7 +666,7 @@ int crp_csr_dev_update_values(crp_csr_dev_p A, const double *val, void *stream)
     for (int i = 0; i < 2; i++)
         if (A->pan[i].built && A->pan[i].entries * (long long) A->pan[i].R >= (1LL << 32)) return -5;
     if (A->team.built && A->team.entries * 8LL >= (1LL << 32)) return -5;
-    if (A->team2.built && A->team2.value_entries * 8LL >= (1LL << 32)) return -5;
+    if ((A->team2.built && A->team2.value_entries >= (1LL << 32)) || (A->team2p.built && A->team2p.value_entries >= (1LL << 32))) return -5;
     int is_dev = 0;
     crp_dev_ptr_is_device(val, &is_dev);
     CRP_TRY(hipMemcpyAsync(A->val, val, sizeof(double) * (size_t) A->nnz, is_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
@@ -658,10 +682,12 @@ int crp_csr_dev_update_values(crp_csr_dev_p A, const double *val, void *stream)
         if (A->pan[i].built)
             CRP_TRY(crp::scatter_vals_f64(A->nnz, A->pan[i].pmap, A->val, A->pan[i].pval, (hipStream_t) stream));
     if (A->team.built) CRP_TRY(crp::scatter_vals_f64(A->nnz, A->team.tmap, A->val, A->team.tval, (hipStream_t) stream));
-    if (A->team2.built) CRP_TRY(crp::scatter_vals_f64(A->nnz, A->team2.tmap, A->val, A->team2.tval, (hipStream_t) stream));
+    for (Team2Dev *t2 : {&A->team2, &A->team2p})
+        if (t2->built) CRP_TRY(crp::scatter_vals_f64(A->nnz, t2->tmap, A->val, t2->tval, (hipStream_t) stream));
     // fp32 copies follow
     if (A->val32) CRP_TRY(crp::convert_f64_f32(A->nnz, A->val, A->val32, (hipStream_t) stream));
-    if (A->team2.tval32) CRP_TRY(crp::convert_f64_f32(A->team2.value_entries * 8, A->team2.tval, A->team2.tval32, (hipStream_t) stream));
+    for (Team2Dev *t2 : {&A->team2, &A->team2p})
+        if (t2->tval32) CRP_TRY(crp::convert_f64_f32(t2->value_entries, t2->tval, t2->tval32, (hipStream_t) stream));
     return 0;
 }
 
@@ -726,7 +752,7 @@ int crp_spmm_csr_f64(crp_csr_dev_p A, int layout, int n, const double *B0, long 
     // auto: from TEAM2_MIN_N columns on the LDS-sharing team kernel wherever teams share columns (against the best
     // other variant on the pwtk / shell / fem3d stand-ins: n = 128: 1.00 / 0.81 / 0.73 of its time, n = 256: 0.85 /
     // 0.65 / 0.63; at n = 96 -- a tile of 128 columns three quarters used -- 1.17 / 1.00 / 0.94, at n = 32 1.6 x)
-    if (variant == 0 && A->team2_pays && n >= TEAM2_MIN_N && crp::spmm_team2_applicable(a)) v = 5;
+    if (variant == 0 && A->team2_pays && n >= A->team2_min_n && crp::spmm_team2_applicable(a)) v = 5;
     if (v == 5 && (!crp::spmm_team2_applicable(a) || A->nnz == 0 || A->nrow < 8)) v = 3;
     // the derived formats hold the rows in processing order: their C row map is chosen per launch, AFTER every fallback has
     // resolved (a re-ordered matrix that falls back to the CSR kernel writes through the caller's map)
@@ -734,13 +760,15 @@ int crp_spmm_csr_f64(crp_csr_dev_p A, int layout, int n, const double *B0, long 
     if (v == 5)
     {
         a.rowmap = fmt_map;
-        const int rc = ensure_team2(A, (hipStream_t) stream);
+        const int pw = team2_pw(n > 128 ? 2 : 1);
+        const int rc = ensure_team2(A, (hipStream_t) stream, pw);
         if (rc != 0) return rc;
+        const Team2Dev &d = pw == 2 ? A->team2p : A->team2;
         crp::Team2Args t;
-        t.nteam = A->team2.nteam; t.ngrid = A->team2.ngrid; t.tw = A->team2.tw; t.torder = A->team2.torder; t.tpanel = A->team2.tpanel; t.tinfo = A->team2.tinfo;
-        t.tpro = A->team2.tpro; t.trec = A->team2.trec; t.tvoff = A->team2.tvoff; t.tval = A->team2.tval; t.tval32 = nullptr;
-        t.gsync = A->team2.gsync; t.gsync_tiles = A->team2.gsync_tiles; t.gsync_ngen = A->team2.gsync_ngen; t.wgs = A->team2.wgs;
-        for (int x = 0; x < 8; x++) t.nreal[x] = A->team2.nreal[x];
+        t.nteam = d.nteam; t.ngrid = d.ngrid; t.tw = d.tw; t.pw = d.pw; t.torder = d.torder; t.tpanel = d.tpanel; t.tinfo = d.tinfo;
+        t.tpro = d.tpro; t.trec = d.trec; t.tvoff = d.tvoff; t.tval = d.tval; t.tval32 = nullptr;
+        t.gsync = d.gsync; t.gsync_tiles = d.gsync_tiles; t.gsync_ngen = d.gsync_ngen; t.wgs = d.wgs;
+        for (int x = 0; x < 8; x++) t.nreal[x] = d.nreal[x];
         return (int) crp::spmm_rm_f64_team2(t, a, (hipStream_t) stream);
     }
     if (v == 4 && (!crp::spmm_team_applicable(a) || A->b1_rows > 0)) v = 3;   // team kernel: one B source, 256-column tile
@@ -792,20 +820,22 @@ int crp_spmm_csr_f32(crp_csr_dev_p A, int n, const float *B0, long long ldB0, co
     const bool team = (variant == 5 || (variant == 0 && A->team2_pays && n >= TEAM2_MIN_N_F32)) && A->nnz > 0 && A->nrow >= 8 &&
                       crp::spmm_team2_applicable_f32(a);
     if (!team) return (int) crp::spmm_rm_f32_rowgroup(a, (hipStream_t) stream);
-    const int rc = ensure_team2(A, (hipStream_t) stream);
+    const int pw = team2_pw(n > 256 ? 2 : 1);
+    const int rc = ensure_team2(A, (hipStream_t) stream, pw);
     if (rc != 0) return rc;
-    if (A->team2.tval32 == nullptr)
+    Team2Dev &d = pw == 2 ? A->team2p : A->team2;
+    if (d.tval32 == nullptr)
     {
-        CRP_TRY(hipMalloc((void **) &A->team2.tval32, sizeof(float) * ((size_t) A->team2.value_entries * 8 + 1024)));
-        CRP_TRY(hipMemsetAsync(A->team2.tval32, 0, sizeof(float) * ((size_t) A->team2.value_entries * 8 + 1024), (hipStream_t) stream));
-        CRP_TRY(crp::convert_f64_f32(A->team2.value_entries * 8, A->team2.tval, A->team2.tval32, (hipStream_t) stream));
+        CRP_TRY(hipMalloc((void **) &d.tval32, sizeof(float) * ((size_t) d.value_entries + 1024)));
+        CRP_TRY(hipMemsetAsync(d.tval32, 0, sizeof(float) * ((size_t) d.value_entries + 1024), (hipStream_t) stream));
+        CRP_TRY(crp::convert_f64_f32(d.value_entries, d.tval, d.tval32, (hipStream_t) stream));
     }
     if (A->rowmap_fmt != nullptr) a.rowmap = A->rowmap_fmt;
     crp::Team2Args t;
-    t.nteam = A->team2.nteam; t.ngrid = A->team2.ngrid; t.tw = A->team2.tw; t.torder = A->team2.torder; t.tpanel = A->team2.tpanel; t.tinfo = A->team2.tinfo;
-    t.tpro = A->team2.tpro; t.trec = A->team2.trec; t.tvoff = A->team2.tvoff; t.tval = A->team2.tval; t.tval32 = A->team2.tval32;
-    t.gsync = A->team2.gsync; t.gsync_tiles = A->team2.gsync_tiles; t.gsync_ngen = A->team2.gsync_ngen; t.wgs = A->team2.wgs;
-    for (int x = 0; x < 8; x++) t.nreal[x] = A->team2.nreal[x];
+    t.nteam = d.nteam; t.ngrid = d.ngrid; t.tw = d.tw; t.pw = d.pw; t.torder = d.torder; t.tpanel = d.tpanel; t.tinfo = d.tinfo;
+    t.tpro = d.tpro; t.trec = d.trec; t.tvoff = d.tvoff; t.tval = d.tval; t.tval32 = d.tval32;
+    t.gsync = d.gsync; t.gsync_tiles = d.gsync_tiles; t.gsync_ngen = d.gsync_ngen; t.wgs = d.wgs;
+    for (int x = 0; x < 8; x++) t.nreal[x] = d.nreal[x];
     return (int) crp::spmm_rm_f32_team2(t, a, (hipStream_t) stream);
 }
 
@@ -816,10 +846,10 @@ int crp_csr_dev_resolved_variant(crp_csr_dev_p A, int n)
     if (A == NULL) return -1;
     int v = A->auto_variant;
     if (v >= 2 && n < 24) v = 1;
-    if (A->team2_pays && n >= TEAM2_MIN_N && (n % 2 == 0)) v = 5;
+    if (A->team2_pays && n >= A->team2_min_n && (n % 2 == 0)) v = 5;
     return v;
 }
-int crp_csr_dev_lattice(crp_csr_dev_p A) { return A ? ((A->team2.built && A->team2.lattice) || (A->team.built && A->team.lattice) ? 1 : 0) : -1; }
+int crp_csr_dev_lattice(crp_csr_dev_p A) { return A ? ((A->team2.built && A->team2.lattice) || (A->team2p.built && A->team2p.lattice) || (A->team.built && A->team.lattice) ? 1 : 0) : -1; }
 
 int crp_panel_format_host(int nrow, const int *rowptr, const int *colidx, const double *val, int R, int *npanel,
                           int **pptr, int **pcol, unsigned **pmask4, double **pval, long long *real_entries,
@@ -871,6 +901,8 @@ int crp_team_format_host(int nrow, const int *rowptr, const int *colidx, const d
     return 0;
 }
 
+// (host export only: the streams crp_team2_format_host builds -- CRPSPMM_TEAM2_FORMAT_PW=2: two panels per wave)
+int crp_team2_panels_per_wave(void) { return getenv("CRPSPMM_TEAM2_FORMAT_PW") && atoi(getenv("CRPSPMM_TEAM2_FORMAT_PW")) == 2 && team2_waves() == 8 ? 2 : 1; }
 int crp_team2_waves(void) { return team2_waves(); }
 
 static std::vector<int> g_last_tgrid;       // launch grid of the last crp_team2_format_host() (planning / test helper)
@@ -895,7 +927,9 @@ int crp_team2_format_host(int nrow, const int *rowptr, const int *colidx, const 
     crp::build_panels(nrow, rowptr, colidx, val, 8, &h, false, false);
     clk.lap("crp_team2_format_host: build_panels (R = 8)");
     crp::Team2Host th;
-    th.T = team2_waves();
+    const int pw = crp_team2_panels_per_wave();
+    th.T = pw == 2 ? 16 : team2_waves();
+    th.P = pw;
     crp::build_team2(h, nrow, rowptr, colidx, &th);
     clk.lap("crp_team2_format_host: build_team2");
     g_last_tgrid = th.tgrid;
@@ -915,7 +949,7 @@ int crp_team2_format_host(int nrow, const int *rowptr, const int *colidx, const 
     *nrecwords = (long long) th.trec.size();
     *tvoff = (long long *) malloc(sizeof(long long) * (th.tvoff.size() + 1));
     memcpy(*tvoff, th.tvoff.data(), sizeof(long long) * th.tvoff.size());
-    *nvalent = th.tvoff.back();
+    *nvalent = th.nvalues;
     *tval = (double *) calloc(th.tval.size() + 1, sizeof(double));
     if (!th.tval.empty()) memcpy(*tval, th.tval.data(), sizeof(double) * th.tval.size());
     if (vmap)

@@ -70,9 +70,10 @@ struct Team2Args          // panel_format.h, Team2Host
 {
     int nteam;
     int ngrid;                 // entries of torder: the launch grid (Team2Host::tgrid), a multiple of 8
-    int tw;                    // waves (= panels) per team: 8 or 16 (Team2Host::T)
+    int tw;                    // waves per team: 8 or 16
+    int pw;                    // panels per wave: 1, or 2 (Team2Host::P: teams of 16 panels on 8 waves, operands of one 16-byte piece)
     const int      *torder;
-    const int      *tpanel;    // tw * nteam
+    const int      *tpanel;    // tw * pw * nteam
     const int      *tinfo;     // 4 * nteam: rounds, first record block, union entries, 0
     const int      *tpro;      // nteam * TEAM2_D * tw * 2: {column, value offset}
     const uint32_t *trec;      // record blocks (1 KiB each)

@@ -598,7 +598,7 @@ static void build_key_csr(int n, F raw, std::vector<long long> *iptr, std::vecto
     });
 }
 
-void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *colidx, TeamHost *out, int T, const int *colpos)
+void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *colidx, TeamHost *out, int T, const int *colpos, bool balanced)
 {
     constexpr int TMAX = 16;
     if (T != 4 && T != 6 && T != 8 && T != 16) T = 4;
@@ -803,6 +803,13 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
             std::vector<int> &uc = ucol[(size_t) g];
             std::vector<uint32_t> &um = umask[(size_t) g];
             std::vector<int> &us = usrc[(size_t) g];       // per union entry: panel entry of wave 0..3 (or -1)
+            {
+                size_t cap = 0;
+                for (int w = 0; w < T; w++) cap += (size_t) (end[w] - head[w]);
+                uc.reserve(cap);
+                um.reserve(cap);
+                us.reserve(cap * (size_t) T);
+            }
             // Nodes: the union of the four entry lists, equal (column, occurrence) keys merged.
             struct Node { int col; uint32_t mask; int src[TMAX]; int users; bool done; };
             std::vector<Node> nodes;
@@ -850,6 +857,18 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
             int cursor[TMAX];
             for (int w = 0; w < TMAX; w++) cursor[w] = 0;
             size_t left = nodes.size();
+            if (!balanced)
+            {
+                // (the caller orders the union itself -- build_team2 by the phase key --: column order will do, and the
+                //  passes below were a fifth of the nlpkkt240-size format's build time)
+                for (size_t id = 0; id < nodes.size(); id++)
+                {
+                    uc.push_back(nodes[id].col);
+                    um.push_back(nodes[id].mask);
+                    for (int u = 0; u < T; u++) us.push_back(nodes[id].src[u]);
+                }
+                left = 0;
+            }
             auto emit = [&](int id) {
                 Node &nd = nodes[(size_t) id];
                 nd.done = true;
@@ -1047,6 +1066,14 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
         bisection_order(nteam, gptr, gadj, gw, work, T == 16 ? 32 : 64, &out->torder);
         out->bisected = true;
         clk.lap("build_teams: processing order (recursive bisection)");
+        parallel_chunks(nteam, 1024, [&](long long b, long long e, int) {
+            for (long long g = b; g < e; g++)
+            {
+                std::vector<int>().swap(ucol[(size_t) g]);
+                std::vector<uint32_t>().swap(umask[(size_t) g]);
+                std::vector<int>().swap(usrc[(size_t) g]);
+            }
+        });
         return;
     }
     if (clustered && nteam >= 128)
@@ -1152,18 +1179,31 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
         }
     }
     clk.lap("build_teams: processing order (super-teams)");
+    parallel_chunks(nteam, 1024, [&](long long b, long long e, int) {
+        for (long long g = b; g < e; g++)
+        {
+            std::vector<int>().swap(ucol[(size_t) g]);
+            std::vector<uint32_t>().swap(umask[(size_t) g]);
+            std::vector<int>().swap(usrc[(size_t) g]);
+        }
+    });
 }
 
 // ---- team2 streams (panel_format.h) ------------------------------------------------------------------
+static bool phase_env() { return getenv("CRPSPMM_TEAM2_PHASE") == NULL || atoi(getenv("CRPSPMM_TEAM2_PHASE")) != 0; }
+
 void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *colidx, Team2Host *out, const int *colpos)
 {
     constexpr int D = TEAM2_D, CAP = TEAM2_CAP, TMAX = 16;
-    const int T = out->T == 16 ? 16 : TEAM2_T;
-    const int sbits = T == 16 ? 4 : 3, fbase = T == 16 ? 20 : 16;          // slot bits and first flag bit of record word 0
-    const size_t blkw = (size_t) 32 * T;                                    // words of a record block (8 rounds x T waves x 4)
+    const int T = out->T == 16 ? 16 : TEAM2_T;                              // panels of a team
+    const int P = (out->P == 2 && T == 16) ? 2 : 1;                         // panels of a wave
+    const int W = T / P;                                                    // waves of a team = slots of a round
+    out->P = P;
+    const int sbits = W == 16 ? 4 : 3, fbase = W == 16 ? 20 : 16;          // slot bits and first flag bit of record word 0
+    const size_t blkw = (size_t) 32 * W;                                    // words of a record block (8 rounds x W waves x 4)
     PhaseClock clk;
     TeamHost th;
-    build_teams(p, nrow, rowptr, colidx, &th, T, colpos);
+    build_teams(p, nrow, rowptr, colidx, &th, T, colpos, !phase_env());
     clk.lap("build_team2: build_teams total");
     // Phase key of a union entry: (position of its B row in the processing order) mod S, S = rows a team advances
     // along its sweep (8 x the consecutive panels of a lattice team, 64 for eight consecutive panels).  Teams are
@@ -1173,7 +1213,7 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
     // survives in the XCD's L2 -- instead of at unrelated moments of 35-microsecond lives.
     // CRPSPMM_TEAM2_PHASE=0 keeps the balanced order of build_teams().
     const int S = th.lattice ? 8 * th.st : 8 * T;
-    static const bool phase = getenv("CRPSPMM_TEAM2_PHASE") == NULL || atoi(getenv("CRPSPMM_TEAM2_PHASE")) != 0;
+    const bool phase = phase_env();
     const int nteam = th.nteam;
     out->nteam = nteam;
     out->lattice = th.lattice;
@@ -1181,13 +1221,13 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
     out->torder = th.torder;
     auto mask_of = [&](size_t q) { return (p.pmask4[q >> 2] >> (8 * (q & 3))) & 0xFFu; };
 
-    struct Part { int slot, first, len, src; };
+    struct Part { int slot, first, len, src, bank; };       // bank = which of the wave's P panels
     struct TeamOut
     {
         int nr = 0, filled = 0, nparts = 0;
         int anycol = 0;                             // a column of the team (a valid row for the prologue's empty slots)
-        std::vector<int> col;                       // nr * T slot columns (TEAM2_NOCOL = empty slot)
-        // parts of wave w in round r: ownp[(r * T + w) * CAP .. + ownc[r * T + w])  (flat: one small vector per
+        std::vector<int> col;                       // nr * W slot columns (TEAM2_NOCOL = empty slot)
+        // parts of wave w in round r: ownp[(r * W + w) * CAP .. + ownc[r * W + w])  (flat: one small vector per
         // (round, wave) was 126 M heap allocations on the nlpkkt240-size matrix)
         std::vector<Part> ownp;
         std::vector<unsigned char> ownc;
@@ -1233,43 +1273,68 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
     auto schedule_team = [&](int g, const std::vector<int> &nodes, const int *target) {
         TeamOut &to = res[(size_t) g];
         to.anycol = nodes.empty() ? 0 : th.tcol[(size_t) nodes[0]];
-        std::vector<char> taken(nodes.size(), 0);
-        size_t head = 0, left = nodes.size();
+        // the row ranges of every (node, wave), once: byte = first << 4 | len, up to 4 per wave (the look-ahead visits a
+        // node several times before it fits)
+        const size_t nn = nodes.size();
+        std::vector<unsigned char> rk(nn * (size_t) T, 0), rr(nn * (size_t) T * 4, 0);
+        for (size_t t = 0; t < nn; t++)
+            for (int w = 0; w < T; w++)
+            {
+                const int src = th.tsrc[(size_t) nodes[t] * T + (size_t) w];
+                if (src < 0) continue;
+                Part tmp[4];
+                const int kk = ranges(mask_of((size_t) src), tmp);
+                rk[t * (size_t) T + (size_t) w] = (unsigned char) kk;
+                for (int i = 0; i < kk; i++) rr[(t * (size_t) T + (size_t) w) * 4 + (size_t) i] = (unsigned char) (tmp[i].first << 4 | tmp[i].len);
+            }
+        std::vector<char> taken(nn, 0);
+        size_t head = 0, left = nn;
+        {
+            // (one allocation each instead of one per round: the allocator was what the 64 builder threads were waiting for)
+            const size_t est = nn / (size_t) W + nn / (size_t) (4 * W) + 8;
+            to.col.reserve(est * (size_t) W);
+            to.ownp.reserve(est * (size_t) W * CAP);
+            to.ownc.reserve(est * (size_t) W);
+        }
         while (left > 0)
         {
             int cnt[TMAX];
             for (int w = 0; w < TMAX; w++) cnt[w] = 0;
             int nslot = 0;
             const size_t base_col = to.col.size();
-            to.col.resize(base_col + (size_t) T, TEAM2_NOCOL);
-            to.ownp.resize(to.ownp.size() + (size_t) T * CAP);
-            to.ownc.resize(to.ownc.size() + (size_t) T, 0);
-            while (head < nodes.size() && taken[head]) head++;
+            to.col.resize(base_col + (size_t) W, TEAM2_NOCOL);
+            to.ownp.resize(to.ownp.size() + (size_t) W * CAP);
+            to.ownc.resize(to.ownc.size() + (size_t) W, 0);
+            while (head < nn && taken[head]) head++;
             int seen = 0;
-            for (size_t t = head; t < nodes.size() && nslot < T && seen < 4 * T; t++)
+            for (size_t t = head; t < nn && nslot < W && seen < 4 * W; t++)
             {
                 if (taken[t]) continue;
                 if (target != nullptr && target[t] > to.nr + ahead) break;         // (targets ascend with t)
                 seen++;
-                const int q = nodes[t];
-                Part tmp[TMAX][4];
-                int kk[TMAX];
+                const unsigned char *kk = &rk[t * (size_t) T];            // parts of every PANEL; wave of panel x = x / P
                 bool fits = true;
-                for (int w = 0; w < T; w++)
+                for (int w = 0; w < W; w++)
                 {
-                    const int src = th.tsrc[(size_t) q * T + (size_t) w];
-                    kk[w] = src >= 0 ? ranges(mask_of((size_t) src), tmp[w]) : 0;
-                    if (cnt[w] + kk[w] > CAP) fits = false;
+                    int need = 0;
+                    for (int j = 0; j < P; j++) need += kk[w * P + j];
+                    if (cnt[w] + need > CAP) fits = false;
                 }
                 if (!fits) continue;
-                for (int w = 0; w < T; w++)
-                    for (int i = 0; i < kk[w]; i++)
+                const int q = nodes[t];
+                for (int x = 0; x < T; x++)
+                    for (int i = 0; i < kk[x]; i++)
                     {
-                        Part pt = tmp[w][i];
+                        const int w = x / P;
+                        const unsigned char b = rr[(t * (size_t) T + (size_t) x) * 4 + (size_t) i];
+                        Part pt;
+                        pt.first = b >> 4;
+                        pt.len = b & 15;
                         pt.slot = nslot;
-                        pt.src = th.tsrc[(size_t) q * T + (size_t) w];
-                        to.ownp[((size_t) to.nr * T + (size_t) w) * CAP + (size_t) cnt[w]] = pt;
-                        to.ownc[(size_t) to.nr * T + (size_t) w]++;
+                        pt.src = th.tsrc[(size_t) q * T + (size_t) x];
+                        pt.bank = x % P;
+                        to.ownp[((size_t) to.nr * W + (size_t) w) * CAP + (size_t) cnt[w]] = pt;
+                        to.ownc[(size_t) to.nr * W + (size_t) w]++;
                         cnt[w]++;
                         to.nparts++;
                     }
@@ -1285,7 +1350,7 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
     // ---- the launch grid: the order cut into 8 contiguous pieces of equal work (union entries / T + a fixed cost per
     // team), one per XCD -- pieces of equal team COUNT leave XCDs idle when the teams differ (KKT systems: 27-point primal
     // rows, short dual rows).  Under the bisection order the cuts fall on multiples of a generation.
-    const int WGS = T == 16 ? 32 : 64;                                  // workgroups resident on an XCD = a generation
+    const int WGS = W == 16 ? 32 : 64;                                  // workgroups resident on an XCD = a generation
     const bool abs_env = getenv("CRPSPMM_T2_ABS") == NULL || atoi(getenv("CRPSPMM_T2_ABS")) != 0;
     const bool absolute = th.bisected && abs_env && phase;
     out->absolute = absolute;
@@ -1298,13 +1363,13 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
             for (long long g = b; g < e; g++) { team_nodes((int) g, nodes); nn[(size_t) g] = (int) nodes.size(); }
         });
         long long total = 0;
-        for (int g = 0; g < nteam; g++) total += (nn[(size_t) g] + T - 1) / T + 4;
+        for (int g = 0; g < nteam; g++) total += (nn[(size_t) g] + W - 1) / W + 4;
         cut[0] = 0;
         long long acc = 0;
         int x = 1;
         for (int i = 0; i < nteam && x < 8; i++)
         {
-            acc += (nn[(size_t) out->torder[(size_t) i]] + T - 1) / T + 4;
+            acc += (nn[(size_t) out->torder[(size_t) i]] + W - 1) / W + 4;
             while (x < 8 && acc * 8 >= total * x) cut[(size_t) x++] = i + 1;
         }
         if (th.bisected)
@@ -1350,8 +1415,8 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
                 {
                     const int g = out->torder[(size_t) (G.first + i)];
                     team_nodes(g, nodes[(size_t) i]);
-                    rsum += ((long long) nodes[(size_t) i].size() + T - 1) / T;
-                    R = std::max(R, ((int) nodes[(size_t) i].size() + T - 1) / T);
+                    rsum += ((long long) nodes[(size_t) i].size() + W - 1) / W;
+                    R = std::max(R, ((int) nodes[(size_t) i].size() + W - 1) / W);
                     for (int q : nodes[(size_t) i]) all.push_back({((uint64_t) (uint32_t) key(q) << 32) | (uint64_t) col_key(th.tcol[(size_t) q]), 0});
                 }
                 std::sort(all.begin(), all.end());
@@ -1384,29 +1449,52 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
     clk.lap("build_team2: rounds (phase sort, list scheduler)");
     // ---- layout: record blocks, value streams
     out->tinfo.assign((size_t) nteam * 4, 0);
-    out->tpro.assign((size_t) nteam * D * T * 2, 0);
-    out->tvoff.assign((size_t) nteam * T + 1, 0);
+    out->tpro.assign((size_t) nteam * D * W * 2, 0);
+    out->tvoff.assign((size_t) nteam * W + 1, 0);
     std::vector<int> blk0((size_t) nteam + 1, 0);
     long long run = 0;
     out->real_entries = out->slots = out->parts = 0;
-    for (int g = 0; g < nteam; g++)
+    // value units (TEAM2_VUNIT values) of a round of a wave: its parts' rows, padded
+    auto round_units = [&](const TeamOut &to, int r, int w) {
+        int nv = 0;
+        const Part *ow = &to.ownp[((size_t) r * W + (size_t) w) * CAP];
+        for (int i = 0; i < (int) to.ownc[(size_t) r * W + (size_t) w]; i++) nv += ow[i].len;
+        return (nv + TEAM2_VUNIT - 1) / TEAM2_VUNIT;
+    };
     {
-        const TeamOut &to = res[(size_t) g];
-        blk0[(size_t) g + 1] = blk0[(size_t) g] + (to.nr + 7) / 8;
-        out->tinfo[(size_t) g * 4] = to.nr;
-        out->tinfo[(size_t) g * 4 + 1] = blk0[(size_t) g];
-        out->tinfo[(size_t) g * 4 + 2] = to.nparts;
-        out->tinfo[(size_t) g * 4 + 3] = to.filled;
-        out->real_entries += to.filled;
-        out->slots += (long long) to.nr * T;
-        out->parts += to.nparts;
-        for (int w = 0; w < T; w++)
+        std::vector<long long> wunits((size_t) nteam * W, 0);
+        parallel_chunks(nteam, 256, [&](long long b, long long e, int) {
+            for (long long g = b; g < e; g++)
+            {
+                const TeamOut &to = res[(size_t) g];
+                for (int w = 0; w < W; w++)
+                {
+                    long long u = 0;
+                    for (int r = 0; r < to.nr; r++) u += round_units(to, r, w);
+                    wunits[(size_t) g * W + (size_t) w] = u;
+                }
+            }
+        });
+        for (int g = 0; g < nteam; g++)
         {
-            out->tvoff[(size_t) g * T + (size_t) w] = run;
-            for (int r = 0; r < to.nr; r++) run += (long long) to.ownc[(size_t) r * T + (size_t) w];
+            const TeamOut &to = res[(size_t) g];
+            blk0[(size_t) g + 1] = blk0[(size_t) g] + (to.nr + 7) / 8;
+            out->tinfo[(size_t) g * 4] = to.nr;
+            out->tinfo[(size_t) g * 4 + 1] = blk0[(size_t) g];
+            out->tinfo[(size_t) g * 4 + 2] = to.nparts;
+            out->tinfo[(size_t) g * 4 + 3] = to.filled;
+            out->real_entries += to.filled;
+            out->slots += (long long) to.nr * W;
+            out->parts += to.nparts;
+            for (int w = 0; w < W; w++)
+            {
+                out->tvoff[(size_t) g * W + (size_t) w] = run;
+                run += wunits[(size_t) g * W + (size_t) w];
+            }
         }
     }
-    out->tvoff[(size_t) nteam * T] = run;
+    out->tvoff[(size_t) nteam * W] = run;
+    out->nvalues = run * TEAM2_VUNIT;
     // launch grid: run x of tgrid = what XCD x processes, in order (the cuts computed above)
     {
         int cpx = 1;
@@ -1416,61 +1504,81 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
             for (int i = cut[(size_t) q]; i < cut[(size_t) q + 1]; i++) out->tgrid[(size_t) q * cpx + (size_t) (i - cut[(size_t) q])] = out->torder[(size_t) i];
     }
     parallel_fill(out->trec, (size_t) blk0[(size_t) nteam] * blkw + blkw, 0u);
-    parallel_fill(out->tval, (size_t) run * 8, 0.0);
+    parallel_fill(out->tval, (size_t) run * TEAM2_VUNIT, 0.0);
     // vmap through the panel format's slot map: pmap[nz] = q * 8 + row of the panel format
     big_vector<uint32_t> slot_of;                                          // panel-format value slot -> tval slot
-    parallel_fill(slot_of, p.pcol.size() * 8, 0xFFFFFFFFu);
+    slot_of.resize(p.pcol.size() * 8);          // (only the (entry, row) pairs that exist are written below and read through pmap)
     parallel_chunks(nteam, 32, [&](long long b, long long e, int) {
         for (long long g = b; g < e; g++)
         {
             const TeamOut &to = res[(size_t) g];
-            for (int w = 0; w < T; w++)
+            for (int w = 0; w < W; w++)
             {
-                long long k = out->tvoff[(size_t) g * T + (size_t) w];
-                const long long k0 = k;
+                // value units of every round of this wave (prefix), then the records
+                std::vector<long long> voff((size_t) to.nr + 1, 0);
+                std::vector<int> nvals((size_t) to.nr + 1, 0);
                 for (int r = 0; r < to.nr; r++)
                 {
-                    const Part *ow = &to.ownp[((size_t) r * T + (size_t) w) * CAP];
-                    const size_t nown = to.ownc[(size_t) r * T + (size_t) w];
-                    uint32_t x = (uint32_t) nown, y = 0;
+                    const Part *ow = &to.ownp[((size_t) r * W + (size_t) w) * CAP];
+                    int nv = 0;
+                    for (int i = 0; i < (int) to.ownc[(size_t) r * W + (size_t) w]; i++) nv += ow[i].len;
+                    nvals[(size_t) r] = nv;
+                    voff[(size_t) r + 1] = voff[(size_t) r] + (nv + TEAM2_VUNIT - 1) / TEAM2_VUNIT;
+                }
+                if (voff[(size_t) to.nr] >= (1LL << 20)) { fprintf(stderr, "[FATAL] team2 format: a wave's value stream exceeds 2^20 units\n"); abort(); }
+                const long long e0 = out->tvoff[(size_t) g * W + (size_t) w] * TEAM2_VUNIT;     // first value of the wave's stream
+                for (int r = 0; r < to.nr; r++)
+                {
+                    const Part *ow = &to.ownp[((size_t) r * W + (size_t) w) * CAP];
+                    const size_t nown = to.ownc[(size_t) r * W + (size_t) w];
+                    uint32_t x = (uint32_t) nown, y = 0, z = 0;
+                    long long e = e0 + voff[(size_t) r] * TEAM2_VUNIT;       // where the round's block starts
+                    int prefix = 0;
                     for (size_t i = 0; i < nown; i++)
                     {
                         const Part &pt = ow[i];
                         x |= (uint32_t) pt.slot << (4 + sbits * (int) i);
-                        y |= (uint32_t) (pt.first * 8 - pt.first * (pt.first - 1) / 2 + pt.len - 1) << (6 * i);
+                        y |= (uint32_t) (pt.first * 8 + pt.len - 1) << (6 * i);
+                        // value position of the part: prefix + 7 - first (tools/gen_team2_asm.py)
+                        const uint32_t pos = (uint32_t) (prefix + 7 - pt.first);
+                        x |= (uint32_t) pt.bank << (fbase + 11 + (int) i);       // which of the wave's panels (P = 2)
+                        if (i == 0) x |= pos << (fbase + 5);
+                        else if (i == 1) y |= pos << 24;
+                        else if (i == 2) z |= pos << 20;
+                        else z |= pos << 26;
                         for (int rr = pt.first; rr < pt.first + pt.len; rr++)
                         {
-                            out->tval[(size_t) k * 8 + (size_t) rr] = p.pval[(size_t) pt.src * 8 + (size_t) rr];
-                            slot_of[(size_t) pt.src * 8 + (size_t) rr] = (uint32_t) (k * 8 + rr);
+                            const size_t at = (size_t) (e + prefix + (rr - pt.first));
+                            out->tval[at] = p.pval[(size_t) pt.src * 8 + (size_t) rr];
+                            slot_of[(size_t) pt.src * 8 + (size_t) rr] = (uint32_t) at;
                         }
-                        k++;
+                        prefix += pt.len;
                     }
-                    uint32_t *rec = &out->trec[((size_t) blk0[(size_t) g] + (size_t) (r >> 3)) * blkw + (size_t) (r & 7) * 4 * T + (size_t) w * 4];
+                    uint32_t *rec = &out->trec[((size_t) blk0[(size_t) g] + (size_t) (r >> 3)) * blkw + (size_t) (r & 7) * 4 * W + (size_t) w * 4];
                     rec[0] = x;
                     rec[1] = y;
+                    rec[2] = z;
                 }
-                // value offsets and columns fetched D rounds ahead
-                std::vector<long long> voff((size_t) to.nr + 1, 0);
-                for (int r = 0; r < to.nr; r++) voff[(size_t) r + 1] = voff[(size_t) r] + (long long) to.ownc[(size_t) r * T + (size_t) w];
-                (void) k0;
+                // what is fetched D rounds ahead: value block (offset, size class), column
                 for (int r = 0; r < to.nr; r++)
                 {
                     const int rd = r + D;
-                    uint32_t *rec = &out->trec[((size_t) blk0[(size_t) g] + (size_t) (r >> 3)) * blkw + (size_t) (r & 7) * 4 * T + (size_t) w * 4];
-                    rec[2] = (uint32_t) (rd < to.nr ? voff[(size_t) rd] : voff[(size_t) to.nr]);
-                    rec[3] = (uint32_t) (rd < to.nr ? to.col[(size_t) rd * T + (size_t) w] : TEAM2_NOCOL);
+                    uint32_t *rec = &out->trec[((size_t) blk0[(size_t) g] + (size_t) (r >> 3)) * blkw + (size_t) (r & 7) * 4 * W + (size_t) w * 4];
+                    rec[2] |= (uint32_t) (rd < to.nr ? voff[(size_t) rd] : voff[(size_t) to.nr]);
+                    if (rd < to.nr && nvals[(size_t) rd] > 0) rec[1] |= (uint32_t) ((nvals[(size_t) rd] + 7) / 8 - 1) << 30;
+                    rec[3] = (uint32_t) (rd < to.nr ? to.col[(size_t) rd * W + (size_t) w] : TEAM2_NOCOL);
                     // flags that steer the kernel's round (tools/gen_team2_asm.py)
                     if (rd < to.nr) rec[0] |= 1u << fbase;                                   // ISSUE: fetch for round r + D
-                    if (rd < to.nr && to.ownc[(size_t) rd * T + (size_t) w] == 0) rec[0] |= 1u << (fbase + 4);   // NOVAL: no parts there, no values to fetch
+                    if (rd < to.nr && to.ownc[(size_t) rd * W + (size_t) w] == 0) rec[0] |= 1u << (fbase + 4);   // NOVAL: no parts there, no values to fetch
                     if (r + D - 1 >= to.nr) rec[0] |= 1u << (fbase + 1);                           // TAIL: fewer than D-1 younger rounds in flight
                     if (r == to.nr - 1) rec[0] |= 1u << (fbase + 2);                               // LAST
                     if (w == 0 && (r & 7) == 0 && (r >> 3) + 1 < (to.nr + 7) / 8) rec[0] |= 1u << (fbase + 3);   // RECS: fetch the next record block
                 }
                 for (int d = 0; d < D; d++)
                 {
-                    int *pr = &out->tpro[(((size_t) g * D + (size_t) d) * T + (size_t) w) * 2];
+                    int *pr = &out->tpro[(((size_t) g * D + (size_t) d) * W + (size_t) w) * 2];
                     // (the prologue's fetches are compiled code with a fixed DMA count: an empty slot fetches a valid row)
-                    pr[0] = (d < to.nr && to.col[(size_t) d * T + (size_t) w] != TEAM2_NOCOL) ? to.col[(size_t) d * T + (size_t) w] : to.anycol;
+                    pr[0] = (d < to.nr && to.col[(size_t) d * W + (size_t) w] != TEAM2_NOCOL) ? to.col[(size_t) d * W + (size_t) w] : to.anycol;
                     pr[1] = (int) ((d < to.nr) ? voff[(size_t) d] : voff[(size_t) to.nr]);
                 }
             }
@@ -1482,6 +1590,17 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
         for (long long nz = b; nz < e; nz++) out->vmap[(size_t) nz] = slot_of[(size_t) p.pmap[(size_t) nz]];
     });
     clk.lap("build_team2: value-update map");
+    // (hundreds of thousands of small vectors: released by all threads, not by the one that leaves the function)
+    parallel_chunks(nteam, 1024, [&](long long b, long long e, int) {
+        for (long long g = b; g < e; g++)
+        {
+            TeamOut &to = res[(size_t) g];
+            std::vector<int>().swap(to.col);
+            std::vector<Part>().swap(to.ownp);
+            std::vector<unsigned char>().swap(to.ownc);
+        }
+    });
+    clk.lap("build_team2: release");
 }
 
 void apply_team_schedule(PanelHost *p, const TeamHost &t)

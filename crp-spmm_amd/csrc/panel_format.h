@@ -113,7 +113,9 @@ struct TeamHost
     bool bisected = false;         // torder = recursive bisection of the team graph (team_order.h): a generation = 64 (T = 16: 32) consecutive teams
 };
 // colpos (optional, matrices in a locality order): position of row c of A in the order the panels were built on.
-void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *colidx, TeamHost *out, int T = 4, const int *colpos = nullptr);
+// balanced = false: the union entries of a team stay in column order (the caller orders them itself).
+void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *colidx, TeamHost *out, int T = 4, const int *colpos = nullptr,
+                 bool balanced = true);
 
 // Team schedule for the row-panel kernel itself (no LDS sharing): the entries of every panel are
 // re-ordered to the order in which its wave meets them in the team's balanced schedule, and the
@@ -123,31 +125,38 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
 void apply_team_schedule(PanelHost *p, const TeamHost &t);
 
 // ---- team2: the streams of the LDS-sharing kernel of csrc/team2_kernel.hip ---------------------------
-// A team is TEAM2_T = 8 panels, one per wave of a 512-thread workgroup.  The union of their columns
-// (TeamHost: merged, in a balanced schedule) is walked in rounds of up to 8 union entries ("slots"); wave w
-// fetches slot w of a round (one B row slice) by LDS-DMA into a ring shared by the workgroup, TEAM2_D rounds
-// ahead.  What a wave owns of a round is a list of at most TEAM2_CAP PARTS: a part is one slot together with a
-// CONTIGUOUS range of the panel's rows that have the column (an entry whose rows are not contiguous is split
-// into several parts), so that the kernel can jump to straight-line code for the range instead of testing a
-// mask bit per row.  Per (round, wave) one 16-byte record:
-//   word 0 : bits 0-2 = number of parts c (0..4); bits 4+3i .. 6+3i = ring slot (0..7) of part i; flags: bit 16
-//            ISSUE (r + D < rounds), 17 TAIL (r + D - 1 >= rounds), 18 LAST round, 19 RECS (wave 0, r % 8 == 0 and
-//            a further record block exists: fetch it now)
-//   word 1 : bits 6i .. 6i+5 = range code of part i: code(first, len) = first * 8 - first * (first - 1) / 2 + len - 1
-//            (0..35; first = first row, len = rows)
-//   word 2 : entry offset, inside the wave's value stream, of the parts of round r + TEAM2_D
-//   word 3 : column (two-source encoding) of the union entry this wave fetches for round r + TEAM2_D
-// Records are stored in blocks of 8 rounds x 8 waves (1 KiB, one LDS-DMA instruction); for the first TEAM2_D
-// rounds the (column, value offset) pairs come from tpro.  A wave's values are a stream of 8-double groups, one
-// per part in the order the wave meets them (rows outside the part's range hold 0 and are never read), starting
-// at entry tvoff[8 g + w]; round r's parts are contiguous in it.
+// A team is T panels on W = T / P waves of one workgroup (T = 8, P = 1: 512 threads; T = 16, P = 1: 1024 threads; T = 16,
+// P = 2: 512 threads, every wave owns two panels -- two banks of accumulators -- for operands of one 16-byte piece per
+// lane).  The union of their columns is walked in rounds of up to W union entries ("slots"); wave w fetches slot w of a
+// round (one B row slice) by LDS-DMA into a ring shared by the workgroup, TEAM2_D rounds ahead.  What a wave owns of a round
+// is a list of at most TEAM2_CAP PARTS: a part is one slot together with a CONTIGUOUS range of the rows of one of its panels
+// that have the column (an entry whose rows are not contiguous is split into several parts), so that the kernel can jump to
+// straight-line code for the range instead of testing a mask bit per row.  Per (round, wave) one 16-byte record
+// (W = 8; W = 16 in brackets):
+//   word 0 : bits 0-2 = number of parts c (0..4); bits 4+3i .. [4+4i ..] = ring slot of part i; flags from bit 16 [20]:
+//            ISSUE (r + D < rounds), TAIL (r + D - 1 >= rounds), LAST round, RECS (wave 0, r % 8 == 0 and a further record
+//            block exists: fetch it now), NOVAL (the wave has no parts in round r + D: no values to fetch); bits 21-26
+//            [25-30] = value position of part 0; bits 27 + i = bank (panel of the wave, P = 2) of part i
+//   word 1 : bits 6i .. 6i+5 = range of part i as first * 8 + len - 1; bits 24-29 = value position of part 1;
+//            bits 30-31 = size class q of the value block of round r + TEAM2_D (at most 8 (q + 1) values)
+//   word 2 : bits 0-19 = offset, inside the wave's value stream and in units of TEAM2_VUNIT values, of the block of
+//            round r + TEAM2_D; bits 20-25, 26-31 = value positions of parts 2 and 3
+//   word 3 : column (two-source encoding) of the union entry this wave fetches for round r + TEAM2_D, or TEAM2_NOCOL
+// Records are stored in blocks of 8 rounds x W waves (one or two KiB); for the first TEAM2_D rounds the (column, value
+// offset) pairs come from tpro.  A wave's values are COMPACT: a part of len rows holds len values; the parts of a round form
+// one block of the wave's stream (padded to TEAM2_VUNIT values), in the order the wave meets them; part i's value position
+// = (values of the parts before it in the block) + 7 - first_i, what the kernel adds to a lane's row to find its value.
+// The stream of wave w of team g starts at value TEAM2_VUNIT * tvoff[W g + w].
 constexpr int TEAM2_T = 8;
 constexpr int TEAM2_D = 3;
 constexpr int TEAM2_CAP = 4;
+constexpr int TEAM2_VUNIT = 4;                    // value-stream offsets count units of 4 values (16 bytes of fp32, 32 of fp64)
 constexpr int TEAM2_NOCOL = (int) 0x80000000;   // column word of an empty slot: the wave fetches no B row for it
 struct Team2Host
 {
-    int T = TEAM2_T;                 // panels (= waves = slots of a round) per team: 8, or 16 (set before build_team2)
+    int T = TEAM2_T;                 // panels per team: 8, or 16 (set before build_team2)
+    int P = 1;                       // panels per WAVE: 1, or 2 with T = 16 (teams of 16 panels on 8 waves: the narrow-operand
+                                     // instance of the kernel, two accumulator banks per wave); waves = slots of a round = T / P
     int nteam = 0;
     bool lattice = false;
     std::vector<int>       tpanel;   // 8 * nteam: panel of wave w, or -1
@@ -162,6 +171,7 @@ struct Team2Host
     std::vector<uint32_t>  vmap;     // per CSR nonzero (panel format's own order of pmap): its slot in tval
     bool absolute = false;           // rounds are generation-wide absolute rounds (build_team2): the kernel's generation barrier applies
     int wgs = 64;                    // teams of a generation: the workgroups resident on an XCD (T = 16: 32)
+    long long nvalues = 0;           // values in tval (compact streams, blocks padded to TEAM2_VUNIT)
     long long real_entries = 0;      // union entries (filled slots)
     long long slots = 0;             // slots including the empty ones of partly filled rounds
     long long parts = 0;

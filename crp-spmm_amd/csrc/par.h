@@ -4,7 +4,11 @@
 #pragma once
 #include <algorithm>
 #include <atomic>
+#include <cstdio>
 #include <cstdlib>
+#ifdef __linux__
+#include <sched.h>
+#endif
 #include <memory>
 #include <thread>
 #include <utility>
@@ -12,12 +16,46 @@
 
 namespace crp {
 
+// CPUs this process may actually use: the affinity mask, cut by a cgroup CPU quota when there is one (a container given
+// 16 CPUs' worth of a 256-thread host reports 256 from hardware_concurrency(); 64 threads on 16 CPUs' worth of time made
+// the format builders slower, not faster).
+inline int usable_cpus()
+{
+    int n = (int) std::thread::hardware_concurrency();
+#ifdef __linux__
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0 && CPU_COUNT(&set) > 0) n = CPU_COUNT(&set);
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r"))
+    {
+        long long quota = 0, period = 0;
+        if (fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0)
+            n = std::min<long long>(n, std::max<long long>(1, (quota + period - 1) / period));
+        fclose(f);
+    }
+    else if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r"))
+    {
+        long long quota = 0, period = 100000;
+        if (fscanf(g, "%lld", &quota) == 1 && quota > 0)
+        {
+            if (FILE *h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(h, "%lld", &period) != 1) period = 100000; fclose(h); }
+            n = std::min<long long>(n, std::max<long long>(1, (quota + period - 1) / period));
+        }
+        fclose(g);
+    }
+#endif
+    return n > 0 ? n : 1;
+}
+
 inline int host_threads()
 {
     const char *e = getenv("CRPSPMM_NUM_THREADS");
     if (e == nullptr) e = getenv("OMP_NUM_THREADS");
     int n = e ? atoi(e) : 0;
-    if (n <= 0) n = (int) std::thread::hardware_concurrency();
+    if (n <= 0)
+    {
+        static const int cpus = usable_cpus();
+        n = cpus;
+    }
     if (n <= 0) n = 1;
     return std::min(n, 64);
 }

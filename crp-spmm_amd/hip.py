@@ -138,8 +138,9 @@ def team_format_host(rowptr, colidx, val):
 
 
 def team2_format_host(rowptr, colidx, val):
-    """crp_team2_format_host -> dict(nteam, waves W (8 or 16), lattice, tpanel[nteam, W], tinfo[nteam, 4], tpro[nteam, 3, W, 2],
-    trec (uint32 words), tvoff, tval[groups, 8], torder, vmap, tgrid[8, entries per XCD])."""
+    """crp_team2_format_host -> dict(nteam, waves W (8 or 16), panels_per_wave P (1; 2 with CRPSPMM_TEAM2_FORMAT_PW=2: wave w owns
+    panels tpanel[g, 2w] and tpanel[g, 2w + 1]), lattice, tpanel[nteam, W * P], tinfo[nteam, 4], tpro[nteam, 3, W, 2],
+    trec (uint32 words), tvoff (units of 4 values), tval (compact value streams), torder, vmap, tgrid[8, entries per XCD])."""
     lib = L.load()
     rp = np.ascontiguousarray(rowptr, dtype=np.int32)
     ci = np.ascontiguousarray(colidx, dtype=np.int32)
@@ -158,7 +159,8 @@ def team2_format_host(rowptr, colidx, val):
                                       C.byref(tpr), C.byref(tr), C.byref(nrw), C.byref(tv), C.byref(tval), C.byref(nve),
                                       C.byref(to), C.byref(vm)), "crp_team2_format_host")
     nt = nteam.value
-    W = int(lib.crp_team2_waves())
+    P = int(lib.crp_team2_panels_per_wave())
+    W = 8 if P == 2 else int(lib.crp_team2_waves())
     tg, ng = L.c_int_p(), C.c_int()
     L.check(lib.crp_team2_format_host_grid(C.byref(tg), C.byref(ng)), "crp_team2_format_host_grid")
 
@@ -166,10 +168,10 @@ def team2_format_host(rowptr, colidx, val):
         out = np.ctypeslib.as_array(ptr, (max(cnt, 1),))[:cnt].astype(dt).copy()
         L.c_free(C.cast(ptr, C.c_void_p))
         return out
-    return dict(nteam=nt, waves=W, lattice=bool(lat.value), tpanel=take(tp, W * nt, np.int32).reshape(nt, W),
+    return dict(nteam=nt, waves=W, panels_per_wave=P, lattice=bool(lat.value), tpanel=take(tp, W * P * nt, np.int32).reshape(nt, W * P),
                 tinfo=take(ti, 4 * nt, np.int32).reshape(nt, 4), tpro=take(tpr, 6 * W * nt, np.int32).reshape(nt, 3, W, 2),
                 trec=take(tr, nrw.value, np.uint32), tvoff=take(tv, W * nt + 1, np.int64),
-                tval=take(tval, 8 * nve.value, np.float64).reshape(-1, 8), torder=take(to, nt, np.int32),
+                tval=take(tval, nve.value, np.float64), torder=take(to, nt, np.int32),
                 vmap=take(vm, nnz, np.uint32), tgrid=take(tg, ng.value, np.int32).reshape(8, -1))
 
 

@@ -155,17 +155,24 @@ int crp_team_format_host(int nrow, const int *rowptr, const int *colidx, const d
 /* Host-only: the streams variant 5 ("team2-R8", csrc/team2_kernel.hip) consumes: teams of 8 panels of 8 rows
  * (one per wave of a 512-thread workgroup; tpanel, -1 = none), the union of whose columns is walked in rounds
  * of up to 8 slots.  tinfo[4g] = rounds of team g, [4g+1] = its first record block, [4g+2] = parts of all its
- * waves, [4g+3] = filled slots.  trec = record blocks of 8 rounds x 8 waves x 4 words: {part count | ring
- * slots, range codes (6 bits per part: code(first, len) = first*8 - first*(first-1)/2 + len - 1), value offset
- * of round r+3's parts in the wave's stream, column this wave fetches for round r+3}; tpro[((3g + d)*8 + w)*2 ..]
- * = {column, value offset} of round d < 3; wave w's value groups (8 doubles per part, rows outside the part's
- * range 0) start at tval[8 * tvoff[8g + w]]; vmap[nz] = slot in tval of CSR nonzero nz.  *nvalent = groups in
- * tval.  malloc'd copies (caller frees).  Used by the CPU tests, which replay the streams in numpy.
+ * waves, [4g+3] = filled slots.  trec = record blocks of 8 rounds x 8 waves x 4 words (csrc/panel_format.h, Team2Host):
+ * word 0 = part count | ring slots | flags | value position of part 0; word 1 = ranges (6 bits per part: first * 8 + len
+ * - 1) | value position of part 1 | size class of round r+3's value block; word 2 = offset of round r+3's value block in
+ * the wave's stream (20 bits, units of 4 values) | value positions of parts 2 and 3; word 3 = column this wave fetches for
+ * round r+3 (0x80000000: none).  tpro[((3g + d)*8 + w)*2 ..] = {column, value offset} of round d < 3.  Values are compact:
+ * a part of len rows holds len values; a round's parts form one block (padded to 4 values) of the wave's stream, which
+ * starts at tval[4 * tvoff[8g + w]]; part i's first value sits (position_i - 7 + first_i) values into the block.
+ * vmap[nz] = index in tval of CSR nonzero nz.  *nvalent = values in tval.  malloc'd copies (caller frees).  Used by the
+ * CPU tests, which replay the streams in numpy.
  * With W = crp_team2_waves() = 16 (CRPSPMM_TEAM2_WAVES=16: teams of 16 panels, one 1024-thread workgroup per CU)
  * every "8 waves / 8 slots" above reads 16: tpanel[16g + w], tpro[((3g + d)*16 + w)*2], tvoff[16g + w], record
- * blocks of 8 rounds x 16 waves x 4 words, ring slots 4 bits each from bit 4 of word 0, flags at bits 20-23
- * (W = 8: slots 3 bits each, flags at bits 16-19). */
+ * blocks of 8 rounds x 16 waves x 4 words, ring slots 4 bits each from bit 4 of word 0, flags from bit 20, part 0's
+ * value position from bit 25 (W = 8: slots 3 bits each, flags from bit 16, position from bit 21). */
 int crp_team2_waves(void);
+/* panels per wave of the streams crp_team2_format_host() builds: 1, or 2 (CRPSPMM_TEAM2_FORMAT_PW=2: teams of 16 panels on 8
+ * waves -- tpanel[(8g + w) * 2 + j], j = bank; word 0 bit 27 + i (W = 8) = bank of part i; the instance the library uses for
+ * operands of one 16-byte piece per lane, fp64 n <= 128) */
+int crp_team2_panels_per_wave(void);
 int crp_team2_format_host(int nrow, const int *rowptr, const int *colidx, const double *val, int *nteam, int *lattice,
                           int **tpanel, int **tinfo, int **tpro, unsigned **trec, long long *nrecwords,
                           long long **tvoff, double **tval, long long *nvalent, int **torder, unsigned **vmap);

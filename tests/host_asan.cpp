@@ -153,7 +153,8 @@ int main()
             for (int g = 0; g < t.nteam; g++) if (seen[(size_t) g] != 1) { printf("FAIL tgrid is not a cover\n"); return 1; }
             long long parts = 0;
             for (int g = 0; g < t.nteam; g++) parts += t.tinfo[(size_t) g * 4 + 2];
-            if (parts != t.parts || t.tvoff.back() != parts) { printf("FAIL team2 parts %lld %lld %lld\n", parts, t.parts, t.tvoff.back()); return 1; }
+            if (parts != t.parts || t.tvoff.back() * crp::TEAM2_VUNIT != t.nvalues || (long long) t.tval.size() != t.nvalues)
+            { printf("FAIL team2 parts / values %lld %lld %lld %lld\n", parts, t.parts, t.tvoff.back(), t.nvalues); return 1; }
             if (t.vmap.size() != a.ci.size()) { printf("FAIL team2 vmap\n"); return 1; }
             for (size_t p2 = 0; p2 < t.vmap.size(); p2++)
                 if (t.vmap[p2] >= t.tval.size() || t.tval[t.vmap[p2]] != a.va[p2]) { printf("FAIL team2 vmap entry %zu\n", p2); return 1; }

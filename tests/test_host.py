@@ -615,7 +615,7 @@ def _replay_team2(t, m, B, va=None):
     the column behind ring slot e of round r is what wave e fetched for that round (tpro for the first 3
     rounds, the record of round r - 3 afterwards); the parts of round r take their values from the wave's stream
     at the offset the record of round r - 3 (or tpro) announced.  W = 8 or 16 waves per team."""
-    W = t["waves"]
+    W, P = t["waves"], t.get("panels_per_wave", 1)
     sbits, fbase = (3, 16) if W == 8 else (4, 20)
     C_out = np.zeros((m, B.shape[1]))
     written = np.zeros(m, dtype=bool)
@@ -633,10 +633,11 @@ def _replay_team2(t, m, B, va=None):
                     voffs[r, w] = rec[blk0 + ((r - 3) >> 3), (r - 3) & 7, w, 2]
         parts_total = 0
         for w in range(W):
-            panel = int(t["tpanel"][g, w])
+            panels = [int(t["tpanel"][g, w * P + j]) for j in range(P)]
+            panel = max(panels)                                         # (-1 only when the wave owns nothing)
             k0 = int(t["tvoff"][W * g + w])
             k = 0
-            acc = np.zeros((8, B.shape[1]))
+            acc = np.zeros((P, 8, B.shape[1]))
             for r in range(nr):
                 x, y = int(rec[blk0 + (r >> 3), r & 7, w, 0]), int(rec[blk0 + (r >> 3), r & 7, w, 1])
                 cnt = x & 7
@@ -649,21 +650,38 @@ def _replay_team2(t, m, B, va=None):
                 assert bool(x >> (fbase + 4) & 1) == (cnt3 == 0), (g, w, r)
                 if panel < 0:
                     assert cnt == 0
+                z = int(rec[blk0 + (r >> 3), r & 7, w, 2])
                 if cnt:
-                    assert voffs[r, w] == k, (g, w, r)         # the announced offset is where the stream stands
+                    assert (voffs[r, w] & 0xFFFFF) == k, (g, w, r)         # the announced offset (units of 4 values) is where the stream stands
+                prefix = 0
                 for i in range(cnt):
                     slot = (x >> (4 + sbits * i)) & (W - 1)
-                    first, ln = _range_of_code((y >> (6 * i)) & 63)
+                    code = (y >> (6 * i)) & 63
+                    first, ln = code >> 3, (code & 7) + 1
+                    assert first + ln <= 8
+                    pos = ((x >> (fbase + 5)) & 63, (y >> 24) & 63, (z >> 20) & 63, (z >> 26) & 63)[i]
+                    assert pos == prefix + 7 - first, (g, w, r, i)
                     c = int(cols[r, slot])
                     assert 0 <= c < B.shape[0]
+                    bank = (x >> (fbase + 11 + i)) & 1
+                    assert bank < P and panels[bank] >= 0
                     for rr in range(first, first + ln):
-                        acc[rr] += t["tval"][k0 + k, rr] * B[c]
-                    k += 1
+                        # what lane rr reads: the value at (pos - 7 + rr) of the round's block
+                        acc[bank, rr] += t["tval"][4 * (k0 + k) + pos - 7 + rr] * B[c]
+                    prefix += ln
+                if r >= 3 and cnt:
+                    # the size class announced three rounds earlier covers this round's values
+                    y3 = int(rec[blk0 + ((r - 3) >> 3), (r - 3) & 7, w, 1])
+                    assert 8 * ((y3 >> 30) + 1) >= prefix > 8 * (y3 >> 30), (g, w, r)
+                k += (prefix + 3) // 4
                 parts_total += cnt
             if panel >= 0:
-                assert k0 + k == int(t["tvoff"][W * g + w + 1])
-                lo, hi = panel * 8, min(m, panel * 8 + 8)
-                C_out[lo:hi] = acc[:hi - lo]
+                assert k0 + k == int(t["tvoff"][W * g + w + 1]), (g, w)
+            for j in range(P):
+                if panels[j] < 0:
+                    continue
+                lo, hi = panels[j] * 8, min(m, panels[j] * 8 + 8)
+                C_out[lo:hi] = acc[j, :hi - lo]
                 assert not written[lo:hi].any()
                 written[lo:hi] = True
         assert parts_total == int(t["tinfo"][g, 2])
@@ -673,7 +691,7 @@ def _replay_team2(t, m, B, va=None):
     return C_out
 
 
-@pytest.mark.parametrize("order", ["default", "bisect"])
+@pytest.mark.parametrize("order", ["default", "bisect", "two-panels"])
 def test_team2_streams_replay(crp, orc, monkeypatch, order):
     """The streams of the LDS-sharing kernel (variant 5), replayed in numpy: every row is produced once and
     equals the oracle's product -- for a stride-lattice matrix (teams of 4 x 2 teeth), a random matrix (8
@@ -682,6 +700,9 @@ def test_team2_streams_replay(crp, orc, monkeypatch, order):
     if order == "bisect":
         # the recursive-bisection team order with generation-wide absolute rounds (rounds with empty slots, NOVAL records)
         monkeypatch.setenv("CRPSPMM_T2_ORDER", "bisect")
+    if order == "two-panels":
+        # teams of 16 panels on 8 waves, two panels (accumulator banks) per wave: the narrow-operand instance
+        monkeypatch.setenv("CRPSPMM_TEAM2_FORMAT_PW", "2")
     rng = np.random.default_rng(2)
     cases = []
     # pwtk-like bands (a near band of 14, two far bands of 6): the tooth-shaped lattice teams are kept

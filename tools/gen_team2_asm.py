@@ -13,8 +13,8 @@ Why a generated asm text, and why the whole loop
   * the scalar unit is the scarce resource of this kernel (one SALU issue per cycle and CU, shared by 16 waves).
     The first version tested one mask bit per row and let the compiler write the round's bookkeeping: 119 M
     scalar instructions per launch on the pwtk stand-in, and the kernel was bound by them.  Now
-      - a part names a CONTIGUOUS row range; its FMAs are straight-line code reached by one computed call: 36
-        sequences per staging buffer, each aligned to 2^SEQ bytes, entered with s_swappc_b64, left with s_setpc_b64
+      - a part names a CONTIGUOUS row range; its FMAs are straight-line code reached by one computed call: one
+        sequence per (first, length) and staging buffer, each aligned to 2^SEQ bytes, entered with s_swappc_b64, left with s_setpc_b64
         (per part: 2 x s_bfe, s_lshl, s_add, s_addc + call / return; nothing per row);
       - the loop is unrolled over the NSET = 4 ring sets, so every LDS offset of a round (ring set, value slot,
         record) is an immediate; what a round does is steered by flag bits of its record.
@@ -24,8 +24,16 @@ Record of (round r, wave w), 4 words (panel_format.h, Team2Host):
          | bit 17 TAIL (fewer than D-1 younger rounds in flight at the top of round r: wait vmcnt(0))
          | bit 18 LAST round of the team | bit 19 RECS (this wave fetches the next record block now)
          | bit 20 NOVAL (the wave has no parts in round r + D: the value DMA is issued with EXEC = 0)
-    w3 = 0x80000000 (TEAM2_NOCOL): the wave's slot of round r + D is empty, the row DMAs are issued with EXEC = 0
-    w1 : bits 6i.. range code of part i        w2 : value-stream offset of round r + D        w3 : column of round r + D
+         | bits 21-26 value position of part 0 (below)
+    w1 : bits 6i.. range of part i as first * 8 + len - 1 | bits 24-29 value position of part 1
+         | bits 30-31 size class q of the value block of round r + D: it holds at most 8 (q + 1) values
+    w2 : bits 0-19 value-stream offset of round r + D, in units of 4 values | bits 20-25, 26-31 value positions of parts 2, 3
+    w3 : column of round r + D; 0x80000000 (TEAM2_NOCOL): the wave's slot is empty, the row DMAs are issued with EXEC = 0
+Values are COMPACT: a part of len rows stores len values (round 2 stored 8 per part, zeros for the rows outside the
+range: 146 MB instead of 89 MB on the pwtk stand-in, 4.2 x the nonzeros on the nlpkkt stand-in).  A round's values
+are one block of the wave's stream (padded to 4 values), DMA'd to the wave's value slot; part i's first value sits
+prefix_i values into the block, and its "value position" is prefix_i + 7 - first_i: lane l reads the value at
+(position - 7 + (l & 7)) -- the value of row l & 7 when that row is in the range, anything readable otherwise (never used).
 Per round: [wait own DMAs of the round; s_barrier] -> issue (values: 16-lane LDS-DMA of 256 bytes; row: NV DMAs of 1
 KiB) -> read the next record -> parts: B row slice by ds_read_b128 per 16-byte piece, the part's 8 values by ONE
 ds_read_b64 (lane l holds value l & 7), call of sequence code_i: rows first..first+len-1, per row
@@ -44,22 +52,27 @@ import sys
 
 # cache policy of the B-row DMA (experiment knob at generation time): '', ' nt', ' sc0', ' sc1', ' sc0 sc1'
 BPOL = os.environ.get('T2_BPOL', '')
+# ... of the value and record DMAs (A's streams are read once)
+APOL = os.environ.get('T2_APOL', '')
 
 D = 3
 NSET = 4
 VSLOT = 256
 VBASE = 100          # fixed VGPRs: A0(4) A1(4) AV(2) B0(4) B1(4) BV(2) TA TV REC(4) TP(2: fp32 broadcast pair)
 SBASE = 84           # fixed SGPRs: pc(2) ret(2) tblA(2) tblB(2) t cnt rowbase(2) recsrc(2)
-NCODE = 36
+NCODE = 64          # sequences per staging buffer: index first * 8 + len - 1 (28 of them unused)
 NVREG = 28
 NSREG = 14
 
 
-def gen(nv, has_b1, f32=False, tw=8):
+def gen(nv, has_b1, f32=False, tw=8, pw=1):
     """nv = 16-byte pieces per lane and row; f32: 4 floats per piece (values 4 bytes, 8 per part = 32 bytes, value
     slot 128 bytes), else 2 doubles per piece (values 8 bytes, 64 bytes per part, value slot 256 bytes).
-    tw = waves (= panels = slots of a round) per team: 8, or 16 (one 1024-thread workgroup per CU; slot numbers take 4
-    bits in w0, the flags move up to bits 20-23, a record block is 2 KiB)."""
+    tw = waves (= slots of a round) per team: 8, or 16 (one 1024-thread workgroup per CU; slot numbers take 4
+    bits in w0, the flags move up to bits 20-23, a record block is 2 KiB).
+    pw = panels per wave: 1, or 2 (nv = 1 only: the narrow-operand instance -- a wave owns TWO panels, i.e. two banks of
+    accumulators, so that a team is 16 panels = 128 rows on 8 waves; every part names its bank in w0 bits fbase+11+i and
+    the call goes to that bank's copy of the sequences.  Half the rounds per row, and a B row is fetched once per 128 rows)."""
     sbits = 3 if tw == 8 else 4                     # bits of a slot number in w0
     fbase = 16 if tw == 8 else 20                   # first flag bit of w0: ISSUE, TAIL, LAST, RECS
     recrow = 16 * tw                                # bytes of the records of one round
@@ -79,7 +92,8 @@ def gen(nv, has_b1, f32=False, tw=8):
     # 2^x >= the longest sequence: fp64 8 rows x nv * 2 FMAs x 8 bytes + return; fp32 8 rows x (1 + nv * 2) x 8 bytes + return
     seq_align = {(1, False): 8, (2, False): 9, (1, True): 8, (2, True): 9}[(nv, f32)]
     opr = nv + 1                                    # DMAs a wave issues per round
-    tag = "%s%d%d%s_%%=" % ("s" if f32 else "d", nv, 1 if has_b1 else 0, "w" if tw == 16 else "")
+    assert pw == 1 or nv == 1
+    tag = "%s%d%d%s%s_%%=" % ("s" if f32 else "d", nv, 1 if has_b1 else 0, "w" if tw == 16 else "", "p" if pw == 2 else "")
     L = []
     emit = L.append
 
@@ -92,14 +106,23 @@ def gen(nv, has_b1, f32=False, tw=8):
         emit("ds_read_b128 v[%d:%d], v%d offset:%d" % (X["s0"], X["s0"] + 3, TA, koff))
         if nv == 2:
             emit("ds_read_b128 v[%d:%d], v%d offset:%d" % (X["s1"], X["s1"] + 3, TA, koff + 1024))
+        # the part's values: position field -> address (vsl = slot base - 7 values + this lane's row)
+        word, bit = (("w0", fbase + 5), ("w1", 24), ("w2", 20), ("w2", 26))[i]
+        emit("s_bfe_u32 s%d, %%[%s], 0x%x" % (T, word, (6 << 16) | bit))
+        emit("v_lshl_add_u32 v%d, s%d, %d, %%[vsl]" % (TV, T, 2 if f32 else 3))
         if f32:
-            emit("ds_read_b32 v%d, %%[vsl] offset:%d" % (X["v"], k * vslot + vgrp * i))
+            emit("ds_read_b32 v%d, v%d offset:%d" % (X["v"], TV, k * vslot))
         else:
-            emit("ds_read_b64 v[%d:%d], %%[vsl] offset:%d" % (X["v"], X["v"] + 1, k * vslot + vgrp * i))
+            emit("ds_read_b64 v[%d:%d], v%d offset:%d" % (X["v"], X["v"] + 1, TV, k * vslot))
 
     def call(i, tb):
         emit("s_bfe_u32 s%d, %%[w1], 0x%x" % (T, (6 << 16) | (6 * i)))
         emit("s_lshl_b32 s%d, s%d, %d" % (T, T, seq_align))
+        if pw == 2:
+            # the part's bank: its sequences sit 2 * NCODE further (bank 0: tables A, B; bank 1: tables A, B)
+            emit("s_bitcmp1_b32 %%[w0], %d" % (fbase + 11 + i))
+            emit("s_cselect_b32 s%d, 0x%x, 0" % (CNT, (2 * NCODE) << seq_align))
+            emit("s_add_u32 s%d, s%d, s%d" % (T, T, CNT))
         emit("s_add_u32 s%d, s%d, s%d" % (PC, tb, T))
         emit("s_addc_u32 s%d, s%d, 0" % (PC + 1, tb + 1))
         emit("s_swappc_b64 s[%d:%d], s[%d:%d]" % (RET, RET + 1, PC, PC + 1))
@@ -130,13 +153,19 @@ def gen(nv, has_b1, f32=False, tw=8):
         # -- issue for round r + D
         emit("s_bitcmp1_b32 %%[w0], %d" % fbase)
         emit("s_cbranch_scc0 .Lt2ni%d%s" % (k, tag))
-        emit("v_lshl_add_u32 v%d, %%[w2], %d, %%[lane16]" % (TV, 5 if f32 else 6))
-        # (a DMA whose EXEC is zero moves nothing but still counts in vmcnt: the wait counts of the loop stay fixed)
-        emit("s_bitcmp1_b32 %%[w0], %d" % (fbase + 4))                       # NOVAL: no parts in round r + D
-        emit("s_cselect_b64 exec, 0, 0x%x" % ((1 << (vslot // 16)) - 1))
+        emit("s_and_b32 s%d, %%[w2], 0xfffff" % T)
+        emit("v_lshl_add_u32 v%d, s%d, %d, %%[lane16]" % (TV, T, 4 if f32 else 5))      # block offset: units of 4 values
+        # lanes of the value DMA: the block's size class; a DMA whose EXEC is zero (NOVAL: no parts in round r + D)
+        # moves nothing but still counts in vmcnt: the wait counts of the loop stay fixed
+        emit("s_bfe_u32 s%d, %%[w1], 0x2001e" % T)
+        emit("s_lshl_b32 s%d, s%d, %d" % (T, T, 1 if f32 else 2))
+        emit("s_add_u32 s%d, s%d, %d" % (T, T, 2 if f32 else 4))
+        emit("s_bfm_b64 exec, s%d, 0" % T)
+        emit("s_bitcmp1_b32 %%[w0], %d" % (fbase + 4))
+        emit("s_cselect_b64 exec, 0, exec")
         emit("s_add_u32 m0, %%[vringw], %d" % (kd * vslot))
         emit("s_nop 0")
-        emit("global_load_lds_dwordx4 v%d, %%[vbase]" % TV)
+        emit("global_load_lds_dwordx4 v%d, %%[vbase]%s" % (TV, APOL))
         emit("s_cmp_lg_u32 %[w3], 0x80000000")                                 # TEAM2_NOCOL: empty slot, no row
         emit("s_cselect_b64 exec, -1, 0")
         if has_b1:
@@ -171,9 +200,9 @@ def gen(nv, has_b1, f32=False, tw=8):
         emit("s_xor_b32 %%[recdst], %%[recdst], %d" % recblk)
         emit("s_mov_b32 m0, %[recdst]")
         emit("s_nop 0")
-        emit("global_load_lds_dwordx4 %%[lane16], s[%d:%d]" % (RS, RS + 1))
+        emit("global_load_lds_dwordx4 %%[lane16], s[%d:%d]%s" % (RS, RS + 1, APOL))
         for piece in range(1, recblk // 1024):      # (an immediate offset moves the global AND the LDS address)
-            emit("global_load_lds_dwordx4 %%[lane16], s[%d:%d] offset:%d" % (RS, RS + 1, 1024 * piece))
+            emit("global_load_lds_dwordx4 %%[lane16], s[%d:%d] offset:%d%s" % (RS, RS + 1, 1024 * piece, APOL))
         emit(".Lt2nr%d%s:" % (k, tag))
         # -- record of the next round (LDS reads return in order: it is there when the parts are done)
         if k < NSET - 1:
@@ -220,13 +249,17 @@ def gen(nv, has_b1, f32=False, tw=8):
         if k == NSET - 1:
             emit("s_branch .Lt2round0%s" % tag)
     # ---- the sequences
-    for name, X in (("A", A), ("B", B)):
+    for bank, (name, X) in [(bk, nx) for bk in range(pw) for nx in (("A", A), ("B", B))]:
         code = 0
         for first in range(8):
-            for ln in range(1, 9 - first):
+            for ln in range(1, 9):
                 emit(".p2align %d" % seq_align)
-                if code == 0:
+                if code == 0 and bank == 0:
                     emit(".Lt2tab%s%s:" % (name, tag))
+                code += 1
+                if first + ln > 8:
+                    emit("s_setpc_b64 s[%d:%d]" % (RET, RET + 1))      # (no such range; never called)
+                    continue
                 for r in range(first, first + ln):
                     if f32:
                         # the row's value into every lane once, then PACKED FMAs (two floats per instruction: the fp32
@@ -237,12 +270,11 @@ def gen(nv, has_b1, f32=False, tw=8):
                         for w in range(2):
                             if f32:
                                 emit("v_pk_fma_f32 %%[a%d], v[%d:%d], v[%d:%d], %%[a%d] op_sel_hi:[1,0,1]"
-                                     % ((r * nv + v) * 2 + w, base + 2 * w, base + 2 * w + 1, TP, TP + 1, (r * nv + v) * 2 + w))
+                                     % (((bank * 8 + r) * nv + v) * 2 + w, base + 2 * w, base + 2 * w + 1, TP, TP + 1, ((bank * 8 + r) * nv + v) * 2 + w))
                             else:
                                 emit("v_fmac_f64_dpp %%[a%d], v[%d:%d], v[%d:%d] row_newbcast:%d row_mask:0xf bank_mask:0xf"
-                                     % ((r * nv + v) * 2 + w, X["v"], X["v"] + 1, base + 2 * w, base + 2 * w + 1, r))
+                                     % (((bank * 8 + r) * nv + v) * 2 + w, X["v"], X["v"] + 1, base + 2 * w, base + 2 * w + 1, r))
                 emit("s_setpc_b64 s[%d:%d]" % (RET, RET + 1))
-                code += 1
         assert code == NCODE
     emit(".Lt2done%s:" % tag)
     emit("s_waitcnt lgkmcnt(0)")                     # the record read of the round after the last one
@@ -256,12 +288,12 @@ def main():
               % (VBASE, VBASE + NVREG - 1, SBASE, SBASE + NSREG - 1))
     out.write("#define CRP_TEAM2_CLOBBERS %s, %s\n" % (", ".join('"v%d"' % r for r in range(VBASE, VBASE + NVREG)),
                                                       ", ".join('"s%d"' % r for r in range(SBASE, SBASE + NSREG))))
-    for tw in (8, 16):
+    for tw, pw in ((8, 1), (16, 1), (8, 2)):
      for f32 in (False, True):
-      for nv in (1, 2):
+      for nv in ((1, 2) if pw == 1 else (1,)):
         for hb in (0, 1):
-            out.write("#define CRP_TEAM2_LOOP_%s_NV%d_B%d%s \\\n" % ("F32" if f32 else "F64", nv, hb, "_W16" if tw == 16 else ""))
-            lines = gen(nv, bool(hb), f32, tw)
+            out.write("#define CRP_TEAM2_LOOP_%s_NV%d_B%d%s \\\n" % ("F32" if f32 else "F64", nv, hb, "_W16" if tw == 16 else ("_P2" if pw == 2 else "")))
+            lines = gen(nv, bool(hb), f32, tw, pw)
             for k, l in enumerate(lines):
                 sep = "\\n\\t" if not l.endswith(":") else "\\n"
                 last = k == len(lines) - 1
