@@ -237,13 +237,16 @@ static int team2_waves()
     return w;
 }
 
-// Panels per wave of variant 5 for operands of `pieces` 16-byte pieces per lane and row: two (teams of 16 panels = 128
-// rows on 8 waves) when one piece covers the operand -- half the rounds, barriers and records per row and a B row fetched
-// once per 128 rows instead of 64; CRPSPMM_TEAM2_PW=1 keeps one panel per wave, teams of 16 waves (CRPSPMM_TEAM2_WAVES=16)
-// have no two-panel instance.
+// Panels per wave of variant 5 for operands of `pieces` 16-byte pieces per lane and row.  CRPSPMM_TEAM2_PW=2: two (teams of 16
+// panels = 128 rows on 8 waves) when one piece covers the operand -- half the rounds, barriers and records per row and a B
+// row fetched once per 128 rows instead of 64.  Measured (profiles/r03_narrow_widths.txt, n = 128 / 96 / 64): pwtk stand-in
+// 0.210 / 0.199 / 0.193 ms against 0.225 / 0.217 / 0.206 with one panel per wave, nlpkkt stand-in 1.27 against 1.30, but the
+// Queen and shell stand-ins 8 % and 3 % slower -- below 256 columns the kernel is bound by the instructions per part, not by
+// memory (its time hardly moves from n = 64 to 128), and the second format costs its memory: one panel per wave stays the
+// default.  Teams of 16 waves (CRPSPMM_TEAM2_WAVES=16) have no two-panel instance.
 static int team2_pw(int pieces)
 {
-    static const int env = getenv("CRPSPMM_TEAM2_PW") ? atoi(getenv("CRPSPMM_TEAM2_PW")) : 2;
+    const int env = getenv("CRPSPMM_TEAM2_PW") ? atoi(getenv("CRPSPMM_TEAM2_PW")) : 1;
     return (pieces == 1 && env == 2 && team2_waves() == 8) ? 2 : 1;
 }
 

@@ -1312,7 +1312,7 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
                 if (taken[t]) continue;
                 if (target != nullptr && target[t] > to.nr + ahead) break;         // (targets ascend with t)
                 seen++;
-                const unsigned char *kk = &rk[t * (size_t) T];            // parts of every PANEL; wave of panel x = x / P
+                unsigned char *kk = &rk[t * (size_t) T];                  // parts of every PANEL; wave of panel x = x / P
                 bool fits = true;
                 for (int w = 0; w < W; w++)
                 {
@@ -1320,9 +1320,22 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
                     for (int j = 0; j < P; j++) need += kk[w * P + j];
                     if (cnt[w] + need > CAP) fits = false;
                 }
-                if (!fits) continue;
+                // With two panels per wave a column that both panels of a wave use in many separate ranges can need more
+                // than CAP parts of that wave: it can never fit.  Met in an EMPTY round it is split: the round takes the
+                // parts of the waves' first panels only, the node stays in the list with the rest and is fetched again.
+                bool split = false;
+                if (!fits && nslot == 0 && P == 2)
+                {
+                    bool alone_fits = true;
+                    for (int w = 0; w < W; w++)
+                        if (kk[w * P] + kk[w * P + 1] > CAP) alone_fits = false;
+                    split = !alone_fits;
+                }
+                if (!fits && !split) continue;
                 const int q = nodes[t];
                 for (int x = 0; x < T; x++)
+                {
+                    if (split && (x % P) != 0) continue;
                     for (int i = 0; i < kk[x]; i++)
                     {
                         const int w = x / P;
@@ -1338,10 +1351,22 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
                         cnt[w]++;
                         to.nparts++;
                     }
+                }
                 to.col[base_col + (size_t) nslot] = th.tcol[(size_t) q];
                 nslot++;
+                if (split)
+                {
+                    for (int x = 0; x < T; x += P) rk[t * (size_t) T + (size_t) x] = 0;      // (done; the second panels' parts remain)
+                    continue;
+                }
                 taken[t] = 1;
                 left--;
+            }
+            if (nslot == 0 && (target == nullptr || head >= nn || target[head] <= to.nr + ahead))
+            {
+                // (cannot happen: the first open node of an empty round always fits or is split)
+                fprintf(stderr, "[FATAL] team2 scheduler: a round placed nothing\n");
+                abort();
             }
             to.filled += nslot;
             to.nr++;

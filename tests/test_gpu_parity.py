@@ -759,6 +759,51 @@ def test_team2_bisection_order_absolute_rounds(crp, orc, gpu, monkeypatch, gsync
     A.free()
 
 
+@pytest.mark.parametrize("n", [24, 64, 100, 128])
+def test_team2_two_panels_per_wave(crp, orc, gpu, monkeypatch, n):
+    """CRPSPMM_TEAM2_PW=2: variant 5 for operands of one 16-byte piece per lane on teams of 16 panels, two panels (two
+    accumulator banks) per wave: lattice, clustered (mixed KKT teams) and random matrices -- the last with columns that need
+    more than four parts of a wave and are split over two rounds --, a second B source, value updates, fp32."""
+    import torch
+    from crp_spmm_amd import gen, hip
+    lib = crp.load()
+    monkeypatch.setenv("CRPSPMM_TEAM2_PW", "2")
+    offs = tuple(range(1, 15)) + tuple(range(304, 310)) + tuple(range(3040, 3046))
+    for name, (rp, ci, va), k in (("lattice", gen.banded_fem(9120, offsets=offs, seed=3), 9120), ("kkt", gen.kkt3d(16), 8192),
+                                   ("random", gen.random_csr(777, 1234, 40, seed=3), 1234)):
+        m = len(rp) - 1
+        B = np.random.default_rng(6).normal(size=(k, n))
+        ref = orc.spmm_csr(rp, ci, va, B)
+        A = hip.CsrDev(m, k, rp, ci, va)
+        Bd = _t(B, gpu)
+        Cd = torch.full((m, n), float("nan"), dtype=torch.float64, device=gpu)
+        hip.spmm_csr(A, Bd, Cd, n=n, variant=5)
+        torch.cuda.synchronize()
+        assert orc.rel_fro_err(ref, Cd.cpu().numpy()) <= FP64_TOL, (name, n)
+        v2 = 0.25 * va - 1.0
+        assert lib.crp_csr_dev_update_values(A.handle, v2.ctypes.data, None) == 0
+        hip.spmm_csr(A, Bd, Cd, n=n, variant=5)
+        torch.cuda.synchronize()
+        assert orc.rel_fro_err(orc.spmm_csr(rp, ci, v2, B), Cd.cpu().numpy()) <= FP64_TOL, (name, n)
+        if n % 4 == 0:
+            Cf = torch.empty((m, n), dtype=torch.float32, device=gpu)
+            hip.spmm_csr_f32(A, Bd.to(torch.float32), Cf, n=n, variant=5)
+            torch.cuda.synchronize()
+            assert orc.rel_fro_err(orc.spmm_csr(rp, ci, v2, B), Cf.cpu().numpy().astype(np.float64)) <= 1e-5, (name, n)
+        A.free()
+    rp, ci, va = gen.kkt3d(16)
+    m = len(rp) - 1
+    half = m // 2
+    two = np.where(ci < half, ci, ~(ci - half)).astype(np.int32)
+    B = np.random.default_rng(7).normal(size=(m, n))
+    A = hip.CsrDev(m, half, rp, two, va)
+    Cd = torch.full((m, n), float("nan"), dtype=torch.float64, device=gpu)
+    hip.spmm_csr(A, _t(B[:half], gpu), Cd, n=n, B1=_t(B[half:], gpu), variant=5)
+    torch.cuda.synchronize()
+    assert orc.rel_fro_err(orc.spmm_csr(rp, ci, va, B), Cd.cpu().numpy()) <= FP64_TOL
+    A.free()
+
+
 FP32_TOL = 1e-5      # fp32 path vs the fp64 oracle: relative Frobenius error (there is no fp32 reference: src/rowpara_spmm.h:28)
 
 

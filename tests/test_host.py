@@ -715,6 +715,9 @@ def test_team2_streams_replay(crp, orc, monkeypatch, order):
     # enough clustered teams (>= 128) for the bisection order and the generation-wide absolute schedule; primal rows
     # of 34 and dual rows of 7 nonzeros give teams of very different length (rounds with empty slots, idle waves)
     cases.append(("kkt",) + gen.kkt3d(16))
+    # rows with many scattered nonzeros: with two panels per wave a column can need more than 4 parts of one wave and is
+    # split over two rounds (the scheduler once looped forever on exactly this)
+    cases.append(("random40",) + gen.random_csr(777, 1234, 40, seed=3))
     cases.append(("tiny",) + gen.random_csr(13, 40, 5, seed=1))
     rp, ci, va = gen.random_csr(200, 64, 6, seed=8)
     ci2 = ci.copy()
