@@ -263,7 +263,7 @@ def measure_f32(args, matrix, mtx, steps, lib, torch, dev):
     kern_ms = float(np.mean(per_step))
     from crp_spmm_amd import gen
     alg = gen.alg_bytes(m, int(np.unique(ci).size), n, nnz, vb=4)       # A once, needed B rows once, C once, fp32 values
-    rv = int(lib.crp_csr_dev_resolved_variant(A.handle, n)) if args.variant == 0 else args.variant
+    rv = int(lib.crp_csr_dev_last_variant(A.handle))          # what the products above actually launched
     vname = lib.crp_spmm_variant_name(rv if rv in (1, 5) else 1).decode()
     ki = {"variant": rv, "variant_name": vname, "reordered": bool(lib.crp_csr_dev_reordered(A.handle)), "lattice": bool(lib.crp_csr_dev_lattice(A.handle))}
     free_b, total_b = torch.cuda.mem_get_info()

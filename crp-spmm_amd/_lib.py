@@ -134,6 +134,7 @@ SIGNATURES = {
     "crp_csr_dev_auto_variant": (_I, [_V]),
     "crp_csr_dev_reordered": (_I, [_V]),
     "crp_csr_dev_resolved_variant": (_I, [_V, _I]),
+    "crp_csr_dev_last_variant": (_I, [_V]),
     "crp_csr_dev_lattice": (_I, [_V]),
     "crp_panel_format_host": (_I, [_I, c_int_p, c_int_p, c_dbl_p, _I, c_int_p, C.POINTER(c_int_p), C.POINTER(c_int_p),
                                    C.POINTER(C.POINTER(C.c_uint)), C.POINTER(c_dbl_p), C.POINTER(_LL),
@@ -146,6 +147,7 @@ SIGNATURES = {
     "crp_team2_waves": (_I, []),
     "crp_team2_panels_per_wave": (_I, []),
     "crp_team2_format_host_grid": (_I, [C.POINTER(c_int_p), c_int_p]),
+    "crp_team2_format_host_compact": (_I, []),
     "crp_team2_format_host": (_I, [_I, c_int_p, c_int_p, c_dbl_p, c_int_p, c_int_p, C.POINTER(c_int_p), C.POINTER(c_int_p),
                                    C.POINTER(c_int_p), C.POINTER(C.POINTER(C.c_uint)), C.POINTER(_LL),
                                    C.POINTER(C.POINTER(_LL)), C.POINTER(c_dbl_p), C.POINTER(_LL), C.POINTER(c_int_p),
@@ -285,6 +287,8 @@ def load():
         try:
             fn = getattr(lib, name)
         except AttributeError:
+            if os.environ.get("CRPSPMM_LIB_LENIENT"):      # A/B runs against an older build (CRPSPMM_LIB_PATH): skip what it lacks
+                continue
             raise CrpLibraryError("%s does not export %s" % (LIB_PATH, name))
         fn.restype = res
         fn.argtypes = args

@@ -24,6 +24,11 @@ struct PanelDev
     double   *pval = nullptr;
     double    fill = 0.0;
     long long entries = 0;
+    // compact values for the narrow-operand kernel (R = 8 panels that are mostly holes; PanelHost::cmo / cbase / cval / cmap)
+    uint32_t *cmo = nullptr, *cmap = nullptr;
+    long long *cbase = nullptr;
+    double   *cval = nullptr;
+    long long cvalues = 0;
 };
 
 struct TeamDev
@@ -54,6 +59,7 @@ struct Team2Dev
     int ngrid = 0;                 // entries of torder (= the launch grid, 8 equal runs, -1 = no team)
     int tw = 8;                    // waves per team
     int pw = 1;                    // panels per wave (Team2Host::P)
+    bool compact = true;           // Team2Host::compact
     int *torder = nullptr, *tpanel = nullptr, *tinfo = nullptr, *tpro = nullptr;
     uint32_t *trec = nullptr;
     long long *tvoff = nullptr;
@@ -86,6 +92,7 @@ struct crp_csr_dev
                               // lane (fp64: n <= 128, fp32: n <= 256)
     int      auto_variant = 1; // what variant 0 resolves to below 96 columns (1 rowgroup, 2 panel R4, 3 panel R8)
     bool     team2_pays = false;   // 64 consecutive rows (in format order) share columns: variant 0 takes team2 from team2_min_n columns on
+    int      last_variant = 0;     // what the last product launched (crp_csr_dev_last_variant)
     int      team2_min_n = TEAM2_MIN_N;    // or TEAM2_MIN_N_SPARSE when the R = 8 panels are mostly holes
     long long b0_rows = 0, b1_rows = 0;   // 1 + largest local / receive-buffer row a column index addresses
     float    *val32 = nullptr;            // fp32 copy of val (fp32 path), built on first use
@@ -181,8 +188,32 @@ static int ensure_panel(crp_csr_dev *A, int idx, hipStream_t stream)
     if (e == hipSuccess) e = hipMemcpy(d.pmask4, h.pmask4.data(), sizeof(uint32_t) * h.pmask4.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess && !h.pval.empty())
         e = hipMemcpy(d.pval, h.pval.data(), sizeof(double) * h.pval.size(), hipMemcpyHostToDevice);
+    // Compact values for the narrow-operand kernel when under 60 % of the panels' (row, entry) pairs exist (n = 32, compact
+    // against full values: nlpkkt stand-in, fill 0.23: 0.527 against 0.599 ms; Queen stand-in, 0.57: 0.243 against 0.260; pwtk
+    // stand-in, 0.61: 0.068 against 0.067): CRPSPMM_NARROW_COMPACT=0 never, =1 whatever the fill
+    {
+        const char *ec = getenv("CRPSPMM_NARROW_COMPACT");
+        const bool want = idx == 1 && (ec ? atoi(ec) == 1 : d.fill < 0.6);
+        if (e == hipSuccess && want && A->nnz > 0 && crp::build_compact_values(&h))
+        {
+            d.cvalues = h.cbase.back();          // (cmap is derived from pmap, which is indexed by the caller's nonzeros already)
+            e = hipMalloc((void **) &d.cmo, sizeof(uint32_t) * (h.cmo.size() + 64));
+            if (e == hipSuccess) e = hipMemset(d.cmo, 0, sizeof(uint32_t) * (h.cmo.size() + 64));
+            if (e == hipSuccess) e = hipMemcpy(d.cmo, h.cmo.data(), sizeof(uint32_t) * h.cmo.size(), hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMalloc((void **) &d.cbase, sizeof(long long) * h.cbase.size());
+            if (e == hipSuccess) e = hipMemcpy(d.cbase, h.cbase.data(), sizeof(long long) * h.cbase.size(), hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMalloc((void **) &d.cval, sizeof(double) * h.cval.size());
+            if (e == hipSuccess) e = hipMemcpy(d.cval, h.cval.data(), sizeof(double) * h.cval.size(), hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMalloc((void **) &d.cmap, sizeof(uint32_t) * (h.cmap.size() + 1));
+            if (e == hipSuccess && !h.cmap.empty()) e = hipMemcpy(d.cmap, h.cmap.data(), sizeof(uint32_t) * h.cmap.size(), hipMemcpyHostToDevice);
+        }
+    }
     if (e != hipSuccess) return (int) e;
-    if (A->host_vals_stale && A->nnz > 0) CRP_TRY(crp::scatter_vals_f64(A->nnz, d.pmap, A->val, d.pval, stream));
+    if (A->host_vals_stale && A->nnz > 0)
+    {
+        CRP_TRY(crp::scatter_vals_f64(A->nnz, d.pmap, A->val, d.pval, stream));
+        if (d.cmap) CRP_TRY(crp::scatter_vals_f64(A->nnz, d.cmap, A->val, d.cval, stream));
+    }
     d.built = true;
     return 0;
 }
@@ -262,6 +293,14 @@ static int ensure_team2(crp_csr_dev *A, hipStream_t stream, int pw)
     crp::Team2Host th;
     th.T = pw == 2 ? 16 : team2_waves();
     th.P = pw;
+    // Value blocks: compact (only the values that exist) when under 40 % of the (row, entry) pairs of the panels exist, 8 per
+    // part otherwise -- the kernel instance for full groups decodes no value position (two instructions per part and three
+    // per round fewer): pwtk stand-in (fill 0.61) 3 % faster at n = 256 and 10 % at n = 128 than on compact values, the nlpkkt
+    // stand-in (0.23) 2-5 % slower and 13 GB larger at nlpkkt240 size.  CRPSPMM_TEAM2_COMPACT=0|1 forces.
+    {
+        const char *ec = getenv("CRPSPMM_TEAM2_COMPACT");
+        th.compact = ec ? atoi(ec) != 0 : h.fill() < 0.4;
+    }
     t.tw = th.T / pw;
     t.pw = pw;
     std::vector<int> colpos;                    // position of every row in the processing order (square, re-ordered matrices)
@@ -287,7 +326,8 @@ static int ensure_team2(crp_csr_dev *A, hipStream_t stream, int pw)
     if (e == hipSuccess) e = up((void **) &t.tinfo, th.tinfo.data(), sizeof(int) * th.tinfo.size(), 16);
     if (e == hipSuccess) e = up((void **) &t.tpro, th.tpro.data(), sizeof(int) * th.tpro.size(), 8);
     if (e == hipSuccess) e = up((void **) &t.trec, th.trec.data(), sizeof(uint32_t) * th.trec.size(), 1024);
-    t.value_entries = th.nvalues;          // values of the compact streams
+    t.value_entries = th.nvalues;          // values of the streams
+    t.compact = th.compact;
     if (e == hipSuccess) e = up((void **) &t.tvoff, th.tvoff.data(), sizeof(long long) * th.tvoff.size(), 8);
     // the kernel requests 256 bytes per wave and round: up to four groups past a wave's last part
     if (e == hipSuccess) e = up((void **) &t.tval, th.tval.data(), sizeof(double) * th.tval.size(), 4096);
@@ -628,6 +668,10 @@ int crp_csr_dev_destroy(crp_csr_dev_p *A_)
         if (A->pan[i].pmask4) (void) hipFree(A->pan[i].pmask4);
         if (A->pan[i].pmap) (void) hipFree(A->pan[i].pmap);
         if (A->pan[i].pval) (void) hipFree(A->pan[i].pval);
+        if (A->pan[i].cmo) (void) hipFree(A->pan[i].cmo);
+        if (A->pan[i].cbase) (void) hipFree(A->pan[i].cbase);
+        if (A->pan[i].cval) (void) hipFree(A->pan[i].cval);
+        if (A->pan[i].cmap) (void) hipFree(A->pan[i].cmap);
     }
     if (A->team.torder) (void) hipFree(A->team.torder);
     if (A->team.tpanel) (void) hipFree(A->team.tpanel);
@@ -683,7 +727,10 @@ int crp_csr_dev_update_values(crp_csr_dev_p A, const double *val, void *stream)
     else A->host_vals_stale = true;      // formats built later are refreshed from the device CSR (ensure_*)
     for (int i = 0; i < 2; i++)
         if (A->pan[i].built)
+        {
             CRP_TRY(crp::scatter_vals_f64(A->nnz, A->pan[i].pmap, A->val, A->pan[i].pval, (hipStream_t) stream));
+            if (A->pan[i].cmap) CRP_TRY(crp::scatter_vals_f64(A->nnz, A->pan[i].cmap, A->val, A->pan[i].cval, (hipStream_t) stream));
+        }
     if (A->team.built) CRP_TRY(crp::scatter_vals_f64(A->nnz, A->team.tmap, A->val, A->team.tval, (hipStream_t) stream));
     for (Team2Dev *t2 : {&A->team2, &A->team2p})
         if (t2->built) CRP_TRY(crp::scatter_vals_f64(A->nnz, t2->tmap, A->val, t2->tval, (hipStream_t) stream));
@@ -763,12 +810,13 @@ int crp_spmm_csr_f64(crp_csr_dev_p A, int layout, int n, const double *B0, long 
     if (v == 5)
     {
         a.rowmap = fmt_map;
+        A->last_variant = 5;
         const int pw = team2_pw(n > 128 ? 2 : 1);
         const int rc = ensure_team2(A, (hipStream_t) stream, pw);
         if (rc != 0) return rc;
         const Team2Dev &d = pw == 2 ? A->team2p : A->team2;
         crp::Team2Args t;
-        t.nteam = d.nteam; t.ngrid = d.ngrid; t.tw = d.tw; t.pw = d.pw; t.torder = d.torder; t.tpanel = d.tpanel; t.tinfo = d.tinfo;
+        t.nteam = d.nteam; t.ngrid = d.ngrid; t.tw = d.tw; t.pw = d.pw; t.compact = d.compact; t.torder = d.torder; t.tpanel = d.tpanel; t.tinfo = d.tinfo;
         t.tpro = d.tpro; t.trec = d.trec; t.tvoff = d.tvoff; t.tval = d.tval; t.tval32 = nullptr;
         t.gsync = d.gsync; t.gsync_tiles = d.gsync_tiles; t.gsync_ngen = d.gsync_ngen; t.wgs = d.wgs;
         for (int x = 0; x < 8; x++) t.nreal[x] = d.nreal[x];
@@ -776,6 +824,7 @@ int crp_spmm_csr_f64(crp_csr_dev_p A, int layout, int n, const double *B0, long 
     }
     if (v == 4 && (!crp::spmm_team_applicable(a) || A->b1_rows > 0)) v = 3;   // team kernel: one B source, 256-column tile
     if (v >= 2 && (!crp::spmm_panel_applicable(a) || A->nnz == 0)) v = 1;   // narrow / unaligned operands
+    A->last_variant = v;
     if (v == 4)
     {
         a.rowmap = fmt_map;
@@ -796,6 +845,9 @@ int crp_spmm_csr_f64(crp_csr_dev_p A, int layout, int n, const double *B0, long 
         memset(&p, 0, sizeof(p));
         p.R = d.R; p.npanel = d.npanel; p.pptr = d.pptr; p.porder = d.porder; p.norder = d.norder; p.team_waves = d.team_waves; p.psync = d.psync; p.pcol = d.pcol; p.pmask4 = d.pmask4; p.pval = d.pval;
         p.b0_rows = A->b0_rows; p.b1_rows = A->b1_rows;
+        p.cmo = d.cmo; p.cbase = d.cbase; p.cval = d.cval;
+        p.narrow64 = false;                    // (the two-piece instance loses to the row-panel kernel even on compact values: nlpkkt
+                                               //  stand-in n = 64 1.36 against 1.13 ms, pwtk stand-in 0.135 against 0.119; CRPSPMM_NARROW_MAX=64 forces it)
         e = crp::spmm_rm_f64_panel(p, a, (hipStream_t) stream);
     }
     else e = crp::spmm_rm_f64_rowgroup(a, (hipStream_t) stream);
@@ -822,6 +874,7 @@ int crp_spmm_csr_f32(crp_csr_dev_p A, int n, const float *B0, long long ldB0, co
     a.B0 = B0; a.ldB0 = ldB0; a.B1 = B1; a.ldB1 = ldB1; a.C = C; a.ldC = ldC; a.rowmap = A->rowmap;
     const bool team = (variant == 5 || (variant == 0 && A->team2_pays && n >= TEAM2_MIN_N_F32)) && A->nnz > 0 && A->nrow >= 8 &&
                       crp::spmm_team2_applicable_f32(a);
+    A->last_variant = team ? 5 : 1;
     if (!team) return (int) crp::spmm_rm_f32_rowgroup(a, (hipStream_t) stream);
     const int pw = team2_pw(n > 256 ? 2 : 1);
     const int rc = ensure_team2(A, (hipStream_t) stream, pw);
@@ -835,7 +888,7 @@ int crp_spmm_csr_f32(crp_csr_dev_p A, int n, const float *B0, long long ldB0, co
     }
     if (A->rowmap_fmt != nullptr) a.rowmap = A->rowmap_fmt;
     crp::Team2Args t;
-    t.nteam = d.nteam; t.ngrid = d.ngrid; t.tw = d.tw; t.pw = d.pw; t.torder = d.torder; t.tpanel = d.tpanel; t.tinfo = d.tinfo;
+    t.nteam = d.nteam; t.ngrid = d.ngrid; t.tw = d.tw; t.pw = d.pw; t.compact = d.compact; t.torder = d.torder; t.tpanel = d.tpanel; t.tinfo = d.tinfo;
     t.tpro = d.tpro; t.trec = d.trec; t.tvoff = d.tvoff; t.tval = d.tval; t.tval32 = d.tval32;
     t.gsync = d.gsync; t.gsync_tiles = d.gsync_tiles; t.gsync_ngen = d.gsync_ngen; t.wgs = d.wgs;
     for (int x = 0; x < 8; x++) t.nreal[x] = d.nreal[x];
@@ -852,6 +905,7 @@ int crp_csr_dev_resolved_variant(crp_csr_dev_p A, int n)
     if (A->team2_pays && n >= A->team2_min_n && (n % 2 == 0)) v = 5;
     return v;
 }
+int crp_csr_dev_last_variant(crp_csr_dev_p A) { return A ? A->last_variant : -1; }
 int crp_csr_dev_lattice(crp_csr_dev_p A) { return A ? ((A->team2.built && A->team2.lattice) || (A->team2p.built && A->team2p.lattice) || (A->team.built && A->team.lattice) ? 1 : 0) : -1; }
 
 int crp_panel_format_host(int nrow, const int *rowptr, const int *colidx, const double *val, int R, int *npanel,
@@ -909,6 +963,8 @@ int crp_team2_panels_per_wave(void) { return getenv("CRPSPMM_TEAM2_FORMAT_PW") &
 int crp_team2_waves(void) { return team2_waves(); }
 
 static std::vector<int> g_last_tgrid;       // launch grid of the last crp_team2_format_host() (planning / test helper)
+static int g_last_compact = 1;              // ... and whether its value blocks are compact
+int crp_team2_format_host_compact(void) { return g_last_compact; }
 int crp_team2_format_host_grid(int **tgrid, int *ngrid)
 {
     if (tgrid == NULL || ngrid == NULL) return -1;
@@ -933,7 +989,9 @@ int crp_team2_format_host(int nrow, const int *rowptr, const int *colidx, const 
     const int pw = crp_team2_panels_per_wave();
     th.T = pw == 2 ? 16 : team2_waves();
     th.P = pw;
+    th.compact = getenv("CRPSPMM_TEAM2_COMPACT") ? atoi(getenv("CRPSPMM_TEAM2_COMPACT")) != 0 : h.fill() < 0.4;
     crp::build_team2(h, nrow, rowptr, colidx, &th);
+    g_last_compact = th.compact ? 1 : 0;
     clk.lap("crp_team2_format_host: build_team2");
     g_last_tgrid = th.tgrid;
     *nteam = th.nteam;

@@ -52,6 +52,11 @@ struct PanelArgs
     const double   *pval;
     long long       b0_rows;   // rows of B0 / B1 the column indices can address (for the 4 GiB check)
     long long       b1_rows;
+    // compact values (PanelHost::cmo / cbase / cval), or nullptr: the narrow-operand kernel reads them instead of pmask4 / pval
+    const uint32_t *cmo;
+    const long long *cbase;
+    const double   *cval;
+    bool            narrow64;  // take the narrow-operand kernel up to 64 columns (panels that are mostly holes)
 };
 
 struct TeamArgs
@@ -71,6 +76,7 @@ struct Team2Args          // panel_format.h, Team2Host
     int nteam;
     int ngrid;                 // entries of torder: the launch grid (Team2Host::tgrid), a multiple of 8
     int tw;                    // waves per team: 8 or 16
+    bool compact;              // value blocks hold only the values that exist (Team2Host::compact); false: 8 per part
     int pw;                    // panels per wave: 1, or 2 (Team2Host::P: teams of 16 panels on 8 waves, operands of one 16-byte piece)
     const int      *torder;
     const int      *tpanel;    // tw * pw * nteam

@@ -36,10 +36,15 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 // OFF32: B0 alone and smaller than 4 GiB -- every lane multiplies ITS column by the row stride once per 64 entries and
 // the 32-bit byte offsets travel through ds_bpermute like the masks (the 64-bit multiply per step and lane group of the
 // general path was 84 of its 230 vector cycles per step).
-template <int NP, bool HAS_B1, bool OFF32>
+// COMPACT: the panels' values are stored without the holes (PanelHost::cmo / cbase / cval): pmask4 then points at one word per
+// entry -- row mask | (index of the entry's first value inside the panel) << 8 -- and pval at the compact values; a lane
+// finds its row's value at the entry's offset + the number of mask bits below its row.  For panels that are mostly holes (the
+// nlpkkt stand-in: 23 % of the (row, entry) pairs exist) A shrinks from 69 to ≈ 21 bytes per entry -- at n = 32 A was 60 % of
+// everything the kernel reads.
+template <int NP, bool HAS_B1, bool OFF32, bool COMPACT>
 __global__ __launch_bounds__(256, NP == 2 ? 4 : 7) void spmm_narrow_f64_kernel(
     const int norder, const int nrow, const int n, const int *__restrict__ porder, const int *__restrict__ pcol,
-    const uint32_t *__restrict__ pmask4, const double *__restrict__ pval,
+    const uint32_t *__restrict__ pmask4, const double *__restrict__ pval, const long long *__restrict__ cbase,
     const double *__restrict__ B0, const int64_t ldB0, const double *__restrict__ B1, const int64_t ldB1,
     double *__restrict__ C, const int64_t ldC, const int *__restrict__ rowmap)
 {
@@ -67,6 +72,8 @@ __global__ __launch_bounds__(256, NP == 2 ? 4 : 7) void spmm_narrow_f64_kernel(
         bo[p] = ok[p] ? 32 * p + 2 * l : 0;
     }
     const uint8_t *pmask = reinterpret_cast<const uint8_t *>(pmask4);
+    const double *const vpanel = COMPACT ? pval + cbase[panel] : pval;       // compact: the panel's first value
+    const int myrow = lane & 7;
     double a[16 * NP];
 #pragma unroll
     for (int i = 0; i < 16 * NP; i++) a[i] = 0.0;
@@ -76,7 +83,7 @@ __global__ __launch_bounds__(256, NP == 2 ? 4 : 7) void spmm_narrow_f64_kernel(
     const int sh0 = q * 4;                                                  // ds_bpermute address of lane q
     auto fetch = [&](const int mycol, const int mymask, const int ebase, const int s, double &v, d2 (&b)[NP], int &mk) {
         const int src = s * G + q;
-        v = pval[(size_t) (ebase + src) * 8 + (size_t) (lane & 7)];
+        if constexpr (!COMPACT) v = pval[(size_t) (ebase + src) * 8 + (size_t) (lane & 7)];
         if constexpr (OFF32)
         {
             const int idx = sh0 + s * (G * 4);
@@ -92,6 +99,15 @@ __global__ __launch_bounds__(256, NP == 2 ? 4 : 7) void spmm_narrow_f64_kernel(
             const double *brow = (!HAS_B1 || col >= 0) ? (B0 + (int64_t) col * ldB0) : (B1 + (int64_t) (~col) * ldB1);
 #pragma unroll
             for (int p = 0; p < NP; p++) b[p] = *reinterpret_cast<const d2 *>(brow + bo[p]);
+        }
+        if constexpr (COMPACT)
+        {
+            // mk = row mask | value offset << 8: this lane's row is the (bits below it)-th value of the entry.  A row the
+            // entry lacks reads a neighbouring value (inside the panel's values, or the 16 pad values after the last): never used
+            const uint32_t word = (uint32_t) mk;
+            mk = (int) (word & 0xFFu);
+            const uint32_t rank = (uint32_t) __builtin_popcount(word & ((1u << myrow) - 1u));
+            v = vpanel[(word >> 8) + rank];
         }
     };
     // One step (narrow_rows.inc): the eight row masks of the lanes' entries first (vector compares into SGPR pairs, EXEC
@@ -114,7 +130,7 @@ __global__ __launch_bounds__(256, NP == 2 ? 4 : 7) void spmm_narrow_f64_kernel(
         const int ce = min(64, nent - base);                               // uniform, a multiple of 8
         int mycol = (lane < ce) ? pcol[e0 + base + lane] : 0;
         if constexpr (OFF32) mycol = (int) ((uint32_t) mycol * ld32);
-        const int mymask = (lane < ce) ? (int) pmask[e0 + base + lane] : 0;
+        const int mymask = (lane < ce) ? (COMPACT ? (int) pmask4[e0 + base + lane] : (int) pmask[e0 + base + lane]) : 0;
         const int nstep = ce / G;                                          // even
         // NP = 1: two steps per iteration, their loads in flight together (the compiler's wait before an asm statement
         // cannot be counted across the loop's back edge, so a deeper software pipeline would not overlap anything).
@@ -167,11 +183,12 @@ __global__ __launch_bounds__(256, NP == 2 ? 4 : 7) void spmm_narrow_f64_kernel(
 bool spmm_narrow_applicable(const PanelArgs &p, const SpmmArgs &a)
 {
     static const bool on = getenv("CRPSPMM_NARROW") == NULL || atoi(getenv("CRPSPMM_NARROW")) != 0;
-    // (NP = 2, i.e. 32 < n <= 64, is built but not chosen: 128 VGPRs leave four waves per SIMD with one step in flight
-    //  each -- pwtk stand-in n = 64: 0.168 ms against 0.117 for the row-panel kernel; with 32 lanes per entry and two
-    //  entries per instruction it was 0.115: no gain either; at five waves per SIMD (96 VGPRs, the epilogue's sums
-    //  spilled) 0.209.  CRPSPMM_NARROW_MAX=64 selects it.)
-    static const int nmax = getenv("CRPSPMM_NARROW_MAX") ? atoi(getenv("CRPSPMM_NARROW_MAX")) : 32;
+    // (NP = 2, i.e. 32 < n <= 64, is built but not chosen on the full-value format: 128 VGPRs leave four waves per SIMD with
+    //  one step in flight each -- pwtk stand-in n = 64: 0.168 ms against 0.117 for the row-panel kernel; with 32 lanes per
+    //  entry and two entries per instruction it was 0.115: no gain either; at five waves per SIMD (96 VGPRs, the epilogue's
+    //  sums spilled) 0.209.  CRPSPMM_NARROW_MAX=64 selects it; p.narrow64 = panels that are mostly holes, on compact values.)
+    const int nmax_env = getenv("CRPSPMM_NARROW_MAX") ? atoi(getenv("CRPSPMM_NARROW_MAX")) : 0;
+    const int nmax = nmax_env > 0 ? nmax_env : (p.narrow64 && p.cmo != nullptr ? 64 : 32);
     return on && p.R == 8 && p.team_waves == 4 && a.n >= 24 && a.n <= nmax && a.n <= 64 && (a.n % 2 == 0) && (a.ldB0 % 2 == 0) && (a.ldC % 2 == 0) &&
            (a.B1 == nullptr || a.ldB1 % 2 == 0) && (((uintptr_t) a.B0 | (uintptr_t) a.B1 | (uintptr_t) a.C) % 16 == 0);
 }
@@ -183,11 +200,20 @@ hipError_t spmm_rm_f64_narrow(const PanelArgs &p, const SpmmArgs &a, hipStream_t
     const bool has_b1 = a.B1 != nullptr && p.b1_rows > 0;
     // 32-bit byte offsets: B0 alone, every addressed byte below 4 GiB
     const bool off32 = !has_b1 && (uint64_t) p.b0_rows * (uint64_t) a.ldB0 * 8ull < (1ull << 32);
-#define CRP_NARROW_GO(NP_, HB1_, O32_)                                                                                           \
-    hipLaunchKernelGGL((spmm_narrow_f64_kernel<NP_, HB1_, O32_>), grid, dim3(256), 0, s, p.norder, a.nrow, a.n, p.porder, p.pcol, \
-                       p.pmask4, p.pval, a.B0, a.ldB0, a.B1, a.ldB1, a.C, a.ldC, a.rowmap)
-    if (a.n <= 32) { if (has_b1) CRP_NARROW_GO(1, true, false); else if (off32) CRP_NARROW_GO(1, false, true); else CRP_NARROW_GO(1, false, false); }
-    else           { if (has_b1) CRP_NARROW_GO(2, true, false); else if (off32) CRP_NARROW_GO(2, false, true); else CRP_NARROW_GO(2, false, false); }
+    const bool compact_on = getenv("CRPSPMM_NARROW_COMPACT") == NULL || atoi(getenv("CRPSPMM_NARROW_COMPACT")) != 0;
+    const bool compact = compact_on && p.cmo != nullptr && p.cbase != nullptr && p.cval != nullptr;
+#define CRP_NARROW_GO(NP_, HB1_, O32_, CP_)                                                                                            \
+    hipLaunchKernelGGL((spmm_narrow_f64_kernel<NP_, HB1_, O32_, CP_>), grid, dim3(256), 0, s, p.norder, a.nrow, a.n, p.porder, p.pcol, \
+                       CP_ ? p.cmo : p.pmask4, CP_ ? p.cval : p.pval, p.cbase, a.B0, a.ldB0, a.B1, a.ldB1, a.C, a.ldC, a.rowmap)
+#define CRP_NARROW_PICK(NP_)                                                                                                     \
+    do                                                                                                                           \
+    {                                                                                                                            \
+        if (compact) { if (has_b1) CRP_NARROW_GO(NP_, true, false, true); else if (off32) CRP_NARROW_GO(NP_, false, true, true); else CRP_NARROW_GO(NP_, false, false, true); } \
+        else { if (has_b1) CRP_NARROW_GO(NP_, true, false, false); else if (off32) CRP_NARROW_GO(NP_, false, true, false); else CRP_NARROW_GO(NP_, false, false, false); }     \
+    } while (0)
+    if (a.n <= 32) CRP_NARROW_PICK(1);
+    else CRP_NARROW_PICK(2);
+#undef CRP_NARROW_PICK
 #undef CRP_NARROW_GO
     return hipGetLastError();
 }

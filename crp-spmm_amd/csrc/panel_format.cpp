@@ -83,6 +83,61 @@ double PanelHost::fill() const
     return real_entries > 0 ? (double) nnz / ((double) real_entries * R) : 1.0;
 }
 
+bool build_compact_values(PanelHost *p)
+{
+    if (p->R != 8) return false;
+    const int np = p->npanel;
+    auto mask_of = [&](size_t q) { return (p->pmask4[q >> 2] >> (8 * (q & 3))) & 0xFFu; };
+    p->cbase.assign((size_t) np + 1, 0);
+    std::vector<long long> cnt((size_t) np, 0);
+    bool fits = true;
+    parallel_chunks(np, 4096, [&](long long b, long long e, int) {
+        for (long long pn = b; pn < e; pn++)
+        {
+            long long c = 0;
+            for (int q = p->pptr[(size_t) pn]; q < p->pptr[(size_t) pn + 1]; q++) c += __builtin_popcount(mask_of((size_t) q));
+            cnt[(size_t) pn] = c;
+        }
+    });
+    for (int pn = 0; pn < np; pn++)
+    {
+        if (cnt[(size_t) pn] >= (1LL << 24)) fits = false;
+        p->cbase[(size_t) pn + 1] = p->cbase[(size_t) pn] + cnt[(size_t) pn];
+    }
+    const long long total = p->cbase[(size_t) np];
+    if (!fits || total >= (1LL << 32)) { p->cbase.clear(); return false; }
+    const size_t nent = p->pcol.size();
+    p->cmo.resize(nent);
+    parallel_fill(p->cval, (size_t) total + 16, 0.0);
+    big_vector<uint32_t> ebase;                       // absolute index of every entry's first value
+    ebase.resize(nent);
+    parallel_chunks(np, 4096, [&](long long b, long long e, int) {
+        for (long long pn = b; pn < e; pn++)
+        {
+            long long off = 0;
+            for (int q = p->pptr[(size_t) pn]; q < p->pptr[(size_t) pn + 1]; q++)
+            {
+                const unsigned m = mask_of((size_t) q);
+                p->cmo[(size_t) q] = m | ((uint32_t) off << 8);
+                ebase[(size_t) q] = (uint32_t) (p->cbase[(size_t) pn] + off);
+                for (int r = 0; r < 8; r++)
+                    if ((m >> r) & 1u) p->cval[(size_t) (p->cbase[(size_t) pn] + off++)] = p->pval[(size_t) q * 8 + (size_t) r];
+            }
+        }
+    });
+    p->cmap.resize(p->pmap.size());
+    parallel_chunks((long long) p->pmap.size(), 1 << 18, [&](long long b, long long e, int) {
+        for (long long nz = b; nz < e; nz++)
+        {
+            const uint32_t sl = p->pmap[(size_t) nz];
+            const size_t q = sl >> 3;
+            const unsigned r = sl & 7u;
+            p->cmap[(size_t) nz] = ebase[q] + (uint32_t) __builtin_popcount(mask_of(q) & ((1u << r) - 1u));
+        }
+    });
+    return true;
+}
+
 long long count_panel_entries(int nrow, const int *rowptr, const int *colidx, int R)
 {
     const int npanel = (nrow + R - 1) / R;
@@ -1199,11 +1254,18 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
     const int P = (out->P == 2 && T == 16) ? 2 : 1;                         // panels of a wave
     const int W = T / P;                                                    // waves of a team = slots of a round
     out->P = P;
+    const bool compact = out->compact || T != TEAM2_T || P != 1;            // (only the default geometry has a full-group instance)
+    out->compact = compact;
     const int sbits = W == 16 ? 4 : 3, fbase = W == 16 ? 20 : 16;          // slot bits and first flag bit of record word 0
     const size_t blkw = (size_t) 32 * W;                                    // words of a record block (8 rounds x W waves x 4)
     PhaseClock clk;
     TeamHost th;
-    build_teams(p, nrow, rowptr, colidx, &th, T, colpos, !phase_env());
+    // The balanced passes of build_teams break the ties of the phase key (a lattice team has twenty nodes per key value): in
+    // plain column order the nodes of one wave come in runs, the rounds then hold four parts of one wave and none of another,
+    // and a round lasts as long as its busiest wave -- pwtk stand-in 0.304 -> 0.315 ms at n = 256, 0.199 -> 0.210 at n = 128
+    // (CRPSPMM_T2_BALANCED=0; it saves 1.5 s of a 17-s build at nlpkkt240 size).
+    const bool balanced_env = getenv("CRPSPMM_T2_BALANCED") == NULL || atoi(getenv("CRPSPMM_T2_BALANCED")) != 0;
+    build_teams(p, nrow, rowptr, colidx, &th, T, colpos, !phase_env() || balanced_env);
     clk.lap("build_team2: build_teams total");
     // Phase key of a union entry: (position of its B row in the processing order) mod S, S = rows a team advances
     // along its sweep (8 x the consecutive panels of a lattice team, 64 for eight consecutive panels).  Teams are
@@ -1266,10 +1328,12 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
     // List scheduler of one team: `nodes` in the order they are to be met; target (optional) = the earliest round of
     // every node (absolute schedule: a round takes only nodes whose target has come, and stays partly or wholly empty
     // otherwise); <= T slots per round, <= CAP parts per wave and round, look-ahead 4 T nodes.
-    // Empty slots carry TEAM2_NOCOL: the kernel fetches nothing for them.
+    // Empty slots are marked TEAM2_NOCOL here and written to the records as a row of the team (a fetch nobody reads).
     // CRPSPMM_T2_AHEAD: rounds a team may take a node before its target (fills the slots its own share of a round leaves
     // empty; a line survives about four rounds in L2, so one round of slack costs no hit)
     const int ahead = getenv("CRPSPMM_T2_AHEAD") ? atoi(getenv("CRPSPMM_T2_AHEAD")) : 1;
+    const int loadcap = getenv("CRPSPMM_T2_LOADCAP") ? atoi(getenv("CRPSPMM_T2_LOADCAP")) : 0;
+    const bool load_aware = getenv("CRPSPMM_T2_SCHED") != NULL && strcmp(getenv("CRPSPMM_T2_SCHED"), "load") == 0;
     auto schedule_team = [&](int g, const std::vector<int> &nodes, const int *target) {
         TeamOut &to = res[(size_t) g];
         to.anycol = nodes.empty() ? 0 : th.tcol[(size_t) nodes[0]];
@@ -1298,8 +1362,8 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
         }
         while (left > 0)
         {
-            int cnt[TMAX];
-            for (int w = 0; w < TMAX; w++) cnt[w] = 0;
+            int cnt[TMAX], wload[TMAX];
+            for (int w = 0; w < TMAX; w++) cnt[w] = wload[w] = 0;
             int nslot = 0;
             const size_t base_col = to.col.size();
             to.col.resize(base_col + (size_t) W, TEAM2_NOCOL);
@@ -1307,6 +1371,75 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
             to.ownc.resize(to.ownc.size() + (size_t) W, 0);
             while (head < nn && taken[head]) head++;
             int seen = 0;
+            if (load_aware)
+            {
+                // CRPSPMM_T2_SCHED=load: of the open nodes in the look-ahead window the one that leaves the busiest wave of the
+                // round least busy (a part costs about 3 row-FMAs of overhead plus its rows); ties: the earliest
+                int load[TMAX];
+                for (int w = 0; w < TMAX; w++) load[w] = 0;
+                while (nslot < W)
+                {
+                    long best = -1;
+                    int best_max = 1 << 30, best_sum = 1 << 30, look = 0;
+                    for (size_t t = head; t < nn && look < 4 * W; t++)
+                    {
+                        if (taken[t]) continue;
+                        if (target != nullptr && target[t] > to.nr + ahead) break;
+                        look++;
+                        const unsigned char *kk = &rk[t * (size_t) T];
+                        bool fits = true;
+                        int mx = 0, sum = 0;
+                        for (int w = 0; w < W; w++)
+                        {
+                            int need = 0, work = 0;
+                            for (int j = 0; j < P; j++)
+                            {
+                                need += kk[w * P + j];
+                                for (int i = 0; i < kk[w * P + j]; i++) work += 3 + (rr[(t * (size_t) T + (size_t) (w * P + j)) * 4 + (size_t) i] & 15);
+                            }
+                            if (cnt[w] + need > CAP) fits = false;
+                            mx = std::max(mx, load[w] + work);
+                            sum += work;
+                        }
+                        if (!fits) continue;
+                        if (mx < best_max || (mx == best_max && sum > best_sum && false)) { best = (long) t; best_max = mx; best_sum = sum; }
+                    }
+                    if (best < 0) break;
+                    const size_t t = (size_t) best;
+                    const unsigned char *kk = &rk[t * (size_t) T];
+                    const int q = nodes[t];
+                    for (int x = 0; x < T; x++)
+                        for (int i = 0; i < kk[x]; i++)
+                        {
+                            const int w = x / P;
+                            const unsigned char b = rr[(t * (size_t) T + (size_t) x) * 4 + (size_t) i];
+                            Part pt;
+                            pt.first = b >> 4;
+                            pt.len = b & 15;
+                            pt.slot = nslot;
+                            pt.src = th.tsrc[(size_t) q * T + (size_t) x];
+                            pt.bank = x % P;
+                            to.ownp[((size_t) to.nr * W + (size_t) w) * CAP + (size_t) cnt[w]] = pt;
+                            to.ownc[(size_t) to.nr * W + (size_t) w]++;
+                            cnt[w]++;
+                            load[w] += 3 + pt.len;
+                            to.nparts++;
+                        }
+                    to.col[base_col + (size_t) nslot] = th.tcol[(size_t) q];
+                    nslot++;
+                    taken[t] = 1;
+                    left--;
+                    while (head < nn && taken[head]) head++;
+                }
+                if (nslot > 0 || P != 2)
+                {
+                    if (nslot == 0 && (target == nullptr || head >= nn || target[head] <= to.nr + ahead)) { fprintf(stderr, "[FATAL] team2 scheduler: a round placed nothing\n"); abort(); }
+                    to.filled += nslot;
+                    to.nr++;
+                    continue;
+                }
+                // (P = 2 and nothing fits an empty round: the splitting path below)
+            }
             for (size_t t = head; t < nn && nslot < W && seen < 4 * W; t++)
             {
                 if (taken[t]) continue;
@@ -1316,9 +1449,16 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
                 bool fits = true;
                 for (int w = 0; w < W; w++)
                 {
-                    int need = 0;
-                    for (int j = 0; j < P; j++) need += kk[w * P + j];
+                    int need = 0, work = 0;
+                    for (int j = 0; j < P; j++)
+                    {
+                        need += kk[w * P + j];
+                        if (loadcap > 0)
+                            for (int i = 0; i < kk[w * P + j]; i++) work += 3 + (rr[(t * (size_t) T + (size_t) (w * P + j)) * 4 + (size_t) i] & 15);
+                    }
                     if (cnt[w] + need > CAP) fits = false;
+                    // CRPSPMM_T2_LOADCAP: a wave takes no more work in a round than this (a part = 3 + its rows), unless the round is empty
+                    if (loadcap > 0 && nslot > 0 && wload[w] + work > loadcap && work > 0) fits = false;
                 }
                 // With two panels per wave a column that both panels of a wave use in many separate ranges can need more
                 // than CAP parts of that wave: it can never fit.  Met in an EMPTY round it is split: the round takes the
@@ -1349,6 +1489,7 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
                         to.ownp[((size_t) to.nr * W + (size_t) w) * CAP + (size_t) cnt[w]] = pt;
                         to.ownc[(size_t) to.nr * W + (size_t) w]++;
                         cnt[w]++;
+                        wload[w] += 3 + pt.len;
                         to.nparts++;
                     }
                 }
@@ -1483,7 +1624,7 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
     auto round_units = [&](const TeamOut &to, int r, int w) {
         int nv = 0;
         const Part *ow = &to.ownp[((size_t) r * W + (size_t) w) * CAP];
-        for (int i = 0; i < (int) to.ownc[(size_t) r * W + (size_t) w]; i++) nv += ow[i].len;
+        for (int i = 0; i < (int) to.ownc[(size_t) r * W + (size_t) w]; i++) nv += compact ? ow[i].len : 8;
         return (nv + TEAM2_VUNIT - 1) / TEAM2_VUNIT;
     };
     {
@@ -1546,7 +1687,7 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
                 {
                     const Part *ow = &to.ownp[((size_t) r * W + (size_t) w) * CAP];
                     int nv = 0;
-                    for (int i = 0; i < (int) to.ownc[(size_t) r * W + (size_t) w]; i++) nv += ow[i].len;
+                    for (int i = 0; i < (int) to.ownc[(size_t) r * W + (size_t) w]; i++) nv += compact ? ow[i].len : 8;
                     nvals[(size_t) r] = nv;
                     voff[(size_t) r + 1] = voff[(size_t) r] + (nv + TEAM2_VUNIT - 1) / TEAM2_VUNIT;
                 }
@@ -1564,7 +1705,9 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
                         const Part &pt = ow[i];
                         x |= (uint32_t) pt.slot << (4 + sbits * (int) i);
                         y |= (uint32_t) (pt.first * 8 + pt.len - 1) << (6 * i);
-                        // value position of the part: prefix + 7 - first (tools/gen_team2_asm.py)
+                        // value position of the part: prefix + 7 - first (tools/gen_team2_asm.py); full groups: the part's 8
+                        // values start at 8 i, row r at 8 i + r, i.e. "prefix" = 8 i + first
+                        if (!compact) prefix = 8 * (int) i + pt.first;
                         const uint32_t pos = (uint32_t) (prefix + 7 - pt.first);
                         x |= (uint32_t) pt.bank << (fbase + 11 + (int) i);       // which of the wave's panels (P = 2)
                         if (i == 0) x |= pos << (fbase + 5);
@@ -1591,10 +1734,11 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
                     uint32_t *rec = &out->trec[((size_t) blk0[(size_t) g] + (size_t) (r >> 3)) * blkw + (size_t) (r & 7) * 4 * W + (size_t) w * 4];
                     rec[2] |= (uint32_t) (rd < to.nr ? voff[(size_t) rd] : voff[(size_t) to.nr]);
                     if (rd < to.nr && nvals[(size_t) rd] > 0) rec[1] |= (uint32_t) ((nvals[(size_t) rd] + 7) / 8 - 1) << 30;
-                    rec[3] = (uint32_t) (rd < to.nr ? to.col[(size_t) rd * W + (size_t) w] : TEAM2_NOCOL);
+                    // (an empty slot fetches a row of the team that nobody reads: testing for it in the kernel's issue block, behind
+                    //  the barrier and on the CU's one scalar unit, cost more than the few fetches of the default schedules)
+                    rec[3] = (uint32_t) ((rd < to.nr && to.col[(size_t) rd * W + (size_t) w] != TEAM2_NOCOL) ? to.col[(size_t) rd * W + (size_t) w] : to.anycol);
                     // flags that steer the kernel's round (tools/gen_team2_asm.py)
                     if (rd < to.nr) rec[0] |= 1u << fbase;                                   // ISSUE: fetch for round r + D
-                    if (rd < to.nr && to.ownc[(size_t) rd * W + (size_t) w] == 0) rec[0] |= 1u << (fbase + 4);   // NOVAL: no parts there, no values to fetch
                     if (r + D - 1 >= to.nr) rec[0] |= 1u << (fbase + 1);                           // TAIL: fewer than D-1 younger rounds in flight
                     if (r == to.nr - 1) rec[0] |= 1u << (fbase + 2);                               // LAST
                     if (w == 0 && (r & 7) == 0 && (r >> 3) + 1 < (to.nr + 7) / 8) rec[0] |= 1u << (fbase + 3);   // RECS: fetch the next record block

@@ -55,7 +55,16 @@ struct PanelHost
     long long real_entries = 0;    // entries before padding
     double fill() const;           // nnz / (real_entries * R)
     long long nnz = 0;
+    // Compact values (build_compact_values; the narrow-operand kernel on panels that are mostly holes): only the (entry, row)
+    // pairs that exist, entry after entry, rows ascending.  cmo[q] = row mask of entry q | (index of its first value,
+    // relative to the panel's first) << 8; cbase[panel] = the panel's first value in cval; cmap[nz] = where CSR nonzero nz sits.
+    big_vector<uint32_t>  cmo;
+    std::vector<long long> cbase;  // npanel + 1
+    big_vector<double>    cval;
+    big_vector<uint32_t>  cmap;
 };
+// R = 8 only.  Returns false (nothing built) when a panel holds 2^24 values or more, or the matrix 2^32.
+bool build_compact_values(PanelHost *p);
 
 // Processing order of the panels for temporal locality of B: panels are taken in groups of
 // `group` consecutive panels (neighbouring rows share most of their columns, so a group keeps its
@@ -135,13 +144,14 @@ void apply_team_schedule(PanelHost *p, const TeamHost &t);
 // (W = 8; W = 16 in brackets):
 //   word 0 : bits 0-2 = number of parts c (0..4); bits 4+3i .. [4+4i ..] = ring slot of part i; flags from bit 16 [20]:
 //            ISSUE (r + D < rounds), TAIL (r + D - 1 >= rounds), LAST round, RECS (wave 0, r % 8 == 0 and a further record
-//            block exists: fetch it now), NOVAL (the wave has no parts in round r + D: no values to fetch); bits 21-26
-//            [25-30] = value position of part 0; bits 27 + i = bank (panel of the wave, P = 2) of part i
+//            block exists: fetch it now), one spare; bits 21-26 [25-30] = value position of part 0; bits 27 + i = bank (panel of
+//            the wave, P = 2) of part i
 //   word 1 : bits 6i .. 6i+5 = range of part i as first * 8 + len - 1; bits 24-29 = value position of part 1;
 //            bits 30-31 = size class q of the value block of round r + TEAM2_D (at most 8 (q + 1) values)
 //   word 2 : bits 0-19 = offset, inside the wave's value stream and in units of TEAM2_VUNIT values, of the block of
 //            round r + TEAM2_D; bits 20-25, 26-31 = value positions of parts 2 and 3
-//   word 3 : column (two-source encoding) of the union entry this wave fetches for round r + TEAM2_D, or TEAM2_NOCOL
+//   word 3 : column (two-source encoding) of the union entry this wave fetches for round r + TEAM2_D (an empty slot: a row of
+//            the team, fetched and not read)
 // Records are stored in blocks of 8 rounds x W waves (one or two KiB); for the first TEAM2_D rounds the (column, value
 // offset) pairs come from tpro.  A wave's values are COMPACT: a part of len rows holds len values; the parts of a round form
 // one block of the wave's stream (padded to TEAM2_VUNIT values), in the order the wave meets them; part i's value position
@@ -151,10 +161,12 @@ constexpr int TEAM2_T = 8;
 constexpr int TEAM2_D = 3;
 constexpr int TEAM2_CAP = 4;
 constexpr int TEAM2_VUNIT = 4;                    // value-stream offsets count units of 4 values (16 bytes of fp32, 32 of fp64)
-constexpr int TEAM2_NOCOL = (int) 0x80000000;   // column word of an empty slot: the wave fetches no B row for it
+constexpr int TEAM2_NOCOL = (int) 0x80000000;   // builder-internal mark of an empty slot (the records name a row of the team instead)
 struct Team2Host
 {
     int T = TEAM2_T;                 // panels per team: 8, or 16 (set before build_team2)
+    bool compact = true;             // value blocks hold only the values that exist; false (T = 8, P = 1 only): 8 values per part,
+                                     // part i's row r at 8 i + r of the round's block -- the kernel then decodes no value position
     int P = 1;                       // panels per WAVE: 1, or 2 with T = 16 (teams of 16 panels on 8 waves: the narrow-operand
                                      // instance of the kernel, two accumulator banks per wave); waves = slots of a round = T / P
     int nteam = 0;

@@ -634,7 +634,12 @@ void crp_rp_spmm_kernel_info(crp_rp_spmm_p e, int *variant, int *reordered, int 
     if (e == NULL) return;
     crp_csr_dev_p A = e->A_dev ? e->A_dev : e->A_int;
     if (A == NULL) return;
-    if (variant) *variant = e->variant != 0 ? e->variant : crp_csr_dev_resolved_variant(A, e->glb_n);
+    // what the last exec launched (after alignment fallbacks); before the first exec, what auto would pick
+    if (variant)
+    {
+        const int last = crp_csr_dev_last_variant(A);
+        *variant = last > 0 ? last : (e->variant != 0 ? e->variant : crp_csr_dev_resolved_variant(A, e->glb_n));
+    }
     if (reordered) *reordered = crp_csr_dev_reordered(A);
     if (lattice) *lattice = crp_csr_dev_lattice(A);
 }

@@ -168,7 +168,7 @@ def team2_format_host(rowptr, colidx, val):
         out = np.ctypeslib.as_array(ptr, (max(cnt, 1),))[:cnt].astype(dt).copy()
         L.c_free(C.cast(ptr, C.c_void_p))
         return out
-    return dict(nteam=nt, waves=W, panels_per_wave=P, lattice=bool(lat.value), tpanel=take(tp, W * P * nt, np.int32).reshape(nt, W * P),
+    return dict(nteam=nt, waves=W, panels_per_wave=P, compact=bool(lib.crp_team2_format_host_compact()), lattice=bool(lat.value), tpanel=take(tp, W * P * nt, np.int32).reshape(nt, W * P),
                 tinfo=take(ti, 4 * nt, np.int32).reshape(nt, 4), tpro=take(tpr, 6 * W * nt, np.int32).reshape(nt, 3, W, 2),
                 trec=take(tr, nrw.value, np.uint32), tvoff=take(tv, W * nt + 1, np.int64),
                 tval=take(tval, nve.value, np.float64), torder=take(to, nt, np.int32),

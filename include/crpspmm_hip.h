@@ -102,7 +102,7 @@ long long crp_csr_dev_bytes(crp_csr_dev_p A);
 /* The fp32 value path (BASELINE configs[3]; the reference itself is fp64-only, src/rowpara_spmm.h:28): the same
  * product with A's values, B and C in fp32 and fp32 FMAs, row-major operands.  A is the matrix created from fp64
  * values; its fp32 copies are derived on first use and follow crp_csr_dev_update_values.  variant 0 = auto (the
- * fp32 instance of the team kernel from 96 columns on where teams share columns and the operands are 16-byte
+ * fp32 instance of the team kernel from 64 columns on where teams share columns and the operands are 16-byte
  * aligned with n, ldB, ldC multiples of 4; else the fp32 CSR row-group kernel), 1 = row-group, 5 = team kernel.
  * Parity is defined against the fp64 product: relative Frobenius error <= 1e-5 (tests/test_gpu_parity.py). */
 int crp_spmm_csr_f32(crp_csr_dev_p A, int n, const float *B0, long long ldB0, const float *B1, long long ldB1, float *C,
@@ -114,10 +114,14 @@ int crp_csr_dev_auto_variant(crp_csr_dev_p A);
  * CRPSPMM_REORDER=0|1 overrides).  Results do not depend on it: C rows are written through a row map and
  * every row's products are still summed in the kernel variant's own order. */
 int crp_csr_dev_reordered(crp_csr_dev_p A);
-/* the variant `variant = 0` (auto) runs for a row-major product of n columns with aligned, even operands: the
- * create-time choice (crp_csr_dev_auto_variant), replaced by 5 (team2-R8) from 96 columns on when that choice is a
- * row-panel kernel, and by 1 below 24 columns. */
+/* the variant `variant = 0` (auto) runs for a row-major fp64 product of n columns with 16-byte aligned operands and even n,
+ * ldB, ldC: the create-time choice (crp_csr_dev_auto_variant), replaced by 5 (team2-R8) from 112 columns on (from 80 when
+ * fewer than 35 % of the (row, entry) pairs of the R = 8 panels exist) where 64 consecutive rows share columns, and by 1
+ * below 24 columns.  Operands that are not aligned like that fall back (5 -> 3 -> 1): what a product actually launched is
+ * crp_csr_dev_last_variant(). */
 int crp_csr_dev_resolved_variant(crp_csr_dev_p A, int n);
+/* the variant the last crp_spmm_csr_f64 / _f32 on this matrix launched (after every fallback), or 0 before the first */
+int crp_csr_dev_last_variant(crp_csr_dev_p A);
 /* 1 when the team formats built so far found the two nested strides of a mesh numbered along its lines (their
  * teams are then blocks of neighbouring mesh lines), 0 otherwise / not built yet. */
 int crp_csr_dev_lattice(crp_csr_dev_p A);
@@ -159,7 +163,7 @@ int crp_team_format_host(int nrow, const int *rowptr, const int *colidx, const d
  * word 0 = part count | ring slots | flags | value position of part 0; word 1 = ranges (6 bits per part: first * 8 + len
  * - 1) | value position of part 1 | size class of round r+3's value block; word 2 = offset of round r+3's value block in
  * the wave's stream (20 bits, units of 4 values) | value positions of parts 2 and 3; word 3 = column this wave fetches for
- * round r+3 (0x80000000: none).  tpro[((3g + d)*8 + w)*2 ..] = {column, value offset} of round d < 3.  Values are compact:
+ * round r+3.  tpro[((3g + d)*8 + w)*2 ..] = {column, value offset} of round d < 3.  Values are compact:
  * a part of len rows holds len values; a round's parts form one block (padded to 4 values) of the wave's stream, which
  * starts at tval[4 * tvoff[8g + w]]; part i's first value sits (position_i - 7 + first_i) values into the block.
  * vmap[nz] = index in tval of CSR nonzero nz.  *nvalent = values in tval.  malloc'd copies (caller frees).  Used by the
@@ -178,9 +182,11 @@ int crp_team2_format_host(int nrow, const int *rowptr, const int *colidx, const 
                           long long **tvoff, double **tval, long long *nvalent, int **torder, unsigned **vmap);
 /* The launch grid of the streams crp_team2_format_host() built last (process-wide, planning / test helper only): 8 runs
  * of *ngrid / 8 entries, run x = the teams XCD x processes, in order (-1 = none); a generation = 64 (W = 16: 32)
- * consecutive entries of a run.  Slots of a round that hold no B row carry the column 0x80000000 (the kernel fetches
- * nothing for them); record word 0 bit 20 (W = 16: 24) = the wave has no values to fetch for round r + 3. */
+ * consecutive entries of a run.  Slots of a round that hold no B row name a row of the team (fetched, not read). */
 int crp_team2_format_host_grid(int **tgrid, int *ngrid);
+/* 1 when the value blocks of those streams are compact (a part of len rows holds len values), 0 when every part holds 8
+ * values, row r of part i at 8 i + r of the round's block (panels filled to 40 % and more; CRPSPMM_TEAM2_COMPACT=0|1 forces) */
+int crp_team2_format_host_compact(void);
 
 /* Host-only: the processing order of the rows of a square A that crp_csr_dev_create() applies for B-row
  * locality (csrc/locality.cpp: row groups with identical column lists, `nparts` slabs by breadth-first

@@ -480,12 +480,15 @@ def test_full_size_properties_pwtk_standin(crp, orc, gpu):
     A.free()
 
 
+@pytest.mark.parametrize("values", ["compact", "full"])
 @pytest.mark.parametrize("n", [24, 64, 100, 128, 130, 200, 256, 300, 520])
-def test_team2_kernel_vs_oracle(crp, orc, gpu, n):
+def test_team2_kernel_vs_oracle(crp, orc, gpu, monkeypatch, n, values):
     """Variant 5 (LDS-sharing team kernel, csrc/team2_kernel.hip): random matrix with empty rows (teams of 8
     consecutive panels, ragged last team), padded leading dimensions, and a stride-lattice matrix (teams of
-    4 x 2 teeth); widths on both tile shapes (128 / 256 columns) and beyond one tile."""
+    4 x 2 teeth); widths on both tile shapes (128 / 256 columns) and beyond one tile; both kernel instances -- value
+    blocks without the holes (taken by itself for panels filled under 40 %) and with 8 values per part."""
     from crp_spmm_amd import gen
+    monkeypatch.setenv("CRPSPMM_TEAM2_COMPACT", "1" if values == "compact" else "0")
     m, k = 777, 1234
     rp, ci, va = gen.random_csr(m, k, 70, seed=n, empty_every=13)
     B = np.random.default_rng(n).uniform(-2, 2, size=(k, n))
@@ -502,10 +505,12 @@ def test_team2_kernel_vs_oracle(crp, orc, gpu, n):
     assert orc.rel_fro_err(orc.spmm_csr(rp, ci, va, B), got) <= FP64_TOL, ("lattice", n)
 
 
-def test_team2_two_source_nonfinite_update_rowmap(crp, orc, gpu):
+@pytest.mark.parametrize("values", ["compact", "full"])
+def test_team2_two_source_nonfinite_update_rowmap(crp, orc, gpu, monkeypatch, values):
     """Variant 5: two-source column index (B1 = receive buffer), absent pairs never multiplied (an Inf in a B
     row that a panel-mate reads must not leak NaNs into rows that do not have that column), value updates,
     row maps, bit-identical repeats."""
+    monkeypatch.setenv("CRPSPMM_TEAM2_COMPACT", "1" if values == "compact" else "0")
     import torch
     from crp_spmm_amd import gen, hip
     lib = crp.load()
@@ -860,8 +865,9 @@ def test_fp32_two_source_and_update(crp, orc, gpu):
     A.free()
 
 
-@pytest.mark.parametrize("n", [24, 26, 30, 32])
-def test_narrow_kernel(crp, orc, gpu, n):
+@pytest.mark.parametrize("compact", ["auto", "0", "1"])
+@pytest.mark.parametrize("n", [24, 26, 30, 32, 48, 64])
+def test_narrow_kernel(crp, orc, gpu, monkeypatch, n, compact):
     """The narrow-operand kernel (csrc/narrow_kernel.hip: row-panel format, four entries per instruction; variant 3 at
     24 <= n <= 32, even n, 16-byte aligned operands): random / banded / empty-row matrices with padded leading dimensions,
     the two-source column index (general addressing path), non-finite B rows next to absent pairs, value updates,
@@ -869,8 +875,16 @@ def test_narrow_kernel(crp, orc, gpu, n):
     import torch
     from crp_spmm_amd import gen, hip
     lib = crp.load()
+    # compact: the values of the panels without their holes (auto: when under half of the (row, entry) pairs exist; "1": always;
+    # "0": never); n = 48, 64: the two-piece instance, taken by itself only for panels that are mostly holes
+    if compact != "auto":
+        monkeypatch.setenv("CRPSPMM_NARROW_COMPACT", compact)
+    if n > 32:
+        if compact == "auto":
+            pytest.skip("two-piece instance: forced cases only")
+        monkeypatch.setenv("CRPSPMM_NARROW_MAX", "64")
     cases = [gen.random_csr(777, 1234, 70, seed=n, empty_every=13), gen.banded_fem(5000, offsets=(1, 2, 3, 40, 41, 900), seed=n),
-             gen.random_csr(13, 40, 5, seed=1)]
+             gen.random_csr(13, 40, 5, seed=1), gen.kkt3d(10)]
     for rp, ci, va in cases:
         m = len(rp) - 1
         k = max(int(ci.max()) + 1, 1) if ci.size else 1
@@ -916,7 +930,7 @@ def test_narrow_kernel(crp, orc, gpu, n):
     torch.cuda.synchronize()
     assert orc.rel_fro_err(orc.spmm_csr(rp, ci, v2, Bf), Cd.cpu().numpy()) <= FP64_TOL
     A.free()
-    if n == 32:
+    if n == 32 and compact != "0":
         # B rows addressed past 4 GiB: the 64-bit addressing path
         kb, ld = 1100, 1 << 19
         rpb, cib, vab = gen.random_csr(1500, kb, 40, seed=21)

@@ -615,7 +615,7 @@ def _replay_team2(t, m, B, va=None):
     the column behind ring slot e of round r is what wave e fetched for that round (tpro for the first 3
     rounds, the record of round r - 3 afterwards); the parts of round r take their values from the wave's stream
     at the offset the record of round r - 3 (or tpro) announced.  W = 8 or 16 waves per team."""
-    W, P = t["waves"], t.get("panels_per_wave", 1)
+    W, P, compact = t["waves"], t.get("panels_per_wave", 1), t.get("compact", True)
     sbits, fbase = (3, 16) if W == 8 else (4, 20)
     C_out = np.zeros((m, B.shape[1]))
     written = np.zeros(m, dtype=bool)
@@ -645,9 +645,6 @@ def _replay_team2(t, m, B, va=None):
                 # flags: ISSUE while a round r + 3 exists, TAIL near the end, LAST on the last round
                 assert bool(x >> fbase & 1) == (r + 3 < nr) and bool(x >> (fbase + 2) & 1) == (r == nr - 1)
                 assert bool(x >> (fbase + 1) & 1) == (r + 2 >= nr)
-                # NOVAL: the wave has no parts in round r + 3, so it fetches no values for it
-                cnt3 = int(rec[blk0 + ((r + 3) >> 3), (r + 3) & 7, w, 0]) & 7 if r + 3 < nr else 1
-                assert bool(x >> (fbase + 4) & 1) == (cnt3 == 0), (g, w, r)
                 if panel < 0:
                     assert cnt == 0
                 z = int(rec[blk0 + (r >> 3), r & 7, w, 2])
@@ -660,7 +657,8 @@ def _replay_team2(t, m, B, va=None):
                     first, ln = code >> 3, (code & 7) + 1
                     assert first + ln <= 8
                     pos = ((x >> (fbase + 5)) & 63, (y >> 24) & 63, (z >> 20) & 63, (z >> 26) & 63)[i]
-                    assert pos == prefix + 7 - first, (g, w, r, i)
+                    # compact blocks: the part's values follow those of the parts before it; full groups: 8 per part
+                    assert pos == ((prefix + 7 - first) if compact else (8 * i + 7)), (g, w, r, i)
                     c = int(cols[r, slot])
                     assert 0 <= c < B.shape[0]
                     bank = (x >> (fbase + 11 + i)) & 1
@@ -668,7 +666,7 @@ def _replay_team2(t, m, B, va=None):
                     for rr in range(first, first + ln):
                         # what lane rr reads: the value at (pos - 7 + rr) of the round's block
                         acc[bank, rr] += t["tval"][4 * (k0 + k) + pos - 7 + rr] * B[c]
-                    prefix += ln
+                    prefix += ln if compact else 8
                 if r >= 3 and cnt:
                     # the size class announced three rounds earlier covers this round's values
                     y3 = int(rec[blk0 + ((r - 3) >> 3), (r - 3) & 7, w, 1])
@@ -691,7 +689,7 @@ def _replay_team2(t, m, B, va=None):
     return C_out
 
 
-@pytest.mark.parametrize("order", ["default", "bisect", "two-panels"])
+@pytest.mark.parametrize("order", ["default", "bisect", "two-panels", "compact", "full-groups"])
 def test_team2_streams_replay(crp, orc, monkeypatch, order):
     """The streams of the LDS-sharing kernel (variant 5), replayed in numpy: every row is produced once and
     equals the oracle's product -- for a stride-lattice matrix (teams of 4 x 2 teeth), a random matrix (8
@@ -700,6 +698,9 @@ def test_team2_streams_replay(crp, orc, monkeypatch, order):
     if order == "bisect":
         # the recursive-bisection team order with generation-wide absolute rounds (rounds with empty slots, NOVAL records)
         monkeypatch.setenv("CRPSPMM_T2_ORDER", "bisect")
+    if order in ("compact", "full-groups"):
+        # value blocks without the holes / with 8 values per part, whatever the fill (the default picks by fill)
+        monkeypatch.setenv("CRPSPMM_TEAM2_COMPACT", "1" if order == "compact" else "0")
     if order == "two-panels":
         # teams of 16 panels on 8 waves, two panels (accumulator banks) per wave: the narrow-operand instance
         monkeypatch.setenv("CRPSPMM_TEAM2_FORMAT_PW", "2")

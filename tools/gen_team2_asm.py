@@ -23,12 +23,11 @@ Record of (round r, wave w), 4 words (panel_format.h, Team2Host):
     w0 : bits 0-2 part count c (0..4) | bits 4+3i.. ring slot of part i | bit 16 ISSUE (fetch for round r + D)
          | bit 17 TAIL (fewer than D-1 younger rounds in flight at the top of round r: wait vmcnt(0))
          | bit 18 LAST round of the team | bit 19 RECS (this wave fetches the next record block now)
-         | bit 20 NOVAL (the wave has no parts in round r + D: the value DMA is issued with EXEC = 0)
          | bits 21-26 value position of part 0 (below)
     w1 : bits 6i.. range of part i as first * 8 + len - 1 | bits 24-29 value position of part 1
          | bits 30-31 size class q of the value block of round r + D: it holds at most 8 (q + 1) values
     w2 : bits 0-19 value-stream offset of round r + D, in units of 4 values | bits 20-25, 26-31 value positions of parts 2, 3
-    w3 : column of round r + D; 0x80000000 (TEAM2_NOCOL): the wave's slot is empty, the row DMAs are issued with EXEC = 0
+    w3 : column of round r + D (an empty slot names a row of the team: a fetch nobody reads)
 Values are COMPACT: a part of len rows stores len values (round 2 stored 8 per part, zeros for the rows outside the
 range: 146 MB instead of 89 MB on the pwtk stand-in, 4.2 x the nonzeros on the nlpkkt stand-in).  A round's values
 are one block of the wave's stream (padded to 4 values), DMA'd to the wave's value slot; part i's first value sits
@@ -65,11 +64,14 @@ NVREG = 28
 NSREG = 14
 
 
-def gen(nv, has_b1, f32=False, tw=8, pw=1):
+def gen(nv, has_b1, f32=False, tw=8, pw=1, compact=True):
     """nv = 16-byte pieces per lane and row; f32: 4 floats per piece (values 4 bytes, 8 per part = 32 bytes, value
     slot 128 bytes), else 2 doubles per piece (values 8 bytes, 64 bytes per part, value slot 256 bytes).
     tw = waves (= slots of a round) per team: 8, or 16 (one 1024-thread workgroup per CU; slot numbers take 4
     bits in w0, the flags move up to bits 20-23, a record block is 2 KiB).
+    compact = False: the value blocks hold 8 values per part (part i's row r at 8 i + r): no value position to decode per part and
+    a value DMA of fixed size -- two instructions per part and three per round fewer; the instance for panels that are well filled
+    (pwtk stand-in, fill 0.61: 3 % faster at n = 256 and 10 % at n = 128 than on compact values; nlpkkt stand-in, 0.23: 2-5 % slower).
     pw = panels per wave: 1, or 2 (nv = 1 only: the narrow-operand instance -- a wave owns TWO panels, i.e. two banks of
     accumulators, so that a team is 16 panels = 128 rows on 8 waves; every part names its bank in w0 bits fbase+11+i and
     the call goes to that bank's copy of the sequences.  Half the rounds per row, and a B row is fetched once per 128 rows)."""
@@ -93,7 +95,7 @@ def gen(nv, has_b1, f32=False, tw=8, pw=1):
     seq_align = {(1, False): 8, (2, False): 9, (1, True): 8, (2, True): 9}[(nv, f32)]
     opr = nv + 1                                    # DMAs a wave issues per round
     assert pw == 1 or nv == 1
-    tag = "%s%d%d%s%s_%%=" % ("s" if f32 else "d", nv, 1 if has_b1 else 0, "w" if tw == 16 else "", "p" if pw == 2 else "")
+    tag = "%s%d%d%s%s%s_%%=" % ("s" if f32 else "d", nv, 1 if has_b1 else 0, "w" if tw == 16 else "", "p" if pw == 2 else "", "" if compact else "f")
     L = []
     emit = L.append
 
@@ -106,6 +108,13 @@ def gen(nv, has_b1, f32=False, tw=8, pw=1):
         emit("ds_read_b128 v[%d:%d], v%d offset:%d" % (X["s0"], X["s0"] + 3, TA, koff))
         if nv == 2:
             emit("ds_read_b128 v[%d:%d], v%d offset:%d" % (X["s1"], X["s1"] + 3, TA, koff + 1024))
+        if not compact:
+            # 8 values per part: the lane's row of part i at a fixed offset (vsl = slot base - 7 values + this lane's row)
+            if f32:
+                emit("ds_read_b32 v%d, %%[vsl] offset:%d" % (X["v"], k * vslot + vgrp * i + 28))
+            else:
+                emit("ds_read_b64 v[%d:%d], %%[vsl] offset:%d" % (X["v"], X["v"] + 1, k * vslot + vgrp * i + 56))
+            return
         # the part's values: position field -> address (vsl = slot base - 7 values + this lane's row)
         word, bit = (("w0", fbase + 5), ("w1", 24), ("w2", 20), ("w2", 26))[i]
         emit("s_bfe_u32 s%d, %%[%s], 0x%x" % (T, word, (6 << 16) | bit))
@@ -150,24 +159,12 @@ def gen(nv, has_b1, f32=False, tw=8, pw=1):
         emit("s_waitcnt vmcnt(0)")
         emit("s_barrier")
         emit(".Lt2body%d%s:" % (k, tag))
-        # -- issue for round r + D
+        # -- issue for round r + D.  The B row first: every wave of the workgroup runs this block right behind the barrier, all
+        # of them on the CU's one scalar unit, and what the CU is short of is requests in flight -- the row DMAs go out
+        # before the bookkeeping of the value DMA (round 3: with the value block's size and the empty-slot tests in front of
+        # them the pwtk stand-in ran 6 % slower).
         emit("s_bitcmp1_b32 %%[w0], %d" % fbase)
         emit("s_cbranch_scc0 .Lt2ni%d%s" % (k, tag))
-        emit("s_and_b32 s%d, %%[w2], 0xfffff" % T)
-        emit("v_lshl_add_u32 v%d, s%d, %d, %%[lane16]" % (TV, T, 4 if f32 else 5))      # block offset: units of 4 values
-        # lanes of the value DMA: the block's size class; a DMA whose EXEC is zero (NOVAL: no parts in round r + D)
-        # moves nothing but still counts in vmcnt: the wait counts of the loop stay fixed
-        emit("s_bfe_u32 s%d, %%[w1], 0x2001e" % T)
-        emit("s_lshl_b32 s%d, s%d, %d" % (T, T, 1 if f32 else 2))
-        emit("s_add_u32 s%d, s%d, %d" % (T, T, 2 if f32 else 4))
-        emit("s_bfm_b64 exec, s%d, 0" % T)
-        emit("s_bitcmp1_b32 %%[w0], %d" % (fbase + 4))
-        emit("s_cselect_b64 exec, 0, exec")
-        emit("s_add_u32 m0, %%[vringw], %d" % (kd * vslot))
-        emit("s_nop 0")
-        emit("global_load_lds_dwordx4 v%d, %%[vbase]%s" % (TV, APOL))
-        emit("s_cmp_lg_u32 %[w3], 0x80000000")                                 # TEAM2_NOCOL: empty slot, no row
-        emit("s_cselect_b64 exec, -1, 0")
         if has_b1:
             # c < 0: row ~c of B1
             emit("s_cmp_lt_i32 %[w3], 0")
@@ -190,6 +187,21 @@ def gen(nv, has_b1, f32=False, tw=8, pw=1):
         emit("global_load_lds_dwordx4 %%[voffa], s[%d:%d]%s" % (RB, RB + 1, BPOL))
         if nv == 2:
             emit("global_load_lds_dwordx4 %%[voffb], s[%d:%d] offset:1024%s" % (RB, RB + 1, BPOL))
+        # the wave's value block of round r + D: offset in units of 4 values, 4 (q + 1) lanes of 16 bytes (fp32: 2 (q + 1))
+        emit("s_and_b32 s%d, %%[w2], 0xfffff" % T)
+        emit("v_lshl_add_u32 v%d, s%d, %d, %%[lane16]" % (TV, T, 4 if f32 else 5))
+        if compact:
+            emit("s_bfe_u32 s%d, %%[w1], 0x2001e" % T)
+            if f32:
+                emit("s_lshl1_add_u32 s%d, s%d, 2" % (T, T))
+            else:
+                emit("s_lshl2_add_u32 s%d, s%d, 4" % (T, T))
+            emit("s_bfm_b64 exec, s%d, 0" % T)
+        else:
+            emit("s_mov_b64 exec, 0x%x" % ((1 << (vslot // 16)) - 1))
+        emit("s_add_u32 m0, %%[vringw], %d" % (kd * vslot))
+        emit("s_nop 0")
+        emit("global_load_lds_dwordx4 v%d, %%[vbase]%s" % (TV, APOL))
         emit("s_mov_b64 exec, -1")
         emit(".Lt2ni%d%s:" % (k, tag))
         # -- next record block (one wave, every 8 rounds)
@@ -288,12 +300,12 @@ def main():
               % (VBASE, VBASE + NVREG - 1, SBASE, SBASE + NSREG - 1))
     out.write("#define CRP_TEAM2_CLOBBERS %s, %s\n" % (", ".join('"v%d"' % r for r in range(VBASE, VBASE + NVREG)),
                                                       ", ".join('"s%d"' % r for r in range(SBASE, SBASE + NSREG))))
-    for tw, pw in ((8, 1), (16, 1), (8, 2)):
+    for tw, pw, compact in ((8, 1, True), (8, 1, False), (16, 1, True), (8, 2, True)):
      for f32 in (False, True):
       for nv in ((1, 2) if pw == 1 else (1,)):
         for hb in (0, 1):
-            out.write("#define CRP_TEAM2_LOOP_%s_NV%d_B%d%s \\\n" % ("F32" if f32 else "F64", nv, hb, "_W16" if tw == 16 else ("_P2" if pw == 2 else "")))
-            lines = gen(nv, bool(hb), f32, tw, pw)
+            out.write("#define CRP_TEAM2_LOOP_%s_NV%d_B%d%s \\\n" % ("F32" if f32 else "F64", nv, hb, "_W16" if tw == 16 else ("_P2" if pw == 2 else ("" if compact else "_F"))))
+            lines = gen(nv, bool(hb), f32, tw, pw, compact)
             for k, l in enumerate(lines):
                 sep = "\\n\\t" if not l.endswith(":") else "\\n"
                 last = k == len(lines) - 1

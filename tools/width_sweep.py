@@ -85,7 +85,7 @@ def main():
             lib.crp_event_destroy(y)
         kern_ms = float(np.mean(per))
         alg = gen.alg_bytes(m, kcols, n, nnz)
-        rv = int(lib.crp_csr_dev_resolved_variant(A.handle, n))
+        rv = int(lib.crp_csr_dev_last_variant(A.handle))
         free_b, total_b = torch.cuda.mem_get_info()
         line = {"matrix": label, "rows": m, "nnz": nnz, "n": n, "kernel_variant": lib.crp_spmm_variant_name(rv).decode(),
                 "ms": kern_ms, "ms_min": float(np.min(per)), "ms_max": float(np.max(per)), "GFLOP/s": 2.0 * nnz * n / (kern_ms * 1e-3) / 1e9,
