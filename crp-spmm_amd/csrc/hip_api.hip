@@ -286,17 +286,19 @@ static int ensure_team2(crp_csr_dev *A, hipStream_t stream, int pw)
     Team2Dev &t = pw == 2 ? A->team2p : A->team2;
     if (t.built) return 0;
     crp::PhaseClock clk;
-    crp::PanelHost h;
+    crp::released_async<crp::PanelHost> h_owner;          // (freed by a background thread when this function returns)
+    crp::PanelHost &h = *h_owner;
     crp::build_panels(A->nrow, fmt_rowptr(A), fmt_colidx(A), fmt_val(A), 8, &h, false, false);
     fmt_slotmap_to_caller(A, &h.pmap);
     clk.lap("ensure_team2: build_panels (R = 8)");
-    crp::Team2Host th;
+    crp::released_async<crp::Team2Host> th_owner;
+    crp::Team2Host &th = *th_owner;
     th.T = pw == 2 ? 16 : team2_waves();
     th.P = pw;
     // Value blocks: compact (only the values that exist) when under 40 % of the (row, entry) pairs of the panels exist, 8 per
     // part otherwise -- the kernel instance for full groups decodes no value position (two instructions per part and three
-    // per round fewer): pwtk stand-in (fill 0.61) 3 % faster at n = 256 and 10 % at n = 128 than on compact values, the nlpkkt
-    // stand-in (0.23) 2-5 % slower and 13 GB larger at nlpkkt240 size.  CRPSPMM_TEAM2_COMPACT=0|1 forces.
+    // per round fewer).  Same box, compact against full groups: shell stand-in 0.2686 / 0.2649 ms, Queen stand-in 0.8597 / 0.854,
+    // nlpkkt stand-in (fill 0.23) 1.91 / 2.05 and 13 GB smaller at nlpkkt240 size.  CRPSPMM_TEAM2_COMPACT=0|1 forces.
     {
         const char *ec = getenv("CRPSPMM_TEAM2_COMPACT");
         th.compact = ec ? atoi(ec) != 0 : h.fill() < 0.4;

@@ -1259,7 +1259,8 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
     const int sbits = W == 16 ? 4 : 3, fbase = W == 16 ? 20 : 16;          // slot bits and first flag bit of record word 0
     const size_t blkw = (size_t) 32 * W;                                    // words of a record block (8 rounds x W waves x 4)
     PhaseClock clk;
-    TeamHost th;
+    released_async<TeamHost> th_owner;                                      // (freed by a background thread)
+    TeamHost &th = *th_owner;
     // The balanced passes of build_teams break the ties of the phase key (a lattice team has twenty nodes per key value): in
     // plain column order the nodes of one wave come in runs, the rounds then hold four parts of one wave and none of another,
     // and a round lasts as long as its busiest wave -- pwtk stand-in 0.304 -> 0.315 ms at n = 256, 0.199 -> 0.210 at n = 128
@@ -1332,6 +1333,7 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
     // CRPSPMM_T2_AHEAD: rounds a team may take a node before its target (fills the slots its own share of a round leaves
     // empty; a line survives about four rounds in L2, so one round of slack costs no hit)
     const int ahead = getenv("CRPSPMM_T2_AHEAD") ? atoi(getenv("CRPSPMM_T2_AHEAD")) : 1;
+    const bool swap_on = (getenv("CRPSPMM_T2_SWAP") == NULL || atoi(getenv("CRPSPMM_T2_SWAP")) != 0) && nteam <= 120000;   // (2 s per 100 k teams on 16 CPUs)
     const int loadcap = getenv("CRPSPMM_T2_LOADCAP") ? atoi(getenv("CRPSPMM_T2_LOADCAP")) : 0;
     const bool load_aware = getenv("CRPSPMM_T2_SCHED") != NULL && strcmp(getenv("CRPSPMM_T2_SCHED"), "load") == 0;
     auto schedule_team = [&](int g, const std::vector<int> &nodes, const int *target) {
@@ -1513,6 +1515,81 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
             to.nr++;
         }
     };
+    // Balance pass over a team's finished rounds: a round lasts as long as its busiest wave (one barrier per round), so for
+    // every pair of consecutive rounds the exchange of one slot of each that lowers (busiest wave of r) + (busiest wave of
+    // r + 1) most is made -- rounds stay full (an empty slot is a fetch), a node moves by one round at most per pass (the phase
+    // order it was placed by has that much slack).  Work of a part = 3 + its rows.  CRPSPMM_T2_SWAP=0 skips it.
+    auto balance_rounds = [&](TeamOut &to) {
+        const int nr = to.nr;
+        if (nr < 2) return;
+        // work[(r * W + slot) * W + w], count likewise: what slot `slot` of round r gives wave w
+        std::vector<unsigned char> swork((size_t) nr * W * W, 0), scnt((size_t) nr * W * W, 0);
+        std::vector<int> load((size_t) nr * W, 0), cnt((size_t) nr * W, 0);
+        for (int r = 0; r < nr; r++)
+            for (int w = 0; w < W; w++)
+            {
+                const Part *ow = &to.ownp[((size_t) r * W + (size_t) w) * CAP];
+                const int c = to.ownc[(size_t) r * W + (size_t) w];
+                cnt[(size_t) r * W + (size_t) w] = c;
+                for (int i = 0; i < c; i++)
+                {
+                    swork[((size_t) r * W + (size_t) ow[i].slot) * W + (size_t) w] += (unsigned char) (3 + ow[i].len);
+                    scnt[((size_t) r * W + (size_t) ow[i].slot) * W + (size_t) w]++;
+                    load[(size_t) r * W + (size_t) w] += 3 + ow[i].len;
+                }
+            }
+        auto maxload = [&](int r) { int m = 0; for (int w = 0; w < W; w++) m = std::max(m, load[(size_t) r * W + (size_t) w]); return m; };
+        for (int pass = 0; pass < 2; pass++)
+            for (int r = 0; r + 1 < nr; r++)
+            {
+                const int cur = maxload(r) + maxload(r + 1);
+                int best = cur, bi = -1, bj = -1;
+                for (int i = 0; i < W; i++)
+                {
+                    if (to.col[(size_t) r * W + (size_t) i] == TEAM2_NOCOL) continue;
+                    const unsigned char *wa = &swork[((size_t) r * W + (size_t) i) * W], *ca = &scnt[((size_t) r * W + (size_t) i) * W];
+                    for (int j = 0; j < W; j++)
+                    {
+                        if (to.col[(size_t) (r + 1) * W + (size_t) j] == TEAM2_NOCOL) continue;
+                        const unsigned char *wb = &swork[((size_t) (r + 1) * W + (size_t) j) * W], *cb = &scnt[((size_t) (r + 1) * W + (size_t) j) * W];
+                        int m0 = 0, m1 = 0;
+                        bool ok = true;
+                        for (int w = 0; w < W; w++)
+                        {
+                            if (cnt[(size_t) r * W + (size_t) w] - ca[w] + cb[w] > CAP || cnt[(size_t) (r + 1) * W + (size_t) w] - cb[w] + ca[w] > CAP) { ok = false; break; }
+                            m0 = std::max(m0, load[(size_t) r * W + (size_t) w] - wa[w] + wb[w]);
+                            m1 = std::max(m1, load[(size_t) (r + 1) * W + (size_t) w] - wb[w] + wa[w]);
+                        }
+                        if (ok && m0 + m1 < best) { best = m0 + m1; bi = i; bj = j; }
+                    }
+                }
+                if (bi < 0) continue;
+                // exchange slot bi of round r with slot bj of round r + 1
+                std::swap(to.col[(size_t) r * W + (size_t) bi], to.col[(size_t) (r + 1) * W + (size_t) bj]);
+                for (int w = 0; w < W; w++)
+                {
+                    Part *p0 = &to.ownp[((size_t) r * W + (size_t) w) * CAP], *p1 = &to.ownp[((size_t) (r + 1) * W + (size_t) w) * CAP];
+                    Part keep0[4], keep1[4], mv0[4], mv1[4];
+                    int k0 = 0, k1 = 0, n0 = 0, n1 = 0;
+                    for (int i = 0; i < (int) to.ownc[(size_t) r * W + (size_t) w]; i++) { if (p0[i].slot == bi) mv0[n0++] = p0[i]; else keep0[k0++] = p0[i]; }
+                    for (int i = 0; i < (int) to.ownc[(size_t) (r + 1) * W + (size_t) w]; i++) { if (p1[i].slot == bj) mv1[n1++] = p1[i]; else keep1[k1++] = p1[i]; }
+                    for (int i = 0; i < n1; i++) { mv1[i].slot = bi; keep0[k0++] = mv1[i]; }
+                    for (int i = 0; i < n0; i++) { mv0[i].slot = bj; keep1[k1++] = mv0[i]; }
+                    for (int i = 0; i < k0; i++) p0[i] = keep0[i];
+                    for (int i = 0; i < k1; i++) p1[i] = keep1[i];
+                    to.ownc[(size_t) r * W + (size_t) w] = (unsigned char) k0;
+                    to.ownc[(size_t) (r + 1) * W + (size_t) w] = (unsigned char) k1;
+                    const int wa = swork[((size_t) r * W + (size_t) bi) * W + (size_t) w], wb = swork[((size_t) (r + 1) * W + (size_t) bj) * W + (size_t) w];
+                    const int ca = scnt[((size_t) r * W + (size_t) bi) * W + (size_t) w], cb = scnt[((size_t) (r + 1) * W + (size_t) bj) * W + (size_t) w];
+                    load[(size_t) r * W + (size_t) w] += wb - wa;
+                    load[(size_t) (r + 1) * W + (size_t) w] += wa - wb;
+                    cnt[(size_t) r * W + (size_t) w] += cb - ca;
+                    cnt[(size_t) (r + 1) * W + (size_t) w] += ca - cb;
+                    std::swap(swork[((size_t) r * W + (size_t) bi) * W + (size_t) w], swork[((size_t) (r + 1) * W + (size_t) bj) * W + (size_t) w]);
+                    std::swap(scnt[((size_t) r * W + (size_t) bi) * W + (size_t) w], scnt[((size_t) (r + 1) * W + (size_t) bj) * W + (size_t) w]);
+                }
+            }
+    };
     // ---- the launch grid: the order cut into 8 contiguous pieces of equal work (union entries / T + a fixed cost per
     // team), one per XCD -- pieces of equal team COUNT leave XCDs idle when the teams differ (KKT systems: 27-point primal
     // rows, short dual rows).  Under the bisection order the cuts fall on multiples of a generation.
@@ -1553,6 +1630,7 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
                 team_nodes((int) g, nodes);
                 if (phase) std::stable_sort(nodes.begin(), nodes.end(), [&](int x, int y) { return key(x) < key(y); });
                 schedule_team((int) g, nodes, nullptr);
+                if (swap_on) balance_rounds(res[(size_t) g]);
             }
         });
     else

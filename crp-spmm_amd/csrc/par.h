@@ -103,6 +103,27 @@ struct default_init_allocator : std::allocator<T>
 };
 template <typename T> using big_vector = std::vector<T, default_init_allocator<T>>;
 
+// Owns a heap object and hands it to a detached thread on scope exit: the builders' temporaries are tens of gigabytes on the
+// largest inputs, and returning them to the system took seconds of the first product's time.
+template <typename T>
+struct released_async
+{
+    T *p;
+    released_async() : p(new T) {}
+    released_async(const released_async &) = delete;
+    released_async &operator=(const released_async &) = delete;
+    ~released_async()
+    {
+        T *q = p;
+        p = nullptr;
+        if (getenv("CRPSPMM_SYNC_RELEASE") != nullptr) { delete q; return; }      // (leak checkers: nothing may outlive main)
+        try { std::thread([q] { delete q; }).detach(); }
+        catch (...) { delete q; }
+    }
+    T &operator*() { return *p; }
+    T *operator->() { return p; }
+};
+
 template <typename V, typename T>
 void parallel_fill(V &v, size_t n, T value)
 {

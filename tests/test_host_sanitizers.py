@@ -21,6 +21,6 @@ def test_host_code_under_asan_ubsan(tmp_path):
            os.path.join(ROOT, "tests", "host_asan.cpp"), *files, "-o", exe]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
-    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", CRPSPMM_NUM_THREADS="4")
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", CRPSPMM_NUM_THREADS="4", CRPSPMM_SYNC_RELEASE="1")
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "HOST_ASAN_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
