@@ -84,10 +84,15 @@ static void para2d_init_common(crp_comm_t *comm, int pm, int pn, const int *A0_r
         static const bool host_only = getenv("CRPSPMM_REPLICATE") != NULL && strcmp(getenv("CRPSPMM_REPLICATE"), "host") == 0;
         if (comm_row->allgatherv_dev != NULL && !plan_only && !host_only && p_nnz > 0)
         {
-            // Device replication (reference :81-83: two overlapped MPI_Iallgatherv on duplicate communicators):
-            // the own slices go up once, column indices and values are all-gathered between device buffers on
-            // two streams -- over xGMI every source feeds its pn - 1 peers on distinct links --, and the panel
-            // comes back through pinned memory for the plan and the format construction, which run on the host.
+            // Device replication (reference :81-83: two MPI_Iallgatherv on duplicate communicators): the own slices go
+            // up once, column indices and values are all-gathered between device buffers -- over xGMI every source feeds
+            // its pn - 1 peers on distinct links; the two gathers use ONE RCCL communicator, which runs them one after the
+            // other whatever streams they are given, so no overlap between them is claimed --, and the panel comes back
+            // through pinned memory: the plan is built on the host from the column indices, and the values are a public
+            // host field of the engine (struct rowpara_spmm::A_val, /root/reference/src/rowpara_spmm.h:8-40), so the copy
+            // down is owed to the API.  What could still be saved is the second upload of the values by
+            // crp_csr_dev_create (8 bytes per nonzero over PCIe: 2.3 GB, about 50 ms, for an nlpkkt240 panel of a 2 x 4
+            // grid, against the seconds of the format build that follows); not done.
             void *s_i = NULL, *s_v = NULL, *d_ci = NULL, *d_va = NULL, *d_ci_all = NULL, *d_va_all = NULL, *h_ci = NULL, *h_va = NULL;
             int rc = crp_stream_create(&s_i);
             if (rc == 0) rc = crp_stream_create(&s_v);

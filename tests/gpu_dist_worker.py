@@ -16,11 +16,17 @@ def main():
     import oracle as orc
     from crp_spmm_amd import comm as crp_comm, engine, gen, planner
 
-    torch.cuda.set_device(0)
-    dev = torch.device("cuda", 0)
-    crp_comm.init_process_group()
-    assert crp_comm.exchange_mode() == "host"
+    # one-GPU rehearsal (CRPSPMM_EXCHANGE=host: every rank on device 0, payloads staged through the host), or -- on a node
+    # with a GPU per rank, tests/test_gpu_dist.py::test_engines_native_rccl_multi_gpu -- the native RCCL transport
+    native = os.environ.get("CRPSPMM_EXPECT_NATIVE_RCCL") == "1"
+    idev = int(os.environ.get("LOCAL_RANK", "0")) if native else 0
+    torch.cuda.set_device(idev)
+    dev = torch.device("cuda", idev)
+    crp_comm.init_process_group(device=idev if native else None)
+    assert crp_comm.exchange_mode() == ("nccl" if native else "host")
     world = crp_comm.TorchComm()
+    if native:
+        assert world.device_ranks() == world.nproc, "the native RCCL communicator did not come up"
     P, me = world.nproc, world.rank
     m = k = 6000
     rp, ci, va = gen.banded_fem(m, offsets=(1, 2, 3, 4, 50, 51, 1400), seed=5)

@@ -33,3 +33,31 @@ def test_rccl_backend_single_rank():
                        env=env, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "GPU_NCCL_WORKER_OK" in r.stdout
+
+
+def _gpu_count():
+    try:
+        import torch
+        return torch.cuda.device_count()
+    except Exception:
+        return 0
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_engines_native_rccl_multi_gpu(world):
+    """The native RCCL members (grouped ncclSend / ncclRecv exchange, device all-gather of A, the non-blocking bootstrap) with
+    one rank per GPU -- the path that has only ever run at world size 1, because every box this suite has seen so far had one
+    GPU.  Skipped there; on a node with `world` GPUs it runs the same worker as the host-staged rehearsal, WITHOUT
+    CRPSPMM_EXCHANGE=host, and the worker asserts that the device transport is the one in use."""
+    if _gpu_count() < world:
+        pytest.skip("needs %d GPUs (native RCCL refuses two ranks on one device)" % world)
+    env = dict(os.environ)
+    env["OMP_NUM_THREADS"] = "1"
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    env["CRPSPMM_EXPECT_NATIVE_RCCL"] = "1"
+    env.pop("CRPSPMM_EXCHANGE", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(29800 + world), os.path.join(ROOT, "tests", "gpu_dist_worker.py")]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=1200, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "GPU_DIST_WORKER_OK world=%d" % world in r.stdout
