@@ -74,6 +74,19 @@ struct Team2Dev
     int nreal[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
+struct Team2NDev              // panel_format.h, Team2NHost: the narrow-operand team kernel's streams (variant 6)
+{
+    bool built = false;
+    int G = 4, nteam = 0, ngrid = 0;
+    int *tgrid = nullptr, *tpanel = nullptr, *tinfo = nullptr;
+    uint32_t *trec = nullptr;
+    long long *tvoff = nullptr;
+    double *tval = nullptr;
+    uint32_t *tmap = nullptr;
+    long long value_entries = 0;
+    bool lattice = false;
+};
+
 struct crp_csr_dev
 {
     int       nrow = 0;
@@ -90,6 +103,7 @@ struct crp_csr_dev
     Team2Dev team2;           // teams of eight R = 8 panels, LDS-shared B rows (variant 5)
     Team2Dev team2p;          // teams of 16 panels on 8 waves, two panels per wave: variant 5 for operands of one 16-byte piece per
                               // lane (fp64: n <= 128, fp32: n <= 256)
+    Team2NDev team2n[2];      // [0]: four entries per instruction (n <= 32), [1]: two (n <= 64)
     int      auto_variant = 1; // what variant 0 resolves to below 96 columns (1 rowgroup, 2 panel R4, 3 panel R8)
     bool     team2_pays = false;   // 64 consecutive rows (in format order) share columns: variant 0 takes team2 from team2_min_n columns on
     int      last_variant = 0;     // what the last product launched (crp_csr_dev_last_variant)
@@ -359,6 +373,60 @@ static int ensure_team2(crp_csr_dev *A, hipStream_t stream, int pw)
     clk.lap("ensure_team2: upload");
     t.built = true;
     return 0;
+}
+
+static int ensure_team2n(crp_csr_dev *A, hipStream_t stream, int G)
+{
+    Team2NDev &t = A->team2n[G == 2 ? 1 : 0];
+    if (t.built) return 0;
+    crp::PhaseClock clk;
+    crp::released_async<crp::PanelHost> h_owner;
+    crp::PanelHost &h = *h_owner;
+    crp::build_panels(A->nrow, fmt_rowptr(A), fmt_colidx(A), fmt_val(A), 8, &h, false, false);
+    fmt_slotmap_to_caller(A, &h.pmap);
+    clk.lap("ensure_team2n: build_panels (R = 8)");
+    crp::released_async<crp::Team2NHost> th_owner;
+    crp::Team2NHost &th = *th_owner;
+    th.G = G == 2 ? 2 : 4;
+    std::vector<int> colpos;
+    if (!A->perm.empty())
+    {
+        colpos.resize(A->perm.size());
+        for (size_t i = 0; i < A->perm.size(); i++) colpos[(size_t) A->perm[i]] = (int) i;
+    }
+    crp::build_team2n(h, A->nrow, fmt_rowptr(A), fmt_colidx(A), &th, colpos.empty() ? nullptr : colpos.data());
+    clk.lap("ensure_team2n: build_team2n");
+    t.G = th.G;
+    t.nteam = th.nteam;
+    t.lattice = th.lattice;
+    t.ngrid = (int) th.tgrid.size();
+    t.value_entries = th.nvalues;
+    auto up = [](void **dst, const void *src, size_t bytes, size_t pad) -> hipError_t {
+        hipError_t e = hipMalloc(dst, bytes + pad);
+        if (e == hipSuccess && pad) e = hipMemset((char *) *dst + bytes, 0, pad);
+        if (e == hipSuccess && bytes) e = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+        return e;
+    };
+    hipError_t e = up((void **) &t.tgrid, th.tgrid.data(), sizeof(int) * th.tgrid.size(), 4);
+    if (e == hipSuccess) e = up((void **) &t.tpanel, th.tpanel.data(), sizeof(int) * th.tpanel.size(), 4);
+    if (e == hipSuccess) e = up((void **) &t.tinfo, th.tinfo.data(), sizeof(int) * th.tinfo.size(), 16);
+    if (e == hipSuccess) e = up((void **) &t.trec, th.trec.data(), sizeof(uint32_t) * th.trec.size(), 1024);
+    if (e == hipSuccess) e = up((void **) &t.tvoff, th.tvoff.data(), sizeof(long long) * th.tvoff.size(), 8);
+    // a wave's value DMA takes whole 16-byte lanes of its block: nothing past the stream's padding is addressed
+    if (e == hipSuccess) e = up((void **) &t.tval, th.tval.data(), sizeof(double) * th.tval.size(), 4096);
+    if (e == hipSuccess) e = up((void **) &t.tmap, th.vmap.data(), sizeof(uint32_t) * th.vmap.size(), 4);
+    if (e != hipSuccess) return (int) e;
+    if (A->host_vals_stale && A->nnz > 0) CRP_TRY(crp::scatter_vals_f64(A->nnz, t.tmap, A->val, t.tval, stream));
+    clk.lap("ensure_team2n: upload");
+    t.built = true;
+    return 0;
+}
+
+// variant 0 below the team2 threshold: the narrow team kernel (CRPSPMM_TEAM2N=0 keeps the row-panel kernels)
+static bool team2n_auto()
+{
+    const char *e = getenv("CRPSPMM_TEAM2N");
+    return e != NULL && atoi(e) != 0;
 }
 
 extern "C" {
@@ -696,6 +764,16 @@ int crp_csr_dev_destroy(crp_csr_dev_p *A_)
         if (t2->tval32) (void) hipFree(t2->tval32);
         if (t2->gsync) (void) hipFree(t2->gsync);
     }
+    for (Team2NDev &tn : A->team2n)
+    {
+        if (tn.tgrid) (void) hipFree(tn.tgrid);
+        if (tn.tpanel) (void) hipFree(tn.tpanel);
+        if (tn.tinfo) (void) hipFree(tn.tinfo);
+        if (tn.trec) (void) hipFree(tn.trec);
+        if (tn.tvoff) (void) hipFree(tn.tvoff);
+        if (tn.tval) (void) hipFree(tn.tval);
+        if (tn.tmap) (void) hipFree(tn.tmap);
+    }
     if (A->val32) (void) hipFree(A->val32);
     if (A->rowptr) (void) hipFree(A->rowptr);
     if (A->colidx) (void) hipFree(A->colidx);
@@ -716,6 +794,8 @@ int crp_csr_dev_update_values(crp_csr_dev_p A, const double *val, void *stream)
         if (A->pan[i].built && A->pan[i].entries * (long long) A->pan[i].R >= (1LL << 32)) return -5;
     if (A->team.built && A->team.entries * 8LL >= (1LL << 32)) return -5;
     if ((A->team2.built && A->team2.value_entries >= (1LL << 32)) || (A->team2p.built && A->team2p.value_entries >= (1LL << 32))) return -5;
+    for (Team2NDev &tn : A->team2n)
+        if (tn.built && tn.value_entries >= (1LL << 32)) return -5;
     int is_dev = 0;
     crp_dev_ptr_is_device(val, &is_dev);
     CRP_TRY(hipMemcpyAsync(A->val, val, sizeof(double) * (size_t) A->nnz, is_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
@@ -736,6 +816,8 @@ int crp_csr_dev_update_values(crp_csr_dev_p A, const double *val, void *stream)
     if (A->team.built) CRP_TRY(crp::scatter_vals_f64(A->nnz, A->team.tmap, A->val, A->team.tval, (hipStream_t) stream));
     for (Team2Dev *t2 : {&A->team2, &A->team2p})
         if (t2->built) CRP_TRY(crp::scatter_vals_f64(A->nnz, t2->tmap, A->val, t2->tval, (hipStream_t) stream));
+    for (Team2NDev &tn : A->team2n)
+        if (tn.built) CRP_TRY(crp::scatter_vals_f64(A->nnz, tn.tmap, A->val, tn.tval, (hipStream_t) stream));
     // fp32 copies follow
     if (A->val32) CRP_TRY(crp::convert_f64_f32(A->nnz, A->val, A->val32, (hipStream_t) stream));
     for (Team2Dev *t2 : {&A->team2, &A->team2p})
@@ -775,7 +857,7 @@ int crp_csr_dev_nrow(crp_csr_dev_p A) { return A ? A->nrow : -1; }
 long long crp_csr_dev_nnz(crp_csr_dev_p A) { return A ? A->nnz : -1; }
 long long crp_csr_dev_bytes(crp_csr_dev_p A) { return A ? 12LL * A->nnz + 4LL * ((long long) A->nrow + 1) : -1; }
 
-static const char *k_variant_names[] = {"auto", "csr-rowgroup", "rowpanel-R4", "rowpanel-R8", "team-R8", "team2-R8"};
+static const char *k_variant_names[] = {"auto", "csr-rowgroup", "rowpanel-R4", "rowpanel-R8", "team-R8", "team2-R8", "team2n-R8"};
 int crp_spmm_variant_count(void) { return (int) (sizeof(k_variant_names) / sizeof(k_variant_names[0])); }
 const char *crp_spmm_variant_name(int variant)
 {
@@ -806,6 +888,13 @@ int crp_spmm_csr_f64(crp_csr_dev_p A, int layout, int n, const double *B0, long 
     // 0.65 / 0.63; at n = 96 -- a tile of 128 columns three quarters used -- 1.17 / 1.00 / 0.94, at n = 32 1.6 x)
     if (variant == 0 && A->team2_pays && n >= A->team2_min_n && crp::spmm_team2_applicable(a)) v = 5;
     if (v == 5 && (!crp::spmm_team2_applicable(a) || A->nnz == 0 || A->nrow < 8)) v = 3;
+    // narrow operands (24 <= n <= 64): the team kernel that takes several union entries per instruction
+    {
+        crp::Team2NArgs tn;
+        tn.G = n <= 32 ? 4 : 2;
+        if (variant == 0 && v != 5 && A->team2_pays && team2n_auto() && n <= 64 && A->nnz > 0 && A->nrow >= 8 && crp::spmm_team2n_applicable(tn, a)) v = 6;
+        if (v == 6 && (!crp::spmm_team2n_applicable(tn, a) || A->nnz == 0 || A->nrow < 8)) v = 3;
+    }
     // the derived formats hold the rows in processing order: their C row map is chosen per launch, AFTER every fallback has
     // resolved (a re-ordered matrix that falls back to the CSR kernel writes through the caller's map)
     int *const fmt_map = A->rowmap_fmt != nullptr ? A->rowmap_fmt : A->rowmap;
@@ -823,6 +912,18 @@ int crp_spmm_csr_f64(crp_csr_dev_p A, int layout, int n, const double *B0, long 
         t.gsync = d.gsync; t.gsync_tiles = d.gsync_tiles; t.gsync_ngen = d.gsync_ngen; t.wgs = d.wgs;
         for (int x = 0; x < 8; x++) t.nreal[x] = d.nreal[x];
         return (int) crp::spmm_rm_f64_team2(t, a, (hipStream_t) stream);
+    }
+    if (v == 6)
+    {
+        a.rowmap = fmt_map;
+        A->last_variant = 6;
+        const int G = n <= 32 ? 4 : 2;
+        const int rc = ensure_team2n(A, (hipStream_t) stream, G);
+        if (rc != 0) return rc;
+        const Team2NDev &d = A->team2n[G == 2 ? 1 : 0];
+        crp::Team2NArgs t;
+        t.G = d.G; t.nteam = d.nteam; t.ngrid = d.ngrid; t.tgrid = d.tgrid; t.tpanel = d.tpanel; t.tinfo = d.tinfo; t.trec = d.trec; t.tvoff = d.tvoff; t.tval = d.tval;
+        return (int) crp::spmm_rm_f64_team2n(t, a, (hipStream_t) stream);
     }
     if (v == 4 && (!crp::spmm_team_applicable(a) || A->b1_rows > 0)) v = 3;   // team kernel: one B source, 256-column tile
     if (v >= 2 && (!crp::spmm_panel_applicable(a) || A->nnz == 0)) v = 1;   // narrow / unaligned operands
@@ -973,6 +1074,38 @@ int crp_team2_format_host_grid(int **tgrid, int *ngrid)
     *ngrid = (int) g_last_tgrid.size();
     *tgrid = (int *) malloc(sizeof(int) * (g_last_tgrid.size() + 1));
     if (!g_last_tgrid.empty()) memcpy(*tgrid, g_last_tgrid.data(), sizeof(int) * g_last_tgrid.size());
+    return 0;
+}
+
+int crp_team2n_format_host(int nrow, const int *rowptr, const int *colidx, const double *val, int G, int *nteam, int *lattice, int **tpanel,
+                           int **tinfo, unsigned **trec, long long *nrecwords, long long **tvoff, double **tval, long long *nvalent,
+                           int **tgrid, int *ngrid, unsigned **vmap, long long *stats)
+{
+    if (nrow < 0 || rowptr == NULL || (G != 2 && G != 4) || !nteam || !tpanel || !tinfo || !trec || !nrecwords || !tvoff || !tval || !nvalent || !tgrid || !ngrid)
+        return -1;
+    crp::PanelHost h;
+    crp::build_panels(nrow, rowptr, colidx, val, 8, &h, false, false);
+    crp::Team2NHost th;
+    th.G = G;
+    crp::build_team2n(h, nrow, rowptr, colidx, &th);
+    *nteam = th.nteam;
+    if (lattice) *lattice = th.lattice ? 1 : 0;
+    auto dup = [](const void *src, size_t bytes) {
+        void *p = malloc(bytes + 8);
+        if (bytes) memcpy(p, src, bytes);
+        return p;
+    };
+    *tpanel = (int *) dup(th.tpanel.data(), sizeof(int) * th.tpanel.size());
+    *tinfo = (int *) dup(th.tinfo.data(), sizeof(int) * th.tinfo.size());
+    *tgrid = (int *) dup(th.tgrid.data(), sizeof(int) * th.tgrid.size());
+    *ngrid = (int) th.tgrid.size();
+    *trec = (unsigned *) dup(th.trec.data(), sizeof(unsigned) * th.trec.size());
+    *nrecwords = (long long) th.trec.size();
+    *tvoff = (long long *) dup(th.tvoff.data(), sizeof(long long) * th.tvoff.size());
+    *tval = (double *) dup(th.tval.data(), sizeof(double) * (size_t) th.nvalues);
+    *nvalent = th.nvalues;
+    if (vmap) *vmap = (unsigned *) dup(th.vmap.data(), sizeof(unsigned) * th.vmap.size());
+    if (stats) { stats[0] = th.rounds; stats[1] = th.parts; stats[2] = th.slots_filled; }
     return 0;
 }
 

@@ -94,6 +94,19 @@ struct Team2Args          // panel_format.h, Team2Host
     int             nreal[8];      // real teams of every run (the -1 entries sit at its end)
 };
 
+struct Team2NArgs         // panel_format.h, Team2NHost
+{
+    int G;                     // entries per instruction: 4 (n <= 32) or 2 (n <= 64)
+    int nteam;
+    int ngrid;                 // entries of tgrid, a multiple of 8
+    const int      *tgrid;
+    const int      *tpanel;    // 8 * nteam
+    const int      *tinfo;     // 2 * nteam: rounds, first record (in rounds)
+    const uint32_t *trec;      // 128 words per round
+    const long long *tvoff;    // 8 * nteam
+    const double   *tval;
+};
+
 // narrow_kernel.hip: row-panel format, n <= 64 (several entries of a panel per instruction)
 bool spmm_narrow_applicable(const PanelArgs &p, const SpmmArgs &a);
 hipError_t spmm_rm_f64_narrow(const PanelArgs &p, const SpmmArgs &a, hipStream_t s);
@@ -105,6 +118,10 @@ bool spmm_panel_applicable(const SpmmArgs &a);
 hipError_t spmm_rm_f64_panel(const PanelArgs &p, const SpmmArgs &a, hipStream_t s);
 bool spmm_team_applicable(const SpmmArgs &a);
 hipError_t spmm_rm_f64_team(const TeamArgs &t, const SpmmArgs &a, hipStream_t s);
+
+// team2n_kernel.hip
+bool spmm_team2n_applicable(const Team2NArgs &t, const SpmmArgs &a);
+hipError_t spmm_rm_f64_team2n(const Team2NArgs &t, const SpmmArgs &a, hipStream_t s);
 
 // team2_kernel.hip
 bool spmm_team2_applicable(const SpmmArgs &a);

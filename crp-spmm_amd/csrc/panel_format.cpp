@@ -1850,6 +1850,225 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
     clk.lap("build_team2: release");
 }
 
+// ---- team2n streams (panel_format.h) ----------------------------------------------------------------------
+void build_team2n(const PanelHost &p, int nrow, const int *rowptr, const int *colidx, Team2NHost *out, const int *colpos)
+{
+    constexpr int W = 8, T = 8;
+    const int G = out->G == 2 ? 2 : 4;
+    out->G = G;
+    const int S = W * G, PMAX = 4 * G;                                       // slots of a round, parts of a wave and round
+    PhaseClock clk;
+    released_async<TeamHost> th_owner;
+    TeamHost &th = *th_owner;
+    build_teams(p, nrow, rowptr, colidx, &th, T, colpos, false);
+    clk.lap("build_team2n: build_teams total");
+    const int nteam = th.nteam;
+    out->nteam = nteam;
+    out->lattice = th.lattice;
+    out->tpanel = th.tpanel;
+    out->torder = th.torder;
+    const int Skey = th.lattice ? 8 * th.st : 8 * T;
+    auto mask_of = [&](size_t q) { return (p.pmask4[q >> 2] >> (8 * (q & 3))) & 0xFFu; };
+    auto key = [&](int q) {
+        const int c = th.tcol[(size_t) q];
+        const long long ps = c >= 0 ? (colpos ? colpos[c] : c) : (long long) (~c);
+        if (th.clustered && c >= 0 && ps / 8 < (long long) th.plocal.size()) return (int) (ps % 8) * 16 + th.plocal[(size_t) (ps / 8)];
+        return (int) (ps % Skey);
+    };
+    struct PartN { unsigned char slot, mask; int src; };
+    struct TeamOutN
+    {
+        int nr = 0, anycol = 0;
+        std::vector<int> col;                 // nr * S (TEAM2_NOCOL = empty)
+        std::vector<PartN> parts;             // (nr * W + w) * PMAX
+        std::vector<unsigned char> pc;        // nr * W: parts of wave w in round r
+    };
+    std::vector<TeamOutN> res((size_t) nteam);
+    parallel_chunks(nteam, 32, [&](long long b, long long e, int) {
+        std::vector<int> nodes;
+        for (long long g = b; g < e; g++)
+        {
+            TeamOutN &to = res[(size_t) g];
+            nodes.clear();
+            for (int q = th.tptr[(size_t) g]; q < th.tptr[(size_t) g + 1]; q++)
+            {
+                bool used = false;
+                for (int w = 0; w < T; w++) used = used || th.tsrc[(size_t) q * T + (size_t) w] >= 0;
+                if (used) nodes.push_back(q);
+            }
+            std::stable_sort(nodes.begin(), nodes.end(), [&](int x, int y) { return key(x) < key(y); });
+            to.anycol = nodes.empty() ? 0 : th.tcol[(size_t) nodes[0]];
+            const size_t nn = nodes.size();
+            std::vector<char> taken(nn, 0);
+            size_t head = 0, left = nn;
+            while (left > 0)
+            {
+                int cnt[W], vals[W];
+                for (int w = 0; w < W; w++) cnt[w] = vals[w] = 0;
+                int nslot = 0;
+                const size_t base_col = to.col.size();
+                to.col.resize(base_col + (size_t) S, TEAM2_NOCOL);
+                to.parts.resize(to.parts.size() + (size_t) W * PMAX);
+                to.pc.resize(to.pc.size() + (size_t) W, 0);
+                while (head < nn && taken[head]) head++;
+                int seen = 0;
+                for (size_t t = head; t < nn && nslot < S && seen < 4 * S; t++)
+                {
+                    if (taken[t]) continue;
+                    seen++;
+                    const int q = nodes[t];
+                    bool fits = true;
+                    for (int w = 0; w < W; w++)
+                    {
+                        const int src = th.tsrc[(size_t) q * T + (size_t) w];
+                        if (src < 0) continue;
+                        if (cnt[w] + 1 > PMAX || vals[w] + __builtin_popcount(mask_of((size_t) src)) > TEAM2N_MAXVAL) fits = false;
+                    }
+                    if (!fits) continue;
+                    for (int w = 0; w < W; w++)
+                    {
+                        const int src = th.tsrc[(size_t) q * T + (size_t) w];
+                        if (src < 0) continue;
+                        PartN pt;
+                        pt.slot = (unsigned char) nslot;
+                        pt.mask = (unsigned char) mask_of((size_t) src);
+                        pt.src = src;
+                        to.parts[((size_t) to.nr * W + (size_t) w) * PMAX + (size_t) cnt[w]] = pt;
+                        cnt[w]++;
+                        vals[w] += __builtin_popcount(pt.mask);
+                        to.pc[(size_t) to.nr * W + (size_t) w]++;
+                    }
+                    to.col[base_col + (size_t) nslot] = th.tcol[(size_t) q];
+                    nslot++;
+                    taken[t] = 1;
+                    left--;
+                }
+                if (nslot == 0) { fprintf(stderr, "[FATAL] team2n scheduler: a round placed nothing\n"); abort(); }
+                to.nr++;
+            }
+        }
+    });
+    clk.lap("build_team2n: rounds");
+    // ---- layout
+    out->tinfo.assign((size_t) nteam * 2, 0);
+    out->tvoff.assign((size_t) nteam * W + 1, 0);
+    long long rec0 = 0, run = 0;
+    out->rounds = out->parts = out->slots_filled = 0;
+    {
+        std::vector<long long> wunits((size_t) nteam * W, 0);
+        parallel_chunks(nteam, 256, [&](long long b, long long e, int) {
+            for (long long g = b; g < e; g++)
+            {
+                const TeamOutN &to = res[(size_t) g];
+                for (int w = 0; w < W; w++)
+                {
+                    long long u = 0;
+                    for (int r = 0; r < to.nr; r++)
+                    {
+                        int nv = 0;
+                        for (int i = 0; i < (int) to.pc[(size_t) r * W + (size_t) w]; i++) nv += __builtin_popcount(to.parts[((size_t) r * W + (size_t) w) * PMAX + (size_t) i].mask);
+                        u += (nv + TEAM2_VUNIT - 1) / TEAM2_VUNIT;
+                    }
+                    wunits[(size_t) g * W + (size_t) w] = u;
+                }
+            }
+        });
+        for (int g = 0; g < nteam; g++)
+        {
+            const TeamOutN &to = res[(size_t) g];
+            out->tinfo[(size_t) g * 2] = to.nr;
+            out->tinfo[(size_t) g * 2 + 1] = (int) rec0;
+            rec0 += to.nr;
+            out->rounds += to.nr;
+            for (int w = 0; w < W; w++)
+            {
+                out->tvoff[(size_t) g * W + (size_t) w] = run;
+                run += wunits[(size_t) g * W + (size_t) w];
+            }
+        }
+    }
+    out->tvoff[(size_t) nteam * W] = run;
+    out->nvalues = run * TEAM2_VUNIT;
+    if (rec0 >= (1LL << 31) / 128) { fprintf(stderr, "[FATAL] team2n format: too many rounds\n"); abort(); }
+    // launch grid: 8 runs of equal rounds
+    {
+        std::vector<int> cut(9, nteam);
+        long long total = 0;
+        for (int g = 0; g < nteam; g++) total += res[(size_t) g].nr + 2;
+        cut[0] = 0;
+        long long acc = 0;
+        int x = 1;
+        for (int i = 0; i < nteam && x < 8; i++)
+        {
+            acc += res[(size_t) out->torder[(size_t) i]].nr + 2;
+            while (x < 8 && acc * 8 >= total * x) cut[(size_t) x++] = i + 1;
+        }
+        int cpx = 1;
+        for (int q = 0; q < 8; q++) cpx = std::max(cpx, cut[(size_t) q + 1] - cut[(size_t) q]);
+        out->tgrid.assign((size_t) cpx * 8, -1);
+        for (int q = 0; q < 8; q++)
+            for (int i = cut[(size_t) q]; i < cut[(size_t) q + 1]; i++) out->tgrid[(size_t) q * cpx + (size_t) (i - cut[(size_t) q])] = out->torder[(size_t) i];
+    }
+    parallel_fill(out->trec, (size_t) (rec0 + 1) * 128, 0u);
+    parallel_fill(out->tval, (size_t) run * TEAM2_VUNIT + 256, 0.0);
+    big_vector<uint32_t> slot_of;
+    slot_of.resize(p.pcol.size() * 8);
+    parallel_chunks(nteam, 32, [&](long long b, long long e, int) {
+        for (long long g = b; g < e; g++)
+        {
+            const TeamOutN &to = res[(size_t) g];
+            for (int w = 0; w < W; w++)
+            {
+                long long voff = 0;                                           // units, inside the wave's stream
+                const long long e0 = out->tvoff[(size_t) g * W + (size_t) w] * TEAM2_VUNIT;
+                for (int r = 0; r < to.nr; r++)
+                {
+                    uint32_t *rec = &out->trec[((size_t) out->tinfo[(size_t) g * 2 + 1] + (size_t) r) * 128 + (size_t) w * 16];
+                    const PartN *pp = &to.parts[((size_t) r * W + (size_t) w) * PMAX];
+                    const int np_ = to.pc[(size_t) r * W + (size_t) w];
+                    long long at = e0 + voff * TEAM2_VUNIT;
+                    int nv = 0;
+                    for (int i = 0; i < np_; i++)
+                    {
+                        const int step = i / G, qq = i % G;
+                        rec[6 + 2 * step] |= (uint32_t) pp[i].mask << (8 * qq);
+                        rec[7 + 2 * step] |= (uint32_t) pp[i].slot << (5 * qq);
+                        for (int rr = 0; rr < 8; rr++)
+                            if ((pp[i].mask >> rr) & 1)
+                            {
+                                out->tval[(size_t) at] = p.pval[(size_t) pp[i].src * 8 + (size_t) rr];
+                                slot_of[(size_t) pp[i].src * 8 + (size_t) rr] = (uint32_t) at;
+                                at++;
+                                nv++;
+                            }
+                    }
+                    rec[0] = (uint32_t) np_ | ((uint32_t) nv << 8);
+                    rec[1] = (uint32_t) voff;
+                    for (int qq = 0; qq < G; qq++)
+                    {
+                        const int c = to.col[(size_t) r * S + (size_t) (w * G + qq)];
+                        rec[2 + qq] = (uint32_t) (c != TEAM2_NOCOL ? c : to.anycol);
+                    }
+                    voff += (nv + TEAM2_VUNIT - 1) / TEAM2_VUNIT;
+                }
+            }
+        }
+    });
+    for (int g = 0; g < nteam; g++)
+    {
+        const TeamOutN &to = res[(size_t) g];
+        for (int r = 0; r < to.nr; r++)
+            for (int sl = 0; sl < S; sl++) out->slots_filled += to.col[(size_t) r * S + (size_t) sl] != TEAM2_NOCOL;
+        for (unsigned char c : to.pc) out->parts += c;
+    }
+    clk.lap("build_team2n: records, value streams");
+    out->vmap.resize(p.pmap.size());
+    parallel_chunks((long long) p.pmap.size(), 1 << 18, [&](long long b, long long e, int) {
+        for (long long nz = b; nz < e; nz++) out->vmap[(size_t) nz] = slot_of[(size_t) p.pmap[(size_t) nz]];
+    });
+    clk.lap("build_team2n: value-update map");
+}
+
 void apply_team_schedule(PanelHost *p, const TeamHost &t)
 {
     const int R = p->R, T = t.T;

@@ -194,6 +194,37 @@ struct Team2Host
 // rows of A, for the phase key of the union order (see build_team2); NULL = the column index itself.
 void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *colidx, Team2Host *out, const int *colpos = nullptr);
 
+// ---- team2n: the streams of the narrow-operand team kernel (csrc/team2n_kernel.hip) -----------------------------------
+// Operands of at most 64 fp64 columns: a B row slice fills a quarter (n <= 32) or half (n <= 64) of a wave, so the kernel takes
+// G = 4 or 2 union entries PER INSTRUCTION (lane group q holds entry q, rows an entry lacks are switched off through EXEC, as in
+// narrow_kernel.hip) -- from the LDS ring of a team, so that a B row slice is requested from L2 once per 64 rows (the row-panel
+// format requests it once per panel entry: 11 against 5 requests per B row on the pwtk stand-in, 10.9 against 4.4 on nlpkkt).
+// Same teams as team2 (8 panels on 8 waves).  A round has 8 G slots; wave w fetches slots w G .. w G + G - 1 with ONE LDS-DMA
+// instruction (lane group q fetches slot w G + q: 1024 / G bytes).  What a wave owns of a round is up to 4 G parts = (slot, row
+// mask) pairs -- no contiguous ranges: the mask does the work --, taken G at a time ("steps").  Its values are compact: one
+// block per round (the present rows of its parts, in part order, padded to TEAM2_VUNIT values).  Record of (round, wave), 16 words:
+//   [0] bits 0-4 parts, bits 8-16 values of the block;  [1] offset of the block in the wave's stream (units of TEAM2_VUNIT);
+//   [2 .. 5] columns (two-source encoding) of the G slots the wave fetches for THIS round (an empty slot: a row of the team);
+//   [6 + 2 s], [7 + 2 s] step s: masks (8 bits per part), slots (5 bits per part);  [14], [15] spare.
+// Records of a round are contiguous (8 waves x 16 words); team g's first round is record tinfo[2 g + 1], it has tinfo[2 g] rounds.
+constexpr int TEAM2N_MAXVAL = 128;             // values of one wave's block (1 KiB of LDS per ring set)
+struct Team2NHost
+{
+    int G = 4;                       // entries per instruction: 4 (n <= 32) or 2 (n <= 64); set before build_team2n
+    int nteam = 0;
+    bool lattice = false;
+    std::vector<int>       tpanel;   // 8 * nteam
+    std::vector<int>       torder;
+    std::vector<int>       tgrid;    // the launch grid, as Team2Host::tgrid
+    std::vector<int>       tinfo;    // 2 * nteam: rounds, first record (in rounds)
+    big_vector<uint32_t>   trec;     // 128 words per round
+    std::vector<long long> tvoff;    // 8 * nteam + 1: first value of wave w's stream (units of TEAM2_VUNIT)
+    big_vector<double>     tval;
+    std::vector<uint32_t>  vmap;     // per CSR nonzero: its index in tval
+    long long nvalues = 0, rounds = 0, parts = 0, slots_filled = 0;
+};
+void build_team2n(const PanelHost &p, int nrow, const int *rowptr, const int *colidx, Team2NHost *out, const int *colpos = nullptr);
+
 // Number of panel entries (before padding) a given R would need: cheap pass used
 // to pick R.  colidx may carry the two-source encoding.
 long long count_panel_entries(int nrow, const int *rowptr, const int *colidx, int R);

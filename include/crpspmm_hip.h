@@ -118,7 +118,8 @@ int crp_csr_dev_reordered(crp_csr_dev_p A);
  * ldB, ldC: the create-time choice (crp_csr_dev_auto_variant), replaced by 5 (team2-R8) from 112 columns on (from 80 when
  * fewer than 35 % of the (row, entry) pairs of the R = 8 panels exist) where 64 consecutive rows share columns, and by 1
  * below 24 columns.  Operands that are not aligned like that fall back (5 -> 3 -> 1): what a product actually launched is
- * crp_csr_dev_last_variant(). */
+ * crp_csr_dev_last_variant().  Variant 6 (team2n-R8: the team kernel for 24 <= n <= 64, csrc/team2n_kernel.hip) is never
+ * chosen by auto unless CRPSPMM_TEAM2N=1: measured slower than the row-panel kernels at every width it covers. */
 int crp_csr_dev_resolved_variant(crp_csr_dev_p A, int n);
 /* the variant the last crp_spmm_csr_f64 / _f32 on this matrix launched (after every fallback), or 0 before the first */
 int crp_csr_dev_last_variant(crp_csr_dev_p A);
@@ -187,6 +188,20 @@ int crp_team2_format_host_grid(int **tgrid, int *ngrid);
 /* 1 when the value blocks of those streams are compact (a part of len rows holds len values), 0 when every part holds 8
  * values, row r of part i at 8 i + r of the round's block (panels filled to 40 % and more; CRPSPMM_TEAM2_COMPACT=0|1 forces) */
 int crp_team2_format_host_compact(void);
+
+/* Host-only: the streams variant 6 ("team2n-R8", csrc/team2n_kernel.hip: operands of 24 .. 64 fp64 columns) consumes.  Same
+ * teams as variant 5 (8 panels of 8 rows on 8 waves); G = 4 (n <= 32) or 2 (n <= 64) union entries are taken per instruction.
+ * A round has 8 G ring slots; wave w fetches slots w G .. w G + G - 1.  Team g has tinfo[2g] rounds, its first is round
+ * tinfo[2g + 1] of trec, where round r, wave w owns the 16 words at trec[(r * 8 + w) * 16]: [0] parts (bits 0-4) | values of
+ * the wave's block (bits 8-16); [1] offset of the block (units of 4 values) in the wave's stream, which starts at
+ * tval[4 * tvoff[8g + w]]; [2 .. 2 + G) the columns of the slots the wave fetches for this round (two-source encoding, an empty
+ * slot names a row of the team); [6 + 2 s], [7 + 2 s] step s = parts s G .. s G + G - 1: row masks (8 bits each), ring slots
+ * (5 bits each).  A block holds the present rows' values of the wave's parts, in part order, rows ascending.  tgrid: the launch
+ * grid (8 runs, -1 = none).  vmap[nz] = index in tval of CSR nonzero nz.  stats (3, may be NULL): rounds, parts, filled slots.
+ * malloc'd copies (caller frees).  Used by the CPU tests, which replay the streams in numpy. */
+int crp_team2n_format_host(int nrow, const int *rowptr, const int *colidx, const double *val, int G, int *nteam, int *lattice, int **tpanel,
+                           int **tinfo, unsigned **trec, long long *nrecwords, long long **tvoff, double **tval, long long *nvalent,
+                           int **tgrid, int *ngrid, unsigned **vmap, long long *stats);
 
 /* Host-only: the processing order of the rows of a square A that crp_csr_dev_create() applies for B-row
  * locality (csrc/locality.cpp: row groups with identical column lists, `nparts` slabs by breadth-first

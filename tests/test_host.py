@@ -740,3 +740,92 @@ def test_team2_streams_replay(crp, orc, monkeypatch, order):
         got = _replay_team2(t, m, B, va)
         ref = orc.spmm_csr(rp, ci, va, B)
         assert orc.rel_fro_err(ref, got) <= 1e-13, name
+
+
+def _replay_team2n(t, m, B, va):
+    """What csrc/team2n_kernel.hip does with the streams of crp_team2n_format_host, in numpy (B1-less)."""
+    G = t["G"]
+    out = np.zeros((m, B.shape[1]))
+    done = np.zeros(m, dtype=np.int64)
+    assert np.array_equal(t["tval"][t["vmap"]], va)
+    seen_teams = []
+    for g in t["tgrid"].ravel():
+        if g < 0:
+            continue
+        seen_teams.append(int(g))
+        nr, r0 = (int(x) for x in t["tinfo"][g])
+        acc = np.zeros((8, 8, B.shape[1]))
+        for r in range(nr):
+            recs = t["trec"][r0 + r]                                       # [8 waves, 16 words]
+            cols = np.array([[int(np.int32(recs[w, 2 + q])) for q in range(G)] for w in range(8)]).ravel()   # slot w G + q
+            assert np.all(cols >= 0) and np.all(cols < B.shape[0])        # empty slots name a real row: the DMA reads it
+            for w in range(8):
+                rec = [int(x) for x in recs[w]]
+                npart, nv = rec[0] & 31, (rec[0] >> 8) & 0x1FF
+                assert npart <= 4 * G and nv <= 128
+                first = 4 * (int(t["tvoff"][8 * g + w]) + rec[1])
+                assert first + nv <= 4 * int(t["tvoff"][8 * g + w + 1])   # the block lies inside the wave's stream
+                block = t["tval"][first:first + nv]
+                at = 0
+                for i in range(4 * G):
+                    step, qq = divmod(i, G)
+                    mask = (rec[6 + 2 * step] >> (8 * qq)) & 0xFF
+                    slot = (rec[7 + 2 * step] >> (5 * qq)) & 31
+                    if i >= npart:
+                        assert mask == 0                                   # the kernel takes whole steps: idle lane groups have no rows
+                        continue
+                    assert mask != 0 and slot < 8 * G
+                    for rr in range(8):
+                        if (mask >> rr) & 1:
+                            acc[w, rr] += block[at] * B[cols[slot]]
+                            at += 1
+                assert at == nv
+        for w in range(8):
+            p = int(t["tpanel"][g, w])
+            if p < 0:
+                assert not acc[w].any()
+                continue
+            for rr in range(8):
+                row = p * 8 + rr
+                if row < m:
+                    out[row] = acc[w, rr]
+                    done[row] += 1
+                else:
+                    assert not acc[w, rr].any()
+    assert sorted(seen_teams) == list(range(t["nteam"]))
+    assert np.all(done == 1)
+    return out
+
+
+@pytest.mark.parametrize("G", [4, 2])
+def test_team2n_streams_replay(crp, orc, G):
+    """The streams of the narrow-operand team kernel (variant 6), replayed in numpy: every row is produced once and equals
+    the oracle's product -- same matrices as the team2 replay (lattice / clustered teams, random, duplicates, ragged sizes)."""
+    from crp_spmm_amd import gen, hip
+    rng = np.random.default_rng(4)
+    cases = []
+    offs = tuple(range(1, 15)) + tuple(range(304, 310)) + tuple(range(3040, 3046))
+    cases.append(("lattice",) + gen.banded_fem(9120, offsets=offs, seed=3))
+    nx, ny, nz = 300, 5, 3
+    cases.append(("clustered",) + gen.banded_fem(nx * ny * nz, offsets=(1, 2, 3, nx, nx + 1, nx * ny, nx * ny + 1), seed=3))
+    cases.append(("random",) + gen.random_csr(611, 611, 14, seed=5, empty_every=9))
+    cases.append(("kkt",) + gen.kkt3d(16))
+    cases.append(("random40",) + gen.random_csr(777, 1234, 40, seed=3))     # waves with more than 4 G parts on a round's slots
+    cases.append(("dense64",) + gen.random_csr(64, 40, 36, seed=7))         # blocks that would pass 128 values
+    cases.append(("tiny",) + gen.random_csr(13, 40, 5, seed=1))
+    rp, ci, va = gen.random_csr(200, 64, 6, seed=8)
+    ci2 = ci.copy()
+    ci2[1::7] = ci2[0::7][:ci2[1::7].size]
+    cases.append(("dups", rp, ci2, va))
+    for name, rp, ci, va in cases:
+        m = len(rp) - 1
+        k = int(ci.max()) + 1 if ci.size else 1
+        t = hip.team2n_format_host(rp, ci, va, G=G)
+        assert np.array_equal(np.sort(t["tpanel"][t["tpanel"] >= 0]), np.arange((m + 7) // 8)), name
+        B = rng.uniform(-1, 1, size=(k, 3))
+        got = _replay_team2n(t, m, B, va)
+        ref = orc.spmm_csr(rp, ci, va, B)
+        assert orc.rel_fro_err(ref, got) <= 1e-13, name
+        if name == "lattice":
+            # the point of the format: a B row is fetched once per team, not once per panel entry
+            assert t["slots_filled"] < 0.6 * t["parts"], (t["slots_filled"], t["parts"])
