@@ -155,6 +155,10 @@ SIGNATURES = {
     "crp_team2n_format_host": (_I, [_I, c_int_p, c_int_p, c_dbl_p, _I, c_int_p, c_int_p, C.POINTER(c_int_p), C.POINTER(c_int_p),
                                     C.POINTER(C.POINTER(C.c_uint)), C.POINTER(_LL), C.POINTER(C.POINTER(_LL)), C.POINTER(c_dbl_p),
                                     C.POINTER(_LL), C.POINTER(c_int_p), c_int_p, C.POINTER(C.POINTER(C.c_uint)), C.POINTER(_LL)]),
+    "crp_team2r_format_host": (_I, [_I, c_int_p, c_int_p, c_dbl_p, _I, c_int_p, c_int_p, C.POINTER(c_int_p), C.POINTER(c_int_p),
+                                    C.POINTER(C.POINTER(C.c_uint)), C.POINTER(_LL), C.POINTER(C.POINTER(_LL)), C.POINTER(c_dbl_p),
+                                    C.POINTER(_LL), C.POINTER(c_int_p), c_int_p, C.POINTER(C.POINTER(C.c_uint)), C.POINTER(_LL),
+                                    C.POINTER(C.POINTER(C.c_uint))]),
     "crp_locality_order_host": (_I, [_I, _I, c_int_p, c_int_p, _I, c_int_p, c_dbl_p]),
     "crp_spmm_csr_f32": (_I, [_V, _I, _V, _LL, _V, _LL, _V, _LL, _I, _V]),
     "crp_spmm_csr_f64": (_I, [_V, _I, _I, _V, _LL, _V, _LL, _V, _LL, _I, _V]),

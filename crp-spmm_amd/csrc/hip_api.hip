@@ -83,6 +83,9 @@ struct Team2NDev              // panel_format.h, Team2NHost: the narrow-operand 
     long long *tvoff = nullptr;
     double *tval = nullptr;
     uint32_t *tmap = nullptr;
+    uint32_t *tent = nullptr;      // team2r: the entry table (Team2RHost::tent); its C rows are filled for rows_epoch
+    long long rows_epoch = -1;
+    const int *rows_map = nullptr;
     long long value_entries = 0;
     bool lattice = false;
 };
@@ -104,7 +107,10 @@ struct crp_csr_dev
     Team2Dev team2p;          // teams of 16 panels on 8 waves, two panels per wave: variant 5 for operands of one 16-byte piece per
                               // lane (fp64: n <= 128, fp32: n <= 256)
     Team2NDev team2n[2];      // [0]: four entries per instruction (n <= 32), [1]: two (n <= 64)
+    Team2NDev team2r[2];      // the row-owner team kernel's streams (variant 7; Team2RHost: tvoff in units of 16 bytes, tval = the streams)
     int      auto_variant = 1; // what variant 0 resolves to below 96 columns (1 rowgroup, 2 panel R4, 3 panel R8)
+    long long rowmap_epoch = 0;    // bumped by crp_csr_dev_set_rowmap: the team2r entry tables hold C rows
+    bool     team2r_pays = false;  // narrow operands (24 .. 64 columns): the row-owner team kernel beats the row-panel kernels (panels mostly holes)
     bool     team2_pays = false;   // 64 consecutive rows (in format order) share columns: variant 0 takes team2 from team2_min_n columns on
     int      last_variant = 0;     // what the last product launched (crp_csr_dev_last_variant)
     int      team2_min_n = TEAM2_MIN_N;    // or TEAM2_MIN_N_SPARSE when the R = 8 panels are mostly holes
@@ -420,6 +426,63 @@ static int ensure_team2n(crp_csr_dev *A, hipStream_t stream, int G)
     clk.lap("ensure_team2n: upload");
     t.built = true;
     return 0;
+}
+
+static int ensure_team2r(crp_csr_dev *A, hipStream_t stream, int G)
+{
+    Team2NDev &t = A->team2r[G == 2 ? 1 : 0];
+    if (t.built) return 0;
+    crp::PhaseClock clk;
+    crp::released_async<crp::PanelHost> h_owner;
+    crp::PanelHost &h = *h_owner;
+    crp::build_panels(A->nrow, fmt_rowptr(A), fmt_colidx(A), fmt_val(A), 8, &h, false, false);
+    fmt_slotmap_to_caller(A, &h.pmap);
+    clk.lap("ensure_team2r: build_panels (R = 8)");
+    crp::released_async<crp::Team2RHost> th_owner;
+    crp::Team2RHost &th = *th_owner;
+    th.G = G == 2 ? 2 : 4;
+    std::vector<int> colpos;
+    if (!A->perm.empty())
+    {
+        colpos.resize(A->perm.size());
+        for (size_t i = 0; i < A->perm.size(); i++) colpos[(size_t) A->perm[i]] = (int) i;
+    }
+    crp::build_team2r(h, A->nrow, fmt_rowptr(A), fmt_colidx(A), &th, colpos.empty() ? nullptr : colpos.data());
+    clk.lap("ensure_team2r: build_team2n");
+    t.G = th.G;
+    t.nteam = th.nteam;
+    t.lattice = th.lattice;
+    t.ngrid = (int) th.tgrid.size();
+    t.value_entries = th.nwords;
+    auto up = [](void **dst, const void *src, size_t bytes, size_t pad) -> hipError_t {
+        hipError_t e = hipMalloc(dst, bytes + pad);
+        if (e == hipSuccess && pad) e = hipMemset((char *) *dst + bytes, 0, pad);
+        if (e == hipSuccess && bytes) e = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+        return e;
+    };
+    hipError_t e = up((void **) &t.tgrid, th.tgrid.data(), sizeof(int) * th.tgrid.size(), 4);
+    if (e == hipSuccess) e = up((void **) &t.tpanel, th.tpanel.data(), sizeof(int) * th.tpanel.size(), 4);
+    if (e == hipSuccess) e = up((void **) &t.tinfo, th.tinfo.data(), sizeof(int) * th.tinfo.size(), 16);
+    if (e == hipSuccess) e = up((void **) &t.trec, th.trec.data(), sizeof(uint32_t) * th.trec.size(), 1024);
+    if (e == hipSuccess) e = up((void **) &t.tvoff, th.tvoff.data(), sizeof(long long) * th.tvoff.size(), 8);
+    // (the streams: values and uint16 offsets; a wave's DMAs take whole 16-byte lanes of its block)
+    if (e == hipSuccess) e = up((void **) &t.tval, th.tval.data(), sizeof(double) * th.tval.size(), 4096);
+    if (e == hipSuccess) e = up((void **) &t.tmap, th.vmap.data(), sizeof(uint32_t) * th.vmap.size(), 4);
+    if (e == hipSuccess) e = up((void **) &t.tent, th.tent.data(), sizeof(uint32_t) * th.tent.size(), 1024);
+    t.rows_epoch = -1;
+    if (e != hipSuccess) return (int) e;
+    if (A->host_vals_stale && A->nnz > 0) CRP_TRY(crp::scatter_vals_f64(A->nnz, t.tmap, A->val, t.tval, stream));
+    clk.lap("ensure_team2r: upload");
+    t.built = true;
+    return 0;
+}
+
+// variant 0 on narrow operands: the row-owner team kernel where the R = 8 panels are mostly holes (CRPSPMM_TEAM2R=0|1 forces)
+static bool team2r_auto(const crp_csr_dev *A)
+{
+    const char *e = getenv("CRPSPMM_TEAM2R");
+    if (e != NULL) return atoi(e) != 0;
+    return A->team2r_pays;          // never set: the kernel does not beat the row-panel kernels at nlpkkt240 size (team2r_kernel.hip)
 }
 
 // variant 0 below the team2 threshold: the narrow team kernel (CRPSPMM_TEAM2N=0 keeps the row-panel kernels)
@@ -764,8 +827,9 @@ int crp_csr_dev_destroy(crp_csr_dev_p *A_)
         if (t2->tval32) (void) hipFree(t2->tval32);
         if (t2->gsync) (void) hipFree(t2->gsync);
     }
-    for (Team2NDev &tn : A->team2n)
+    for (Team2NDev *tnp : {&A->team2n[0], &A->team2n[1], &A->team2r[0], &A->team2r[1]})
     {
+        Team2NDev &tn = *tnp;
         if (tn.tgrid) (void) hipFree(tn.tgrid);
         if (tn.tpanel) (void) hipFree(tn.tpanel);
         if (tn.tinfo) (void) hipFree(tn.tinfo);
@@ -773,6 +837,7 @@ int crp_csr_dev_destroy(crp_csr_dev_p *A_)
         if (tn.tvoff) (void) hipFree(tn.tvoff);
         if (tn.tval) (void) hipFree(tn.tval);
         if (tn.tmap) (void) hipFree(tn.tmap);
+        if (tn.tent) (void) hipFree(tn.tent);
     }
     if (A->val32) (void) hipFree(A->val32);
     if (A->rowptr) (void) hipFree(A->rowptr);
@@ -794,8 +859,8 @@ int crp_csr_dev_update_values(crp_csr_dev_p A, const double *val, void *stream)
         if (A->pan[i].built && A->pan[i].entries * (long long) A->pan[i].R >= (1LL << 32)) return -5;
     if (A->team.built && A->team.entries * 8LL >= (1LL << 32)) return -5;
     if ((A->team2.built && A->team2.value_entries >= (1LL << 32)) || (A->team2p.built && A->team2p.value_entries >= (1LL << 32))) return -5;
-    for (Team2NDev &tn : A->team2n)
-        if (tn.built && tn.value_entries >= (1LL << 32)) return -5;
+    for (Team2NDev *tnp : {&A->team2n[0], &A->team2n[1], &A->team2r[0], &A->team2r[1]})
+        if (tnp->built && tnp->value_entries >= (1LL << 32)) return -5;
     int is_dev = 0;
     crp_dev_ptr_is_device(val, &is_dev);
     CRP_TRY(hipMemcpyAsync(A->val, val, sizeof(double) * (size_t) A->nnz, is_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
@@ -816,8 +881,8 @@ int crp_csr_dev_update_values(crp_csr_dev_p A, const double *val, void *stream)
     if (A->team.built) CRP_TRY(crp::scatter_vals_f64(A->nnz, A->team.tmap, A->val, A->team.tval, (hipStream_t) stream));
     for (Team2Dev *t2 : {&A->team2, &A->team2p})
         if (t2->built) CRP_TRY(crp::scatter_vals_f64(A->nnz, t2->tmap, A->val, t2->tval, (hipStream_t) stream));
-    for (Team2NDev &tn : A->team2n)
-        if (tn.built) CRP_TRY(crp::scatter_vals_f64(A->nnz, tn.tmap, A->val, tn.tval, (hipStream_t) stream));
+    for (Team2NDev *tnp : {&A->team2n[0], &A->team2n[1], &A->team2r[0], &A->team2r[1]})
+        if (tnp->built) CRP_TRY(crp::scatter_vals_f64(A->nnz, tnp->tmap, A->val, tnp->tval, (hipStream_t) stream));
     // fp32 copies follow
     if (A->val32) CRP_TRY(crp::convert_f64_f32(A->nnz, A->val, A->val32, (hipStream_t) stream));
     for (Team2Dev *t2 : {&A->team2, &A->team2p})
@@ -827,6 +892,7 @@ int crp_csr_dev_update_values(crp_csr_dev_p A, const double *val, void *stream)
 
 int crp_csr_dev_set_rowmap(crp_csr_dev_p A, const int *rowmap, int c_nrow)
 {
+    if (A != NULL) A->rowmap_epoch++;
     if (A == NULL || (rowmap != NULL && c_nrow < 0)) return -1;
     if (A->rowmap) { CRP_TRY(hipFree(A->rowmap)); A->rowmap = nullptr; }
     A->c_nrow = A->nrow;
@@ -857,7 +923,7 @@ int crp_csr_dev_nrow(crp_csr_dev_p A) { return A ? A->nrow : -1; }
 long long crp_csr_dev_nnz(crp_csr_dev_p A) { return A ? A->nnz : -1; }
 long long crp_csr_dev_bytes(crp_csr_dev_p A) { return A ? 12LL * A->nnz + 4LL * ((long long) A->nrow + 1) : -1; }
 
-static const char *k_variant_names[] = {"auto", "csr-rowgroup", "rowpanel-R4", "rowpanel-R8", "team-R8", "team2-R8", "team2n-R8"};
+static const char *k_variant_names[] = {"auto", "csr-rowgroup", "rowpanel-R4", "rowpanel-R8", "team-R8", "team2-R8", "team2n-R8", "team2r-R8"};
 int crp_spmm_variant_count(void) { return (int) (sizeof(k_variant_names) / sizeof(k_variant_names[0])); }
 const char *crp_spmm_variant_name(int variant)
 {
@@ -894,6 +960,9 @@ int crp_spmm_csr_f64(crp_csr_dev_p A, int layout, int n, const double *B0, long 
         tn.G = n <= 32 ? 4 : 2;
         if (variant == 0 && v != 5 && A->team2_pays && team2n_auto() && n <= 64 && A->nnz > 0 && A->nrow >= 8 && crp::spmm_team2n_applicable(tn, a)) v = 6;
         if (v == 6 && (!crp::spmm_team2n_applicable(tn, a) || A->nnz == 0 || A->nrow < 8)) v = 3;
+        // ... or, where the panels are mostly holes, the one whose lane groups own rows (variant 7)
+        if (variant == 0 && v != 5 && v != 6 && A->team2_pays && team2r_auto(A) && n <= 64 && A->nnz > 0 && A->nrow >= 8 && crp::spmm_team2r_applicable(tn, a)) v = 7;
+        if (v == 7 && (!crp::spmm_team2r_applicable(tn, a) || A->nnz == 0 || A->nrow < 8)) v = 3;
     }
     // the derived formats hold the rows in processing order: their C row map is chosen per launch, AFTER every fallback has
     // resolved (a re-ordered matrix that falls back to the CSR kernel writes through the caller's map)
@@ -923,7 +992,27 @@ int crp_spmm_csr_f64(crp_csr_dev_p A, int layout, int n, const double *B0, long 
         const Team2NDev &d = A->team2n[G == 2 ? 1 : 0];
         crp::Team2NArgs t;
         t.G = d.G; t.nteam = d.nteam; t.ngrid = d.ngrid; t.tgrid = d.tgrid; t.tpanel = d.tpanel; t.tinfo = d.tinfo; t.trec = d.trec; t.tvoff = d.tvoff; t.tval = d.tval;
+        t.tent = nullptr;
         return (int) crp::spmm_rm_f64_team2n(t, a, (hipStream_t) stream);
+    }
+    if (v == 7)
+    {
+        a.rowmap = fmt_map;
+        A->last_variant = 7;
+        const int G = n <= 32 ? 4 : 2;
+        const int rc = ensure_team2r(A, (hipStream_t) stream, G);
+        if (rc != 0) return rc;
+        Team2NDev &d = A->team2r[G == 2 ? 1 : 0];
+        crp::Team2NArgs t;
+        t.G = d.G; t.nteam = d.nteam; t.ngrid = d.ngrid; t.tgrid = d.tgrid; t.tpanel = d.tpanel; t.tinfo = d.tinfo; t.trec = d.trec; t.tvoff = d.tvoff; t.tval = d.tval;
+        t.tent = d.tent;
+        if (d.rows_epoch != A->rowmap_epoch || d.rows_map != a.rowmap)      // the C rows of the panels, once per row map
+        {
+            CRP_TRY(crp::team2r_fill_rows(t, a, (hipStream_t) stream));
+            d.rows_epoch = A->rowmap_epoch;
+            d.rows_map = a.rowmap;
+        }
+        return (int) crp::spmm_rm_f64_team2r(t, a, (hipStream_t) stream);
     }
     if (v == 4 && (!crp::spmm_team_applicable(a) || A->b1_rows > 0)) v = 3;   // team kernel: one B source, 256-column tile
     if (v >= 2 && (!crp::spmm_panel_applicable(a) || A->nnz == 0)) v = 1;   // narrow / unaligned operands
@@ -1106,6 +1195,39 @@ int crp_team2n_format_host(int nrow, const int *rowptr, const int *colidx, const
     *nvalent = th.nvalues;
     if (vmap) *vmap = (unsigned *) dup(th.vmap.data(), sizeof(unsigned) * th.vmap.size());
     if (stats) { stats[0] = th.rounds; stats[1] = th.parts; stats[2] = th.slots_filled; }
+    return 0;
+}
+
+int crp_team2r_format_host(int nrow, const int *rowptr, const int *colidx, const double *val, int G, int *nteam, int *lattice, int **tpanel,
+                           int **tinfo, unsigned **trec, long long *nrecwords, long long **tvoff, double **tval, long long *nwords,
+                           int **tgrid, int *ngrid, unsigned **vmap, long long *stats, unsigned **tent)
+{
+    if (nrow < 0 || rowptr == NULL || (G != 2 && G != 4) || !nteam || !tpanel || !tinfo || !trec || !nrecwords || !tvoff || !tval || !nwords || !tgrid || !ngrid)
+        return -1;
+    crp::PanelHost h;
+    crp::build_panels(nrow, rowptr, colidx, val, 8, &h, false, false);
+    crp::Team2RHost th;
+    th.G = G;
+    crp::build_team2r(h, nrow, rowptr, colidx, &th);
+    *nteam = th.nteam;
+    if (lattice) *lattice = th.lattice ? 1 : 0;
+    auto dup = [](const void *src, size_t bytes) {
+        void *p = malloc(bytes + 8);
+        if (bytes) memcpy(p, src, bytes);
+        return p;
+    };
+    *tpanel = (int *) dup(th.tpanel.data(), sizeof(int) * th.tpanel.size());
+    *tinfo = (int *) dup(th.tinfo.data(), sizeof(int) * th.tinfo.size());
+    *tgrid = (int *) dup(th.tgrid.data(), sizeof(int) * th.tgrid.size());
+    *ngrid = (int) th.tgrid.size();
+    *trec = (unsigned *) dup(th.trec.data(), sizeof(unsigned) * th.trec.size());
+    *nrecwords = (long long) th.trec.size();
+    *tvoff = (long long *) dup(th.tvoff.data(), sizeof(long long) * th.tvoff.size());
+    *tval = (double *) dup(th.tval.data(), sizeof(double) * (size_t) th.nwords);
+    *nwords = th.nwords;
+    if (vmap) *vmap = (unsigned *) dup(th.vmap.data(), sizeof(unsigned) * th.vmap.size());
+    if (stats) { stats[0] = th.rounds; stats[1] = th.steps; stats[2] = th.slots_filled; stats[3] = th.nnz; }
+    if (tent) *tent = (unsigned *) dup(th.tent.data(), sizeof(unsigned) * th.tent.size());
     return 0;
 }
 

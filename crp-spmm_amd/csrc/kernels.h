@@ -105,6 +105,7 @@ struct Team2NArgs         // panel_format.h, Team2NHost
     const uint32_t *trec;      // 128 words per round
     const long long *tvoff;    // 8 * nteam
     const double   *tval;
+    uint32_t       *tent;      // team2r: the entry table (Team2RHost::tent), or nullptr
 };
 
 // narrow_kernel.hip: row-panel format, n <= 64 (several entries of a panel per instruction)
@@ -122,6 +123,11 @@ hipError_t spmm_rm_f64_team(const TeamArgs &t, const SpmmArgs &a, hipStream_t s)
 // team2n_kernel.hip
 bool spmm_team2n_applicable(const Team2NArgs &t, const SpmmArgs &a);
 hipError_t spmm_rm_f64_team2n(const Team2NArgs &t, const SpmmArgs &a, hipStream_t s);
+
+// team2r_kernel.hip (Team2RHost streams; the argument block is Team2NArgs: same arrays, tvoff in units of 16 bytes)
+bool spmm_team2r_applicable(const Team2NArgs &t, const SpmmArgs &a);
+hipError_t spmm_rm_f64_team2r(const Team2NArgs &t, const SpmmArgs &a, hipStream_t s);
+hipError_t team2r_fill_rows(const Team2NArgs &t, const SpmmArgs &a, hipStream_t s);      // the C rows into the entry table: once per row map
 
 // team2_kernel.hip
 bool spmm_team2_applicable(const SpmmArgs &a);

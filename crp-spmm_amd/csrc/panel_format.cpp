@@ -653,7 +653,7 @@ static void build_key_csr(int n, F raw, std::vector<long long> *iptr, std::vecto
     });
 }
 
-void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *colidx, TeamHost *out, int T, const int *colpos, bool balanced)
+void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *colidx, TeamHost *out, int T, const int *colpos, bool balanced, int mix_mode)
 {
     constexpr int TMAX = 16;
     if (T != 4 && T != 6 && T != 8 && T != 16) T = 4;
@@ -720,6 +720,7 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
             long long small = 0;
             for (int q = 0; q < np; q++) small += (2LL * rc[(size_t) q] * np < tot);
             mix = small * 100 >= 15LL * np;
+            if (mix_mode >= 0) mix = mix_mode != 0;
             if (const char *em = getenv("CRPSPMM_TEAM2_MIX")) mix = atoi(em) != 0;
         }
         std::vector<int> pord((size_t) np);
@@ -2067,6 +2068,281 @@ void build_team2n(const PanelHost &p, int nrow, const int *rowptr, const int *co
         for (long long nz = b; nz < e; nz++) out->vmap[(size_t) nz] = slot_of[(size_t) p.pmap[(size_t) nz]];
     });
     clk.lap("build_team2n: value-update map");
+}
+
+// ---- team2r streams (panel_format.h) ----------------------------------------------------------------------
+void build_team2r(const PanelHost &p, int nrow, const int *rowptr, const int *colidx, Team2RHost *out, const int *colpos)
+{
+    constexpr int W = 8, T = 8;
+    const int G = out->G == 2 ? 2 : 4;
+    out->G = G;
+    const int S = 16 * G, SLOTB = 1024 / G, PERW = 2 * G;                   // slots of a round, bytes of a slot, slots a wave fetches
+    PhaseClock clk;
+    released_async<TeamHost> th_owner;
+    TeamHost &th = *th_owner;
+    // teams of ONE kind of panel (no primal + dual mixes: team2's rule for KKT systems): a wave's steps are its panel's, and the
+    // waves of a team meet at every round's barrier (nlpkkt stand-in: useful / issued row slots 0.32 mixed, 0.53 unmixed)
+    build_teams(p, nrow, rowptr, colidx, &th, T, colpos, false, 0);
+    clk.lap("build_team2r: build_teams total");
+    const int nteam = th.nteam;
+    out->nteam = nteam;
+    out->lattice = th.lattice;
+    out->tpanel = th.tpanel;
+    out->torder = th.torder;
+    const int Skey = th.lattice ? 8 * th.st : 8 * T;
+    auto mask_of = [&](size_t q) { return (p.pmask4[q >> 2] >> (8 * (q & 3))) & 0xFFu; };
+    // Order of a team's union entries over its rounds.  team2 sorts by a PHASE (position mod 8 first) so that its parts are
+    // contiguous row ranges; here a round should give every row of a panel about the same number of nonzeros (a wave's steps are
+    // the maximum over its 8 rows): the natural order of the columns does that -- a run of consecutive columns is one mesh line,
+    // which the 8 consecutive rows of a panel touch alike -- where the phase order gives a round the columns that only one or two
+    // of the 8 rows have (nlpkkt stand-in: 2.7 padded steps per nonzero against 1.3 with this order).  CRPSPMM_T2R_KEY=phase: the
+    // team2 order.
+    const bool phase_key = getenv("CRPSPMM_T2R_KEY") != NULL && strcmp(getenv("CRPSPMM_T2R_KEY"), "phase") == 0;
+    auto key = [&](int q) -> long long {
+        const int c = th.tcol[(size_t) q];
+        const long long ps = c >= 0 ? (colpos ? colpos[c] : c) : (1LL << 40) + (long long) (~c);
+        if (!phase_key) return ps;
+        if (th.clustered && c >= 0 && ps / 8 < (long long) th.plocal.size()) return (ps % 8) * 16 + th.plocal[(size_t) (ps / 8)];
+        return ps % Skey;
+    };
+    const bool deal = getenv("CRPSPMM_T2R_DEAL") == NULL || atoi(getenv("CRPSPMM_T2R_DEAL")) != 0;
+    struct ItemR { unsigned char slot; int src; };                            // a panel entry of a wave placed on a slot of the round
+    struct TeamOutR
+    {
+        int nr = 0, anycol = 0;
+        std::vector<int> col;                 // nr * S (TEAM2_NOCOL = empty)
+        std::vector<int> iptr;                // (nr * W) + 1: items of (round, wave)
+        std::vector<ItemR> items;
+        std::vector<unsigned char> lp;        // nr * W: padded steps
+    };
+    std::vector<TeamOutR> res((size_t) nteam);
+    parallel_chunks(nteam, 32, [&](long long b, long long e, int) {
+        std::vector<int> nodes;
+        std::vector<std::vector<ItemR>> wl((size_t) W);
+        for (long long g = b; g < e; g++)
+        {
+            TeamOutR &to = res[(size_t) g];
+            nodes.clear();
+            for (int q = th.tptr[(size_t) g]; q < th.tptr[(size_t) g + 1]; q++)
+            {
+                bool used = false;
+                for (int w = 0; w < T; w++) used = used || th.tsrc[(size_t) q * T + (size_t) w] >= 0;
+                if (used) nodes.push_back(q);
+            }
+            std::stable_sort(nodes.begin(), nodes.end(), [&](int x, int y) { return key(x) < key(y); });
+            // ... dealt out to the rounds like cards: round r takes the entries r, r + R, r + 2 R, ... of that order, so that every
+            // round is a uniform sample of the team's columns and every wave (and every row) finds about 1 / R of its nonzeros in
+            // it -- a wave waits at the round's barrier for the wave with the most steps (nlpkkt stand-in: mean / max steps of a
+            // round's waves 0.59 -> see DESIGN.md; consecutive runs instead: CRPSPMM_T2R_DEAL=0)
+            if (deal && nodes.size() > (size_t) S)
+            {
+                const size_t nn0 = nodes.size(), R = (nn0 + (size_t) S - 1) / (size_t) S;
+                std::vector<int> dealt;
+                dealt.reserve(nn0);
+                for (size_t r = 0; r < R; r++)
+                    for (size_t t = r; t < nn0; t += R) dealt.push_back(nodes[t]);
+                nodes.swap(dealt);
+            }
+            to.anycol = nodes.empty() ? 0 : th.tcol[(size_t) nodes[0]];
+            to.iptr.push_back(0);
+            const size_t nn = nodes.size();
+            std::vector<char> taken(nn, 0);
+            size_t head = 0, left = nn;
+            while (left > 0)
+            {
+                int cnt[W][8];
+                for (int w = 0; w < W; w++)
+                    for (int r = 0; r < 8; r++) cnt[w][r] = 0;
+                for (int w = 0; w < W; w++) wl[(size_t) w].clear();
+                int nslot = 0;
+                const size_t base_col = to.col.size();
+                to.col.resize(base_col + (size_t) S, TEAM2_NOCOL);
+                while (head < nn && taken[head]) head++;
+                int seen = 0;
+                for (size_t t = head; t < nn && nslot < S && seen < 3 * S; t++)
+                {
+                    if (taken[t]) continue;
+                    seen++;
+                    const int q = nodes[t];
+                    bool fits = true;
+                    for (int w = 0; w < W && fits; w++)
+                    {
+                        const int src = th.tsrc[(size_t) q * T + (size_t) w];
+                        if (src < 0) continue;
+                        const unsigned mk = mask_of((size_t) src);
+                        for (int r = 0; r < 8; r++)
+                            if (((mk >> r) & 1) && cnt[w][r] + 1 > TEAM2R_LCAP) fits = false;
+                    }
+                    if (!fits) continue;
+                    for (int w = 0; w < W; w++)
+                    {
+                        const int src = th.tsrc[(size_t) q * T + (size_t) w];
+                        if (src < 0) continue;
+                        const unsigned mk = mask_of((size_t) src);
+                        for (int r = 0; r < 8; r++) cnt[w][r] += (mk >> r) & 1;
+                        ItemR it;
+                        it.slot = (unsigned char) nslot;
+                        it.src = src;
+                        wl[(size_t) w].push_back(it);
+                    }
+                    to.col[base_col + (size_t) nslot] = th.tcol[(size_t) q];
+                    nslot++;
+                    taken[t] = 1;
+                    left--;
+                }
+                if (nslot == 0) { fprintf(stderr, "[FATAL] team2r scheduler: a round placed nothing\n"); abort(); }
+                for (int w = 0; w < W; w++)
+                {
+                    int mx = 0;
+                    for (int r = 0; r < 8; r++) mx = std::max(mx, cnt[w][r]);
+                    to.lp.push_back((unsigned char) ((mx + 3) / 4 * 4));
+                    to.items.insert(to.items.end(), wl[(size_t) w].begin(), wl[(size_t) w].end());
+                    to.iptr.push_back((int) to.items.size());
+                }
+                to.nr++;
+            }
+            if (to.nr == 0)                                                   // no nonzero in 64 rows: one empty round (the kernel's pipeline wants one)
+            {
+                to.col.assign((size_t) S, TEAM2_NOCOL);
+                for (int w = 0; w < W; w++)
+                {
+                    to.lp.push_back(0);
+                    to.iptr.push_back(0);
+                }
+                to.nr = 1;
+            }
+        }
+    });
+    clk.lap("build_team2r: rounds");
+    out->tinfo.assign((size_t) nteam * 2, 0);
+    out->tvoff.assign((size_t) nteam * W + 1, 0);
+    long long rec0 = 0, run = 0;                                              // run: units of 16 bytes
+    out->rounds = out->steps = out->nnz = out->slots_filled = 0;
+    for (int g = 0; g < nteam; g++)
+    {
+        const TeamOutR &to = res[(size_t) g];
+        out->tinfo[(size_t) g * 2] = to.nr;
+        out->tinfo[(size_t) g * 2 + 1] = (int) rec0;
+        rec0 += to.nr;
+        out->rounds += to.nr;
+        for (int w = 0; w < W; w++)
+        {
+            out->tvoff[(size_t) g * W + (size_t) w] = run;
+            long long u = 0;
+            for (int r = 0; r < to.nr; r++)
+            {
+                u += 5LL * to.lp[(size_t) r * W + (size_t) w] + 4;           // 80 Lp bytes of values and offsets + the 64-byte header
+                out->steps += to.lp[(size_t) r * W + (size_t) w];
+            }
+            run += u;
+        }
+        for (int c : to.col) out->slots_filled += c != TEAM2_NOCOL;
+    }
+    out->tvoff[(size_t) nteam * W] = run;
+    out->nwords = run * 2;
+    if (rec0 >= (1LL << 31) / 128 || run >= (1LL << 31)) { fprintf(stderr, "[FATAL] team2r format: streams too long for 32-bit offsets\n"); abort(); }
+    {
+        std::vector<int> cut(9, nteam);
+        long long total = 0;
+        for (int g = 0; g < nteam; g++) total += res[(size_t) g].nr + 1;
+        cut[0] = 0;
+        long long acc = 0;
+        int x = 1;
+        for (int i = 0; i < nteam && x < 8; i++)
+        {
+            acc += res[(size_t) out->torder[(size_t) i]].nr + 1;
+            while (x < 8 && acc * 8 >= total * x) cut[(size_t) x++] = i + 1;
+        }
+        int cpx = 1;
+        for (int q = 0; q < 8; q++) cpx = std::max(cpx, cut[(size_t) q + 1] - cut[(size_t) q]);
+        out->tgrid.assign((size_t) cpx * 8, -1);
+        for (int q = 0; q < 8; q++)
+            for (int i = cut[(size_t) q]; i < cut[(size_t) q + 1]; i++) out->tgrid[(size_t) q * cpx + (size_t) (i - cut[(size_t) q])] = out->torder[(size_t) i];
+    }
+    parallel_fill(out->trec, (size_t) (rec0 + 1) * 128, 0u);
+    parallel_fill(out->tval, (size_t) run * 2 + 512, 0.0);
+    big_vector<uint32_t> slot_of;
+    slot_of.resize(p.pcol.size() * 8);
+    parallel_chunks(nteam, 32, [&](long long b, long long e, int) {
+        for (long long g = b; g < e; g++)
+        {
+            const TeamOutR &to = res[(size_t) g];
+            for (int w = 0; w < W; w++)
+            {
+                long long at16 = 0;                                           // units of 16 bytes inside the wave's stream
+                const long long w0 = out->tvoff[(size_t) g * W + (size_t) w] * 2;   // first 8-byte word of the stream
+                for (int r = 0; r < to.nr; r++)
+                {
+                    uint32_t *rec = &out->trec[((size_t) out->tinfo[(size_t) g * 2 + 1] + (size_t) r) * 128 + (size_t) w * 16];
+                    const int Lp = to.lp[(size_t) r * W + (size_t) w];
+                    rec[0] = (uint32_t) Lp;
+                    rec[1] = (uint32_t) at16;
+                    for (int j = 0; j < PERW; j++)
+                    {
+                        const int c = to.col[(size_t) r * S + (size_t) (w * PERW + j)];
+                        rec[2 + j] = (uint32_t) (c != TEAM2_NOCOL ? c : to.anycol);
+                    }
+                    double *vals = &out->tval[(size_t) (w0 + at16 * 2)];                         // [8][Lp]
+                    uint16_t *offs = reinterpret_cast<uint16_t *>(vals + (size_t) 8 * Lp);       // [8][Lp]
+                    for (int i = 0; i < 8 * Lp; i++) offs[i] = (uint16_t) TEAM2R_ZERO;
+                    int fill[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                    for (int i = to.iptr[(size_t) r * W + (size_t) w]; i < to.iptr[(size_t) r * W + (size_t) w + 1]; i++)
+                    {
+                        const ItemR &it = to.items[(size_t) i];
+                        const unsigned mk = mask_of((size_t) it.src);
+                        for (int rr = 0; rr < 8; rr++)
+                            if ((mk >> rr) & 1)
+                            {
+                                const int st = fill[rr]++;
+                                vals[(size_t) rr * Lp + (size_t) st] = p.pval[(size_t) it.src * 8 + (size_t) rr];
+                                offs[(size_t) rr * Lp + (size_t) st] = (uint16_t) (it.slot * SLOTB);
+                                slot_of[(size_t) it.src * 8 + (size_t) rr] = (uint32_t) (w0 + at16 * 2 + (long long) rr * Lp + st);
+                            }
+                    }
+                    at16 += 5LL * Lp + 4;
+                }
+                // headers: the record of round r + 2 behind the block of round r
+                for (int r = 0; r + 2 < to.nr; r++)
+                {
+                    const uint32_t *rec = &out->trec[((size_t) out->tinfo[(size_t) g * 2 + 1] + (size_t) r) * 128 + (size_t) w * 16];
+                    const uint32_t *rec2 = rec + 2 * 128;
+                    uint32_t *hdr = reinterpret_cast<uint32_t *>(&out->tval[(size_t) (w0 + (long long) rec[1] * 2 + 10LL * rec[0])]);
+                    for (int i = 0; i < 16; i++) hdr[i] = rec2[i];
+                }
+            }
+        }
+    });
+    // what a workgroup needs when it turns to an entry of the launch grid
+    parallel_fill(out->tent, out->tgrid.size() * 256, 0u);
+    parallel_chunks((long long) out->tgrid.size(), 256, [&](long long b, long long e, int) {
+        for (long long en = b; en < e; en++)
+        {
+            const int g = out->tgrid[(size_t) en];
+            if (g < 0) continue;
+            const int nr = out->tinfo[(size_t) g * 2];
+            for (int w = 0; w < W; w++)
+            {
+                uint32_t *t = &out->tent[((size_t) en * 8 + (size_t) w) * 32];
+                const uint32_t *rec = &out->trec[(size_t) out->tinfo[(size_t) g * 2 + 1] * 128 + (size_t) w * 16];
+                const long long vo = out->tvoff[(size_t) g * W + (size_t) w];
+                t[0] = (uint32_t) nr;
+                t[1] = (uint32_t) out->tpanel[(size_t) g * W + (size_t) w];
+                t[2] = (uint32_t) (vo & 0xFFFFFFFFLL);
+                t[3] = (uint32_t) (vo >> 32);
+                for (int i = 0; i < 10; i++) t[4 + i] = rec[i];
+                if (nr > 1)
+                    for (int i = 0; i < 10; i++) t[14 + i] = rec[128 + i];
+                for (int i = 0; i < 8; i++) t[24 + i] = 0xFFFFFFFFu;
+            }
+        }
+    });
+    clk.lap("build_team2r: records, streams, entry table");
+    out->vmap.resize(p.pmap.size());
+    out->nnz = (long long) p.pmap.size();
+    parallel_chunks((long long) p.pmap.size(), 1 << 18, [&](long long b, long long e, int) {
+        for (long long nz = b; nz < e; nz++) out->vmap[(size_t) nz] = slot_of[(size_t) p.pmap[(size_t) nz]];
+    });
+    clk.lap("build_team2r: value-update map");
 }
 
 void apply_team_schedule(PanelHost *p, const TeamHost &t)

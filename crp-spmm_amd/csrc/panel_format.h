@@ -124,7 +124,7 @@ struct TeamHost
 // colpos (optional, matrices in a locality order): position of row c of A in the order the panels were built on.
 // balanced = false: the union entries of a team stay in column order (the caller orders them itself).
 void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *colidx, TeamHost *out, int T = 4, const int *colpos = nullptr,
-                 bool balanced = true);
+                 bool balanced = true, int mix_mode = -1);      // mix_mode: panels of two kinds in one team (median-column order): -1 = by rule, 0 / 1
 
 // Team schedule for the row-panel kernel itself (no LDS sharing): the entries of every panel are
 // re-ordered to the order in which its wave meets them in the team's balanced schedule, and the
@@ -224,6 +224,41 @@ struct Team2NHost
     long long nvalues = 0, rounds = 0, parts = 0, slots_filled = 0;
 };
 void build_team2n(const PanelHost &p, int nrow, const int *rowptr, const int *colidx, Team2NHost *out, const int *colpos = nullptr);
+
+// ---- team2r: the streams of the row-owner team kernel (csrc/team2r_kernel.hip) -- narrow operands, panels that are mostly holes --
+// Same teams, same ring idea as team2n, but the lane groups OWN rows: with G = 4 (n <= 32) lane group q of a wave accumulates rows q
+// and q + 4 of the wave's panel (G = 2, n <= 64: group q owns rows q, q + 2, q + 4, q + 6), and a STEP gives every row its next
+// nonzero of the round: an LDS byte offset of the B row slice inside the ring set + the value.  No row masks, no EXEC games: a row
+// that has run out of nonzeros in this round gets the value 0.0 and the offset of a slice of zeros (TEAM2R_ZERO) -- so an absent
+// (row, column) pair still is never multiplied with a B entry.  ~1.1 instructions per nonzero where the masked-row step of the
+// narrow kernels spends 57 per four panel entries = 7.7 per nonzero when an entry holds 1.84 of 8 rows (nlpkkt).
+// A round has 16 KiB of slices: S = 16 G slots of 1024 / G bytes; wave w fetches slots 2 G w .. 2 G w + 2 G - 1 with two DMA
+// instructions.  What a wave owns of a round: Lp steps (a multiple of 4, at most TEAM2R_LCAP: the scheduler closes a round before a
+// row would pass it), stored as a BLOCK of the wave's stream: [8 rows][Lp] values (doubles), [8 rows][Lp] offsets (uint16), and a
+// 64-byte HEADER = the wave's record of round r + 2 of the same team (zeros past the team's last round): the kernel issues the DMAs
+// of round r + 2 while it consumes round r, and finds what to fetch in the block that has just landed -- no load on its path.
+// Record of (round, wave), 16 words: [0] Lp; [1] first 16-byte unit of the block inside the wave's stream; [2 .. 2 + 2 G) columns of
+// the slots the wave fetches for THIS round (two-source encoding; an empty slot names a row of the team).  Records of a team:
+// trec[(tinfo[2 g + 1] + r) * 128 + w * 16]; wave w's stream starts at byte 16 * tvoff[8 g + w] of tval.
+// tent: what a (persistent) workgroup needs when it turns to the team at entry e of the launch grid, per wave, 32 words at
+// tent[(e * 8 + w) * 32]: [0] rounds (0 = no team: the run ends), [1] panel, [2], [3] tvoff (low, high), [4 .. 14) record of round 0,
+// [14 .. 24) record of round 1 (its first 10 words), [24 .. 32) the C rows of the panel's 8 rows (filled on the device from the row map).
+constexpr int TEAM2R_LCAP = 12;
+constexpr int TEAM2R_ZERO = 16384;              // LDS byte offset of the zero slice inside a ring set
+struct Team2RHost
+{
+    int G = 4;
+    int nteam = 0;
+    bool lattice = false;
+    std::vector<int>       tpanel, torder, tgrid, tinfo;
+    big_vector<uint32_t>   trec;     // 128 words per round
+    big_vector<uint32_t>   tent;     // 256 words per entry of tgrid
+    std::vector<long long> tvoff;    // 8 * nteam + 1, units of 16 bytes
+    big_vector<double>     tval;     // the streams, as 8-byte words
+    std::vector<uint32_t>  vmap;     // per CSR nonzero: its 8-byte word in tval
+    long long nwords = 0, rounds = 0, steps = 0, nnz = 0, slots_filled = 0;   // steps = sum of Lp over (round, wave)
+};
+void build_team2r(const PanelHost &p, int nrow, const int *rowptr, const int *colidx, Team2RHost *out, const int *colpos = nullptr);
 
 // Number of panel entries (before padding) a given R would need: cheap pass used
 // to pick R.  colidx may carry the two-source encoding.

@@ -208,6 +208,39 @@ def team2n_format_host(rowptr, colidx, val, G=4):
                 rounds=int(stats[0]), parts=int(stats[1]), slots_filled=int(stats[2]))
 
 
+def team2r_format_host(rowptr, colidx, val, G=4):
+    """crp_team2r_format_host -> dict(G, nteam, lattice, tpanel[nteam, 8], tinfo[nteam, 2], trec[rounds, 8, 16] (uint32), tvoff (units
+    of 16 bytes), tval (the streams as float64 words; view as uint16 for the offsets), tgrid[8, -1], vmap, rounds, steps, slots_filled, nnz)."""
+    lib = L.load()
+    rp = np.ascontiguousarray(rowptr, dtype=np.int32)
+    ci = np.ascontiguousarray(colidx, dtype=np.int32)
+    va = np.ascontiguousarray(val, dtype=np.float64)
+    nnz = int(rp[-1])
+    if ci.size == 0:
+        ci, va = np.zeros(1, np.int32), np.zeros(1)
+    nteam, lat, ng = C.c_int(), C.c_int(), C.c_int()
+    tp, ti, tg = L.c_int_p(), L.c_int_p(), L.c_int_p()
+    tr, vm, te = C.POINTER(C.c_uint)(), C.POINTER(C.c_uint)(), C.POINTER(C.c_uint)()
+    tv = C.POINTER(C.c_longlong)()
+    tval = L.c_dbl_p()
+    nrw, nwd = C.c_longlong(), C.c_longlong()
+    stats = (C.c_longlong * 4)()
+    L.check(lib.crp_team2r_format_host(rp.size - 1, rp.ctypes.data_as(L.c_int_p), ci.ctypes.data_as(L.c_int_p), va.ctypes.data_as(L.c_dbl_p),
+                                       int(G), C.byref(nteam), C.byref(lat), C.byref(tp), C.byref(ti), C.byref(tr), C.byref(nrw), C.byref(tv),
+                                       C.byref(tval), C.byref(nwd), C.byref(tg), C.byref(ng), C.byref(vm), stats, C.byref(te)), "crp_team2r_format_host")
+    nt = nteam.value
+
+    def take(ptr, cnt, dt):
+        out = np.ctypeslib.as_array(ptr, (max(cnt, 1),))[:cnt].astype(dt).copy()
+        L.c_free(C.cast(ptr, C.c_void_p))
+        return out
+    return dict(G=int(G), nteam=nt, lattice=bool(lat.value), tpanel=take(tp, 8 * nt, np.int32).reshape(nt, 8),
+                tinfo=take(ti, 2 * nt, np.int32).reshape(nt, 2), trec=take(tr, nrw.value, np.uint32).reshape(-1, 8, 16),
+                tvoff=take(tv, 8 * nt + 1, np.int64), tval=take(tval, nwd.value, np.float64),
+                tgrid=take(tg, ng.value, np.int32).reshape(8, -1), vmap=take(vm, nnz, np.uint32),
+                tent=take(te, 256 * ng.value, np.uint32).reshape(-1, 8, 32), rounds=int(stats[0]), steps=int(stats[1]), slots_filled=int(stats[2]), nnz=int(stats[3]))
+
+
 def locality_order_host(rowptr, colidx, ncol=None, nparts=8):
     """crp_locality_order_host -> (perm, info dict or None when the matrix does not qualify)."""
     lib = L.load()

@@ -965,12 +965,15 @@ def test_team2_sixteen_panel_teams_in_a_child_process(crp, orc, gpu):
     assert " passed" in r.stdout
 
 
+@pytest.mark.parametrize("variant", [6, 7])
 @pytest.mark.parametrize("n", [24, 30, 32, 34, 48, 64])
-def test_team2n_kernel(crp, orc, gpu, n):
-    """Variant 6 (csrc/team2n_kernel.hip: the team kernel for 24 <= n <= 64 columns -- B rows shared through LDS, four (n <= 32)
-    or two entries per instruction, compact values): random / banded / lattice / KKT / tiny matrices with padded leading
-    dimensions, the two-source column index, non-finite B rows next to absent pairs, value updates (host and device pointers),
-    row maps through the locality order, bit-identical repeats."""
+def test_team2n_kernel(crp, orc, gpu, n, variant):
+    """Variants 6 and 7, the team kernels for 24 <= n <= 64 columns (B rows shared through LDS).  6 = csrc/team2n_kernel.hip: four
+    (n <= 32) or two panel entries per instruction, masked rows, compact values; 7 = csrc/team2r_kernel.hip: lane groups own rows,
+    a step = every row's next nonzero, padding = 0.0 x a slice of zeros.  Random / banded / lattice / KKT / tiny matrices with
+    padded leading dimensions, the two-source column index, non-finite B rows next to absent pairs, value updates (host and device
+    pointers), row maps through the locality order, bit-identical repeats."""
+    vname = {6: b"team2n-R8", 7: b"team2r-R8"}[variant]
     import torch
     from crp_spmm_amd import gen, hip
     lib = crp.load()
@@ -984,7 +987,7 @@ def test_team2n_kernel(crp, orc, gpu, n):
         B = np.random.default_rng(n).uniform(-2, 2, size=(k, n))
         ref = orc.spmm_csr(rp, ci, va, B)
         for ldpad in (0, 2, 6):
-            got = _spmm(crp, gpu, rp, ci, va, k, B, n, ldpad=ldpad, variant=6)
+            got = _spmm(crp, gpu, rp, ci, va, k, B, n, ldpad=ldpad, variant=variant)
             assert orc.rel_fro_err(ref, got) <= FP64_TOL, (m, ldpad)
     # the variant really ran
     m, k = 500, 900
@@ -993,23 +996,23 @@ def test_team2n_kernel(crp, orc, gpu, n):
     Bf = np.random.default_rng(6).normal(size=(k, n))
     Bd = _t(Bf, gpu)
     Cd = torch.empty((m, n), dtype=torch.float64, device=gpu)
-    hip.spmm_csr(A, Bd, Cd, n=n, variant=6)
+    hip.spmm_csr(A, Bd, Cd, n=n, variant=variant)
     torch.cuda.synchronize()
-    assert lib.crp_spmm_variant_name(lib.crp_csr_dev_last_variant(A.handle)) == b"team2n-R8"
+    assert lib.crp_spmm_variant_name(lib.crp_csr_dev_last_variant(A.handle)) == vname
     # repeats are bit-identical; value updates (host pointer, then device pointer) reach the streams
     first = Cd.clone()
-    hip.spmm_csr(A, Bd, Cd, n=n, variant=6)
+    hip.spmm_csr(A, Bd, Cd, n=n, variant=variant)
     torch.cuda.synchronize()
     assert torch.equal(first, Cd)
     assert orc.rel_fro_err(orc.spmm_csr(rp, ci, va, Bf), Cd.cpu().numpy()) <= FP64_TOL
     v2 = -2.5 * va
     assert lib.crp_csr_dev_update_values(A.handle, v2.ctypes.data, None) == 0
-    hip.spmm_csr(A, Bd, Cd, n=n, variant=6)
+    hip.spmm_csr(A, Bd, Cd, n=n, variant=variant)
     torch.cuda.synchronize()
     assert orc.rel_fro_err(orc.spmm_csr(rp, ci, v2, Bf), Cd.cpu().numpy()) <= FP64_TOL
     v3 = _t(0.5 * va, gpu)
     assert lib.crp_csr_dev_update_values(A.handle, v3.data_ptr(), None) == 0
-    hip.spmm_csr(A, Bd, Cd, n=n, variant=6)
+    hip.spmm_csr(A, Bd, Cd, n=n, variant=variant)
     torch.cuda.synchronize()
     assert orc.rel_fro_err(orc.spmm_csr(rp, ci, 0.5 * va, Bf), Cd.cpu().numpy()) <= FP64_TOL
     A.free()
@@ -1020,14 +1023,14 @@ def test_team2n_kernel(crp, orc, gpu, n):
     pos[remote_rows] = np.arange(remote_rows.size)
     c2 = np.where((ci >= lo) & (ci < hi), ci - lo, ~pos[ci]).astype(np.int32)
     B = np.random.default_rng(n + 1).normal(size=(k, n))
-    got = _spmm(crp, gpu, rp, c2, va, hi - lo, B[lo:hi], n, B1=B[remote_rows], variant=6)
+    got = _spmm(crp, gpu, rp, c2, va, hi - lo, B[lo:hi], n, B1=B[remote_rows], variant=variant)
     assert orc.rel_fro_err(orc.spmm_csr(rp, ci, va, B), got) <= FP64_TOL
     # non-finite B rows: an Inf that a team-mate reads must not leak NaNs into rows without that column
     used = np.unique(ci)
     B[used[::17]] = np.inf
     B[used[5::29]] = np.nan
     ref = orc.spmm_csr(rp, ci, va, B)
-    got = _spmm(crp, gpu, rp, ci, va, k, B, n, variant=6)
+    got = _spmm(crp, gpu, rp, ci, va, k, B, n, variant=variant)
     assert np.array_equal(np.isnan(ref), np.isnan(got)) and np.array_equal(np.isinf(ref), np.isinf(got))
     fin = np.isfinite(ref)
     assert np.abs(ref[fin] - got[fin]).max() <= 1e-12 * np.abs(ref[fin]).max()
@@ -1035,5 +1038,5 @@ def test_team2n_kernel(crp, orc, gpu, n):
     rp, ci, va = gen.fem3d(12)
     m = len(rp) - 1
     B = np.random.default_rng(n + 2).normal(size=(m, n))
-    got = _spmm(crp, gpu, rp, ci, va, m, B, n, variant=6)
+    got = _spmm(crp, gpu, rp, ci, va, m, B, n, variant=variant)
     assert orc.rel_fro_err(orc.spmm_csr(rp, ci, va, B), got) <= FP64_TOL

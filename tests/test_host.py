@@ -829,3 +829,100 @@ def test_team2n_streams_replay(crp, orc, G):
         if name == "lattice":
             # the point of the format: a B row is fetched once per team, not once per panel entry
             assert t["slots_filled"] < 0.6 * t["parts"], (t["slots_filled"], t["parts"])
+
+
+def _replay_team2r(t, m, B, va):
+    """What csrc/team2r_kernel.hip does with the streams of crp_team2r_format_host, in numpy (B1-less)."""
+    G = t["G"]
+    S, slotb, perw = 16 * G, 1024 // G, 2 * G
+    out = np.zeros((m, B.shape[1]))
+    done = np.zeros(m, dtype=np.int64)
+    assert np.array_equal(t["tval"][t["vmap"]], va)
+    u16 = t["tval"].view(np.uint16)
+    u32 = t["tval"].view(np.uint32)
+    seen_teams = []
+    for en, g in enumerate(t["tgrid"].ravel()):
+        ent = t["tent"][en]
+        if g < 0:
+            assert not ent[:, 0].any()                                    # rounds = 0: the run of this XCD ends here
+            continue
+        seen_teams.append(int(g))
+        nr, r0 = (int(x) for x in t["tinfo"][g])
+        assert nr >= 1
+        for w in range(8):                                                # the entry table: what a workgroup reads when it turns to this team
+            assert int(ent[w, 0]) == nr and int(np.int32(ent[w, 1])) == int(t["tpanel"][g, w])
+            assert int(ent[w, 2]) + (int(ent[w, 3]) << 32) == int(t["tvoff"][8 * g + w])
+            assert np.array_equal(ent[w, 4:14], t["trec"][r0, w, :10])
+            if nr > 1:
+                assert np.array_equal(ent[w, 14:24], t["trec"][r0 + 1, w, :10])
+        acc = np.zeros((8, 8, B.shape[1]))
+        for r in range(nr):
+            recs = t["trec"][r0 + r]
+            cols = np.array([[int(np.int32(recs[w, 2 + j])) for j in range(perw)] for w in range(8)]).ravel()   # slot w * perw + j
+            assert np.all(cols >= 0) and np.all(cols < B.shape[0])
+            for w in range(8):
+                Lp, at16 = int(recs[w, 0]), int(recs[w, 1])
+                assert Lp % 4 == 0 and Lp <= 12
+                w0 = 2 * (int(t["tvoff"][8 * g + w]) + at16)              # first 8-byte word of the block
+                assert w0 + 10 * Lp + 8 <= 2 * int(t["tvoff"][8 * g + w + 1])
+                vals = t["tval"][w0:w0 + 8 * Lp].reshape(8, Lp)
+                offs = u16[4 * (w0 + 8 * Lp):4 * (w0 + 8 * Lp) + 8 * Lp].reshape(8, Lp)
+                hdr = u32[2 * (w0 + 10 * Lp):2 * (w0 + 10 * Lp) + 16]
+                if r + 2 < nr:
+                    assert np.array_equal(hdr, t["trec"][r0 + r + 2, w])  # the record of round r + 2 rides behind the block of round r
+                else:
+                    assert not hdr.any()
+                for rr in range(8):
+                    for st in range(Lp):
+                        o = int(offs[rr, st])
+                        if o == 16384:
+                            assert vals[rr, st] == 0.0                    # padding: the slice of zeros, never a B row
+                            continue
+                        assert o % slotb == 0 and o // slotb < S
+                        acc[w, rr] += vals[rr, st] * B[cols[o // slotb]]
+        for w in range(8):
+            p = int(t["tpanel"][g, w])
+            if p < 0:
+                assert not acc[w].any()
+                continue
+            for rr in range(8):
+                row = p * 8 + rr
+                if row < m:
+                    out[row] = acc[w, rr]
+                    done[row] += 1
+                else:
+                    assert not acc[w, rr].any()
+    assert sorted(seen_teams) == list(range(t["nteam"]))
+    assert np.all(done == 1)
+    return out
+
+
+@pytest.mark.parametrize("G", [4, 2])
+def test_team2r_streams_replay(crp, orc, G):
+    """The streams of the row-owner team kernel (variant 7), replayed in numpy: every row is produced once and equals the oracle's
+    product; padding steps carry the value 0.0 and the offset of the slice of zeros."""
+    from crp_spmm_amd import gen, hip
+    rng = np.random.default_rng(4)
+    cases = []
+    offs = tuple(range(1, 15)) + tuple(range(304, 310)) + tuple(range(3040, 3046))
+    cases.append(("lattice",) + gen.banded_fem(9120, offsets=offs, seed=3))
+    nx, ny, nz = 300, 5, 3
+    cases.append(("clustered",) + gen.banded_fem(nx * ny * nz, offsets=(1, 2, 3, nx, nx + 1, nx * ny, nx * ny + 1), seed=3))
+    cases.append(("random",) + gen.random_csr(611, 611, 14, seed=5, empty_every=9))
+    cases.append(("kkt",) + gen.kkt3d(16))
+    cases.append(("random40",) + gen.random_csr(777, 1234, 40, seed=3))
+    cases.append(("dense64",) + gen.random_csr(64, 40, 36, seed=7))         # rows that pass 16 nonzeros on a round's slots: rounds close early
+    cases.append(("tiny",) + gen.random_csr(13, 40, 5, seed=1))
+    rp, ci, va = gen.random_csr(200, 64, 6, seed=8)
+    ci2 = ci.copy()
+    ci2[1::7] = ci2[0::7][:ci2[1::7].size]
+    cases.append(("dups", rp, ci2, va))
+    for name, rp, ci, va in cases:
+        m = len(rp) - 1
+        k = int(ci.max()) + 1 if ci.size else 1
+        t = hip.team2r_format_host(rp, ci, va, G=G)
+        assert np.array_equal(np.sort(t["tpanel"][t["tpanel"] >= 0]), np.arange((m + 7) // 8)), name
+        B = rng.uniform(-1, 1, size=(k, 3))
+        got = _replay_team2r(t, m, B, va)
+        ref = orc.spmm_csr(rp, ci, va, B)
+        assert orc.rel_fro_err(ref, got) <= 1e-13, name
