@@ -3,13 +3,13 @@
 
 On a pm x pn grid (reference mapping: src/para2d_spmm.h:37) a GPU multiplies the rows of ONE of pm contiguous row blocks by n / pn
 columns; the B rows its columns name outside its own block arrive by the per-exec exchange (src/rowpara_spmm.c:275-309).  Both
-parts can be measured on one GPU: the local product -- the MIDDLE row block (halos on both sides) as a matrix of its own, all
+parts can be measured on one GPU: the local product -- one row block as a matrix of its own, all
 columns addressable, n / pn columns wide, through the device-level C ABI the engine calls -- and the exchange volume (distinct
 columns outside the block x n / pn x 8 bytes, what rp_spmm_init's plan would request: src/rowpara_spmm.c:70-118).  Printed per grid:
 T_local, the halo bytes, and the speed-up bounds T(1 GPU) / T_local (exchange fully hidden behind the interior rows' product,
 which the engine overlaps) and T(1 GPU) / (T_local + halo bytes / link rate) (exchange not hidden at all; --link-gbs, default
 the 153 GB/s of one xGMI link: a block's halo comes from its two neighbours over two links, so this is the pessimistic end).
-Row blocks are equal row counts (the planner balances nnz: the same thing on these uniform stand-ins).
+Row blocks are the planner's nnz-balanced contiguous blocks; per grid the block with the largest halo is measured.
 
 usage: grid_proxy.py [--matrix kkt240] [--n 256] [--gpus 8] [--steps 10] [--out FILE.jsonl]
 """
@@ -50,8 +50,20 @@ def main():
     grids = [(1, 1)] + grids
     lines = []
     for pm, pn in grids:
-        blk = pm // 2
-        r0, r1 = (m * blk) // pm, (m * (blk + 1)) // pm
+        # nnz-balanced contiguous row blocks, as csr_mat_row_partition makes them (src/spmat_part.c:12-36); per grid the block
+        # with the LARGEST halo is measured (the exec time of a grid is its slowest rank's)
+        cuts = [int(np.searchsorted(rp, nnz * b // pm)) for b in range(pm + 1)]
+        cuts[0], cuts[-1] = 0, m
+        best = None
+        for b in range(pm):
+            c0, c1 = cuts[b], cuts[b + 1]
+            fl = np.zeros(k, dtype=np.bool_)
+            fl[ci[int(rp[c0]):int(rp[c1])]] = True
+            h = int(fl.sum()) - (int(fl[c0:c1].sum()) if m == k else 0)
+            if best is None or h > best[0]:
+                best = (h, b)
+        blk = best[1]
+        r0, r1 = cuts[blk], cuts[blk + 1]
         e0, e1 = int(rp[r0]), int(rp[r1])
         rpl = (rp[r0:r1 + 1] - rp[r0]).astype(np.int32)
         cil, val = ci[e0:e1], va[e0:e1]
@@ -99,7 +111,7 @@ def main():
             lib.crp_event_destroy(x)
             lib.crp_event_destroy(y)
         rv = int(lib.crp_csr_dev_last_variant(A.handle))
-        line = {"grid": "%d x %d" % (pm, pn), "block_rows": ml, "block_nnz": e1 - e0, "n_local": nl, "kernel_variant": lib.crp_spmm_variant_name(rv).decode(),
+        line = {"grid": "%d x %d" % (pm, pn), "block": blk, "block_rows": ml, "block_nnz": e1 - e0, "n_local": nl, "kernel_variant": lib.crp_spmm_variant_name(rv).decode(),
                 "T_local_ms": float(np.mean(per)), "ms_min": float(np.min(per)), "ms_max": float(np.max(per)), "halo_rows": halo,
                 "halo_MB": halo * nl * 8 / 1e6, "exchange_ms_one_link": halo * nl * 8 / (a.link_gbs * 1e9) * 1e3, "first_product_s": first, "check_rel_err": err}
         lines.append(line)
