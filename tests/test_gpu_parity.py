@@ -392,6 +392,36 @@ def test_row_subset_matrices(crp, orc, gpu):
                 assert (got[parts[1]] == -3.0).all()
             lib.crp_csr_dev_destroy(C.byref(h))
         assert orc.rel_fro_err(C_ref, Cd.cpu().numpy()) <= FP64_TOL, variant
+    # the narrow team kernels (variants 6, 7: 24 .. 64 columns); variant 7 keeps the C rows of its panels in a table that must
+    # follow a row map set AFTER the first product
+    n2 = 48
+    B2 = orc.fill_B(0, k, 0, n2)
+    C2_ref = orc.spmm_csr(rp, ci, va, B2)
+    B2d = _t(B2, gpu)
+    rows = parts[0]
+    cnt = (rp[rows + 1] - rp[rows]).astype(np.int64)
+    sub_rp = np.zeros(rows.size + 1, dtype=np.int32)
+    sub_rp[1:] = np.cumsum(cnt)
+    idx = np.concatenate([np.arange(rp[r], rp[r + 1]) for r in rows])
+    sub_ci, sub_va = np.ascontiguousarray(ci[idx]), np.ascontiguousarray(va[idx])
+    for variant in (6, 7):
+        h = C.c_void_p()
+        assert lib.crp_csr_dev_create(rows.size, k, sub_rp.ctypes.data_as(_IP), sub_ci.ctypes.data_as(_IP), sub_va.ctypes.data_as(_DP), C.byref(h)) == 0
+        Cd = torch.full((m, n2), -3.0, dtype=torch.float64, device=gpu)
+        assert lib.crp_spmm_csr_f64(h, 0, n2, B2d.data_ptr(), n2, None, 0, Cd.data_ptr(), n2, variant, None) == 0      # no map: rows 0 .. rows.size - 1
+        torch.cuda.synchronize()
+        got = Cd.cpu().numpy()
+        assert orc.rel_fro_err(C2_ref[rows], got[:rows.size]) <= FP64_TOL, variant
+        assert (got[rows.size:] == -3.0).all()
+        assert lib.crp_csr_dev_last_variant(h) == variant
+        Cd.fill_(-3.0)
+        assert lib.crp_csr_dev_set_rowmap(h, rows.ctypes.data_as(_IP), m) == 0
+        assert lib.crp_spmm_csr_f64(h, 0, n2, B2d.data_ptr(), n2, None, 0, Cd.data_ptr(), n2, variant, None) == 0
+        torch.cuda.synchronize()
+        got = Cd.cpu().numpy()
+        assert orc.rel_fro_err(C2_ref[rows], got[rows]) <= FP64_TOL, variant
+        assert (got[parts[1]] == -3.0).all()
+        lib.crp_csr_dev_destroy(C.byref(h))
 
 
 def test_crpspmm_engine_single_rank(crp, orc, gpu):
