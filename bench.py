@@ -144,7 +144,7 @@ def kkt240_cached():
 
 def cpu_baseline(rp, ci, va, k, n, budget_s=20.0):
     """The reference's CPU path on this box's host cores: mkl_sparse_d_create_csr + mkl_sparse_d_mm +
-    mkl_sparse_destroy PER CALL, as /root/reference/src/rowpara_spmm.c:398-408 does (kind "mkl"; run in a fresh
+    mkl_sparse_destroy PER CALL, as /root/reference/src/rowpara_spmm.c:398-408 does (kind "reference", engine "mkl"; run in a fresh
     process with MKL_THREADING_LAYER=GNU and all cores, oracle/mkl_baseline.py).  When libmkl_rt does not load:
     the oracle's OpenMP restatement (kind "port")."""
     cores = os.cpu_count() or 1

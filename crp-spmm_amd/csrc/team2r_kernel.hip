@@ -112,8 +112,9 @@ __global__ __launch_bounds__(512, 4) void spmm_team2r_kernel(const int ngrid, co
     const int e_end = (int) ((blockIdx.x & 7) + 1) * cpx;
     const int q = lane / LPG, l = lane % LPG, l16 = lane & 15;
     const int lo = (2 * l + 1 < n) ? l * 16 : 0;                           // lanes past n fetch the row's first bytes: valid, never stored
-    // LDS byte addresses (the kernel's dynamic LDS starts at 0: there is no static LDS in this kernel)
-    const uint32_t blk0 = (uint32_t) (T2R_NSET * T2R_SETB + wave * T2R_WBLK);
+    // LDS byte addresses for the asm reads: the dynamic LDS's own offset (0 while this kernel has no static LDS) + ...
+    const uint32_t lds0 = (uint32_t) (uintptr_t) T2R_LPTR(lds);
+    const uint32_t blk0 = (uint32_t) (T2R_NSET * T2R_SETB + wave * T2R_WBLK);            // relative to lds (DMA destinations), + lds0 for reads
     // the slices of zeros (one per ring set: offsets are relative to the set; 512 bytes: a slice of the G = 2 instance)
     if (threadIdx.x < T2R_NSET * 32)
         *reinterpret_cast<d2 *>(lds + (threadIdx.x >> 5) * T2R_SETB + TEAM2R_ZERO + (threadIdx.x & 31) * 16) = d2{0.0, 0.0};
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(512, 4) void spmm_team2r_kernel(const int ngrid, co
         if (lane < Lp + 4) __builtin_amdgcn_global_load_lds(T2R_GPTR(bsrc + 64 * Lp + lane * 16), T2R_LPTR(bdst + T2R_VALB), 16, 0, 0);
     };
     auto header = [&](const int set, const int Lp) {                        // the record behind the block in ring set `set`
-        const uint32_t ad = blk0 + (uint32_t) (set * T2R_BLKB + T2R_VALB + 16 * Lp);
+        const uint32_t ad = lds0 + blk0 + (uint32_t) (set * T2R_BLKB + T2R_VALB + 16 * Lp);
         u4 h0, h1;
         u2 h2;
         asm volatile("ds_read_b128 %[h0], %[ad]\n\tds_read_b128 %[h1], %[ad] offset:16\n\tds_read_b64 %[h2], %[ad] offset:32\n\ts_waitcnt lgkmcnt(0)"
@@ -284,8 +285,8 @@ __global__ __launch_bounds__(512, 4) void spmm_team2r_kernel(const int ngrid, co
         }
         T2R_CLK(c4);
         const int Lp = f0 & 0xFF;
-        const uint32_t rs = (uint32_t) (sc * T2R_SETB + l * 16);
-        const uint32_t vs = blk0 + (uint32_t) (sc * T2R_BLKB);
+        const uint32_t rs = lds0 + (uint32_t) (sc * T2R_SETB + l * 16);
+        const uint32_t vs = lds0 + blk0 + (uint32_t) (sc * T2R_BLKB);
         const uint32_t os = vs + T2R_VALB;
         if (Lp > 0)
         {

@@ -10,7 +10,8 @@ What /root/reference/src/rowpara_spmm.c:398-408 does for every multiply, through
 
 all three inside the timed region, per call, as the reference has them.  Must run in a fresh process with
 MKL_THREADING_LAYER=GNU (the default Intel layer mixed with libgomp returns garbage); bench.py starts it
-that way.  Prints one JSON line: {"value": GFLOP/s, "unit", "kind": "mkl", "sample": ...}.
+that way.  Prints one JSON line: {"value": GFLOP/s, "unit", "kind": "reference", "engine": "mkl", "sample": ...} -- "reference":
+the reference's own arithmetic (its three MKL calls per multiply), not this repository's restatement ("port").
 
 usage: mkl_baseline.py <npz with rp, ci, va, k, n> <seconds>
 """
@@ -79,7 +80,7 @@ def main():
         if time.time() - t0 > budget or reps >= 200:
             break
     dt = (time.time() - t0) / reps
-    print(json.dumps({"value": 2.0 * ci.size * n / dt / 1e9, "unit": "GFLOP/s", "kind": "mkl",
+    print(json.dumps({"value": 2.0 * ci.size * n / dt / 1e9, "unit": "GFLOP/s", "kind": "reference", "engine": "mkl",
                       "sample": "full workload (%d rows, %d nnz, n=%d), %d calls of mkl_sparse_d_create_csr + mkl_sparse_d_mm + "
                                 "mkl_sparse_destroy (src/rowpara_spmm.c:398-408), %.4f s each, MKL_THREADING_LAYER=%s, %s threads"
                                 % (m, ci.size, n, reps, dt, os.environ.get("MKL_THREADING_LAYER", "?"),
