@@ -222,12 +222,26 @@ __global__ __launch_bounds__(512, 4) void spmm_team2r_kernel(const int ngrid, co
     // rounds issued and not yet consumed, oldest first: steps | last round of its team << 8, entry
     int f0 = 0, f1 = 0, f2 = 0, g0 = 0, g1 = 0, g2 = 0, ahead = 0;
     int si = 0, sc = 0;                                                     // ring set of the next round to issue / to consume
+#ifdef T2R_DBG
+    long long th = 0, tfe = 0;
+#endif
     auto issue_next = [&]() {
         T2RRec R;
+#ifdef T2R_DBG
+        const long long q0 = clock64();
+#endif
         if (ir == 0) R = tm.r0;
         else if (ir == 1) R = tm.r1;
         else R = header(sc, f0 & 0xFF);                                     // rounds ir - 2 (being consumed now) and ir - 1 are the ones in flight
+#ifdef T2R_DBG
+        const long long q1 = clock64();
+#endif
         fetch(R, si, cvb);
+#ifdef T2R_DBG
+        const long long q2 = clock64();
+        th += q1 - q0;
+        tfe += q2 - q1;
+#endif
         const int desc = (int) R.w[0] | ((ir == cnr - 1) ? 256 : 0);
         // (selects, not branches: the optimiser turns a three-way branch into an indexed array on the stack)
         f0 = ahead == 0 ? desc : f0; g0 = ahead == 0 ? ie : g0;
@@ -333,6 +347,7 @@ __global__ __launch_bounds__(512, 4) void spmm_team2r_kernel(const int ngrid, co
     {
         atomicAdd(dbg + 0, (unsigned long long) tw); atomicAdd(dbg + 1, (unsigned long long) tb); atomicAdd(dbg + 2, (unsigned long long) ti);
         atomicAdd(dbg + 3, (unsigned long long) tf); atomicAdd(dbg + 4, (unsigned long long) tc); atomicAdd(dbg + 5, (unsigned long long) nrd);
+        atomicAdd(dbg + 6, (unsigned long long) th); atomicAdd(dbg + 7, (unsigned long long) tfe);
     }
 #endif
 }
@@ -398,8 +413,8 @@ hipError_t spmm_rm_f64_team2r(const Team2NArgs &t, const SpmmArgs &a, hipStream_
         (void) hipMemcpy(h, dbg_buf, 64, hipMemcpyDeviceToHost);
         (void) hipMemset(dbg_buf, 0, 64);
         if (h[5] > 0)
-            fprintf(stderr, "[t2r dbg] wave-rounds %llu: per round  wait %.0f  barrier %.0f  issue %.0f  flush %.0f  consume %.0f (s_memtime ticks)\n", h[5],
-                    (double) h[0] / h[5], (double) h[1] / h[5], (double) h[2] / h[5], (double) h[3] / h[5], (double) h[4] / h[5]);
+            fprintf(stderr, "[t2r dbg] wave-rounds %llu: per round  wait %.0f  barrier %.0f  issue %.0f (record %.0f, four DMAs %.0f)  flush %.0f  consume %.0f (s_memtime ticks)\n", h[5],
+                    (double) h[0] / h[5], (double) h[1] / h[5], (double) h[2] / h[5], (double) h[6] / h[5], (double) h[7] / h[5], (double) h[3] / h[5], (double) h[4] / h[5]);
     }
     dbg = dbg_buf;
 #endif
