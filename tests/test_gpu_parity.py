@@ -533,6 +533,11 @@ def test_team2_kernel_vs_oracle(crp, orc, gpu, monkeypatch, n, values):
     B = np.random.default_rng(n + 1).uniform(-2, 2, size=(mm, n))
     got = _spmm(crp, gpu, rp, ci, va, mm, B, n, variant=5)
     assert orc.rel_fro_err(orc.spmm_csr(rp, ci, va, B), got) <= FP64_TOL, ("lattice", n)
+    if n > 256:
+        # more than one column tile: the option that puts a team's tiles on consecutive workgroups (a 1-D launch grid)
+        monkeypatch.setenv("CRPSPMM_T2_TILEMAJOR", "0")
+        got = _spmm(crp, gpu, rp, ci, va, mm, B, n, variant=5)
+        assert orc.rel_fro_err(orc.spmm_csr(rp, ci, va, B), got) <= FP64_TOL, ("lattice, tiles interleaved", n)
 
 
 @pytest.mark.parametrize("values", ["compact", "full"])
