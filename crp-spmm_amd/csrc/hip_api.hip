@@ -482,7 +482,7 @@ static bool team2r_auto(const crp_csr_dev *A)
 {
     const char *e = getenv("CRPSPMM_TEAM2R");
     if (e != NULL) return atoi(e) != 0;
-    return A->team2r_pays;          // never set: the kernel does not beat the row-panel kernels at nlpkkt240 size (team2r_kernel.hip)
+    return A->team2r_pays;          // panels that are mostly holes (set at create)
 }
 
 // variant 0 below the team2 threshold: the narrow team kernel (CRPSPMM_TEAM2N=0 keeps the row-panel kernels)
@@ -773,7 +773,14 @@ int crp_csr_dev_create(int nrow, int ncol, const int *rowptr, const int *colidx,
         // 0.73 / 1.34 / 1.95 through CSR and 1.00 / 1.10 / 1.45 on R = 4; the shell stand-in 0.106 / 0.129 against 0.135 / 0.144
         // on R = 4.  Erdos-Renyi (e8 = nnz) stays with CSR.
         if ((double) e8 <= 0.6 * (double) nnz) A->auto_variant = 3;
-        if ((double) nnz < 0.35 * 8.0 * (double) e8) A->team2_min_n = TEAM2_MIN_N_SPARSE;
+        if ((double) nnz < 0.35 * 8.0 * (double) e8)
+        {
+            A->team2_min_n = TEAM2_MIN_N_SPARSE;
+            // ... and at 24 .. 64 columns such panels go to the row-owner team kernel (variant 7, csrc/team2r_kernel.hip): nlpkkt
+            // stand-in 0.500 / 1.017 ms at n = 32 / 64 against 0.586 / 1.110 of the narrow and row-panel kernels, at nlpkkt240 size
+            // 7.83 / 17.3 against 8.92 / 18.2 (pwtk stand-in, fill 0.61: 0.075 against 0.062 -- stays).  CRPSPMM_TEAM2R=0|1 forces.
+            A->team2r_pays = true;
+        }
     }
     // The LDS-sharing team kernel fetches a B row once per team of 64 rows: it pays when those rows name far fewer
     // distinct columns than they have nonzeros (pwtk stand-in 0.10, shell 0.09, kkt 0.27, fem3d 0.13 of the nonzeros;
@@ -1095,6 +1102,7 @@ int crp_csr_dev_resolved_variant(crp_csr_dev_p A, int n)
     int v = A->auto_variant;
     if (v >= 2 && n < 24) v = 1;
     if (A->team2_pays && n >= A->team2_min_n && (n % 2 == 0)) v = 5;
+    else if (A->team2_pays && team2r_auto(A) && n >= 24 && n <= 64 && (n % 2 == 0) && A->nnz > 0 && A->nrow >= 8) v = 7;
     return v;
 }
 int crp_csr_dev_last_variant(crp_csr_dev_p A) { return A ? A->last_variant : -1; }

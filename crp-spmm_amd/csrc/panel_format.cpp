@@ -2080,9 +2080,11 @@ void build_team2r(const PanelHost &p, int nrow, const int *rowptr, const int *co
     PhaseClock clk;
     released_async<TeamHost> th_owner;
     TeamHost &th = *th_owner;
-    // teams of ONE kind of panel (no primal + dual mixes: team2's rule for KKT systems): a wave's steps are its panel's, and the
-    // waves of a team meet at every round's barrier (nlpkkt stand-in: useful / issued row slots 0.32 mixed, 0.53 unmixed)
-    build_teams(p, nrow, rowptr, colidx, &th, T, colpos, false, 0);
+    // (teams as team2 builds them, KKT systems' primal + dual mixes included: the B rows both kinds share are fetched once --
+    //  teams of one kind of panel give the waves of a round more equal steps (useful / issued row slots 0.53 against 0.32) and are
+    //  slower all the same: nlpkkt stand-in n = 32 0.533 against 0.500 ms, at nlpkkt240 size 8.96 against 7.83, where the kernel is
+    //  bound by what it fetches from beyond L2)
+    build_teams(p, nrow, rowptr, colidx, &th, T, colpos, false);
     clk.lap("build_team2r: build_teams total");
     const int nteam = th.nteam;
     out->nteam = nteam;
@@ -2105,7 +2107,7 @@ void build_team2r(const PanelHost &p, int nrow, const int *rowptr, const int *co
         if (th.clustered && c >= 0 && ps / 8 < (long long) th.plocal.size()) return (ps % 8) * 16 + th.plocal[(size_t) (ps / 8)];
         return ps % Skey;
     };
-    const bool deal = getenv("CRPSPMM_T2R_DEAL") == NULL || atoi(getenv("CRPSPMM_T2R_DEAL")) != 0;
+    const bool deal = getenv("CRPSPMM_T2R_DEAL") != NULL && atoi(getenv("CRPSPMM_T2R_DEAL")) != 0;
     struct ItemR { unsigned char slot; int src; };                            // a panel entry of a wave placed on a slot of the round
     struct TeamOutR
     {
@@ -2130,10 +2132,11 @@ void build_team2r(const PanelHost &p, int nrow, const int *rowptr, const int *co
                 if (used) nodes.push_back(q);
             }
             std::stable_sort(nodes.begin(), nodes.end(), [&](int x, int y) { return key(x) < key(y); });
-            // ... dealt out to the rounds like cards: round r takes the entries r, r + R, r + 2 R, ... of that order, so that every
-            // round is a uniform sample of the team's columns and every wave (and every row) finds about 1 / R of its nonzeros in
-            // it -- a wave waits at the round's barrier for the wave with the most steps (nlpkkt stand-in: mean / max steps of a
-            // round's waves 0.59 -> see DESIGN.md; consecutive runs instead: CRPSPMM_T2R_DEAL=0)
+            // CRPSPMM_T2R_DEAL=1: ... dealt out to the rounds like cards (round r takes the entries r, r + R, r + 2 R, ... of that
+            // order), so that every round is a uniform sample of the team's columns and every wave finds about 1 / R of its nonzeros
+            // in it -- a wave waits at the round's barrier for the wave with the most steps.  Mean / max steps of a round's waves
+            // 0.59 -> 0.86, and slower (nlpkkt stand-in n = 32 0.576 against 0.500 ms, nlpkkt240 size 8.15 against 7.83): consecutive
+            // columns in a round are consecutive B rows in time for every team of the XCD.  Off.
             if (deal && nodes.size() > (size_t) S)
             {
                 const size_t nn0 = nodes.size(), R = (nn0 + (size_t) S - 1) / (size_t) S;

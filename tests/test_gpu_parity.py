@@ -1069,6 +1069,24 @@ def test_team2n_kernel(crp, orc, gpu, n, variant):
     assert np.array_equal(np.isnan(ref), np.isnan(got)) and np.array_equal(np.isinf(ref), np.isinf(got))
     fin = np.isfinite(ref)
     assert np.abs(ref[fin] - got[fin]).max() <= 1e-12 * np.abs(ref[fin]).max()
+    if variant == 7:
+        # what variant 0 takes for panels that are mostly holes (a KKT system: 1.9 of 8 rows per panel entry) at these widths
+        rp, ci, va = gen.kkt3d(14)
+        m = len(rp) - 1
+        A = hip.CsrDev(m, m, rp, ci, va)
+        assert lib.crp_csr_dev_resolved_variant(A.handle, n) == 7
+        Bk = np.random.default_rng(n + 3).normal(size=(m, n))
+        Cd = torch.empty((m, n), dtype=torch.float64, device=gpu)
+        hip.spmm_csr(A, _t(Bk, gpu), Cd, n=n, variant=0)
+        torch.cuda.synchronize()
+        assert lib.crp_spmm_variant_name(lib.crp_csr_dev_last_variant(A.handle)) == vname
+        assert orc.rel_fro_err(orc.spmm_csr(rp, ci, va, Bk), Cd.cpu().numpy()) <= FP64_TOL
+        A.free()
+        # ... and not for filled panels
+        rp, ci, va = gen.banded_fem(6000, offsets=(1, 2, 3, 4, 5, 6, 40, 41, 42), seed=3)
+        A = hip.CsrDev(6000, 6000, rp, ci, va)
+        assert lib.crp_csr_dev_resolved_variant(A.handle, n) != 7
+        A.free()
     # a square matrix that the locality order re-orders (row map of the formats), and a caller row map on top
     rp, ci, va = gen.fem3d(12)
     m = len(rp) - 1
