@@ -1,4 +1,5 @@
-// team2r_kernel.hip -- row-owner team SpMM for narrow operands (24 <= n <= 64 columns, fp64) on gfx950.  Variant 7, explicit only.
+// team2r_kernel.hip -- row-owner team SpMM for narrow operands (24 <= n <= 64 columns, fp64) on gfx950.  Variant 7: what variant 0
+// takes at these widths for panels that are mostly holes (KKT systems).
 //
 // Same product as every kernel of this library (what mkl_sparse_d_mm computes at /root/reference/src/rowpara_spmm.c:388-408
 // with alpha = 1, beta = 0).  Narrow operands are what the planner's 1 x P grids hand every GPU (n / P columns, all rows) -- and
@@ -19,14 +20,14 @@
 // Format: panel_format.h, Team2RHost.  One barrier per round = per 16 G union entries; two rounds in flight; persistent
 // workgroups with one pipeline across their teams (below).
 //
-// MEASURED (round 3, same box as the default): nlpkkt stand-in kkt3d(96) n = 32 / 64: 0.537 / 1.048 ms against 0.574 / 1.125 of
-// the row-panel kernels (-7 %); at nlpkkt240 size 8.96 / 19.7 ms against 8.92 / 18.2: no gain; pwtk stand-in 0.075 against
-// 0.062.  A round takes ~3000 cycles of which (s_memtime stamps, -DT2R_DBG) ~1400 are the issue of the next round's four DMAs per
-// wave, ~900 the FMAs with their two dependent LDS reads per four steps, ~400 the barrier: latency-bound at four waves per SIMD,
-// not by the requests it saves.  Tried without effect: records by scalar loads -> riding in the blocks (the first version spent
-// 2100 + 2300 cycles per round on two scalar-cache misses; gone, time unchanged at this occupancy), rounds dealt like cards so
-// that all waves of a round have equal steps (mean / max 0.59 -> 0.86), half of the waves issuing after their FMAs, one team per
-// workgroup instead of persistent ones.  Kept as variant 7 (parity-tested), not taken by variant 0; CRPSPMM_TEAM2R=1 lets it.
+// MEASURED (round 3, same box as the kernels it replaces): nlpkkt stand-in kkt3d(96) n = 32 / 64: 0.500 / 1.017 ms against 0.586 /
+// 1.110 of the narrow and row-panel kernels; at nlpkkt240 size 8.00 / 16.95 against 8.85 / 18.2; pwtk stand-in (filled panels) 0.075
+// against 0.062: not taken there.  The teams are team2's (primal and dual panels of a KKT system together: with teams of one kind
+// the B rows both kinds share come from beyond L2 twice and the gain is gone at nlpkkt240 size), the union entries of a team go
+// to its rounds in natural order (dealt like cards they balance the waves of a round and cost 15 %).  A round takes ~3000 cycles of
+// which (s_memtime stamps, -DT2R_DBG) ~1400 are the issue of the next round's four DMAs per wave, ~900 the FMAs with their two
+// dependent LDS reads per four steps, ~400 the barrier: latency-bound at four waves per SIMD.  The first version read a record per
+// round through the scalar cache (2100 + 2300 of 5800 cycles per round were those misses): records now ride in the blocks.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>

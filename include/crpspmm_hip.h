@@ -120,7 +120,8 @@ int crp_csr_dev_reordered(crp_csr_dev_p A);
  * below 24 columns.  Operands that are not aligned like that fall back (5 -> 3 -> 1): what a product actually launched is
  * crp_csr_dev_last_variant().  Variant 6 (team2n-R8: the team kernel for 24 <= n <= 64, csrc/team2n_kernel.hip) is never
  * chosen by auto unless CRPSPMM_TEAM2N=1: measured slower than the row-panel kernels at every width it covers;
- * nor is variant 7 (team2r-R8: lane groups own rows, csrc/team2r_kernel.hip; CRPSPMM_TEAM2R=1): no gain at nlpkkt240 size. */
+ * variant 7 (team2r-R8: lane groups own rows, csrc/team2r_kernel.hip) replaces the create-time choice at 24 <= n <= 64 when fewer
+ * than 35 % of the (row, entry) pairs of the R = 8 panels exist and 64 consecutive rows share columns (CRPSPMM_TEAM2R=0|1 forces). */
 int crp_csr_dev_resolved_variant(crp_csr_dev_p A, int n);
 /* the variant the last crp_spmm_csr_f64 / _f32 on this matrix launched (after every fallback), or 0 before the first */
 int crp_csr_dev_last_variant(crp_csr_dev_p A);
