@@ -385,7 +385,9 @@ bool spmm_team2r_applicable(const Team2NArgs &t, const SpmmArgs &a)
 hipError_t spmm_rm_f64_team2r(const Team2NArgs &t, const SpmmArgs &a, hipStream_t s)
 {
     const bool has_b1 = a.B1 != nullptr;
-    // persistent workgroups: two per CU (the LDS of one is 73.5 KiB), eight XCD runs; never more workgroups than teams of a run
+    // persistent workgroups: two fit a CU (the LDS of one is 73.5 KiB); four times as many are launched, so that the hardware's
+    // dispatcher evens out what round-robin chains of teams leave uneven (nlpkkt stand-in n = 32 / 64: 0.490 / 0.986 ms against
+    // 0.510 / 0.998 with exactly the resident number); eight XCD runs; never more workgroups than teams of a run
     static int ncu = 0;
     if (ncu == 0)
     {
@@ -395,7 +397,7 @@ hipError_t spmm_rm_f64_team2r(const Team2NArgs &t, const SpmmArgs &a, hipStream_
         ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
     const int wgs_env = getenv("CRPSPMM_T2R_WGS") ? atoi(getenv("CRPSPMM_T2R_WGS")) : 0;
-    const int per_xcd = std::max(1, std::min(t.ngrid / 8, (wgs_env > 0 ? wgs_env : 2 * ncu) / 8));
+    const int per_xcd = std::max(1, std::min(t.ngrid / 8, (wgs_env > 0 ? wgs_env : 8 * ncu) / 8));
     dim3 grid(per_xcd * 8);
     unsigned long long *dbg = nullptr;
     const int stagger = getenv("CRPSPMM_T2R_STAGGER") ? atoi(getenv("CRPSPMM_T2R_STAGGER")) : 1;
