@@ -78,6 +78,7 @@ struct Team2NDev              // panel_format.h, Team2NHost: the narrow-operand 
 {
     bool built = false;
     int G = 4, nteam = 0, ngrid = 0;
+    int rowdma = 2;                // team2r: row DMAs of a wave per round (Team2RHost::rowdma)
     int *tgrid = nullptr, *tpanel = nullptr, *tinfo = nullptr;
     uint32_t *trec = nullptr;
     long long *tvoff = nullptr;
@@ -441,6 +442,8 @@ static int ensure_team2r(crp_csr_dev *A, hipStream_t stream, int G)
     crp::released_async<crp::Team2RHost> th_owner;
     crp::Team2RHost &th = *th_owner;
     th.G = G == 2 ? 2 : 4;
+    // half rounds (8 KiB ring sets, three workgroups per CU): CRPSPMM_T2R_ROWDMA=1
+    th.rowdma = (getenv("CRPSPMM_T2R_ROWDMA") && atoi(getenv("CRPSPMM_T2R_ROWDMA")) == 1) ? 1 : 2;
     std::vector<int> colpos;
     if (!A->perm.empty())
     {
@@ -450,6 +453,7 @@ static int ensure_team2r(crp_csr_dev *A, hipStream_t stream, int G)
     crp::build_team2r(h, A->nrow, fmt_rowptr(A), fmt_colidx(A), &th, colpos.empty() ? nullptr : colpos.data());
     clk.lap("ensure_team2r: build_team2n");
     t.G = th.G;
+    t.rowdma = th.rowdma;
     t.nteam = th.nteam;
     t.lattice = th.lattice;
     t.ngrid = (int) th.tgrid.size();
@@ -1013,6 +1017,7 @@ int crp_spmm_csr_f64(crp_csr_dev_p A, int layout, int n, const double *B0, long 
         crp::Team2NArgs t;
         t.G = d.G; t.nteam = d.nteam; t.ngrid = d.ngrid; t.tgrid = d.tgrid; t.tpanel = d.tpanel; t.tinfo = d.tinfo; t.trec = d.trec; t.tvoff = d.tvoff; t.tval = d.tval;
         t.tent = d.tent;
+        t.rowdma = d.rowdma;
         if (d.rows_epoch != A->rowmap_epoch || d.rows_map != a.rowmap)      // the C rows of the panels, once per row map
         {
             CRP_TRY(crp::team2r_fill_rows(t, a, (hipStream_t) stream));
@@ -1210,12 +1215,15 @@ int crp_team2r_format_host(int nrow, const int *rowptr, const int *colidx, const
                            int **tinfo, unsigned **trec, long long *nrecwords, long long **tvoff, double **tval, long long *nwords,
                            int **tgrid, int *ngrid, unsigned **vmap, long long *stats, unsigned **tent)
 {
+    const int rowdma = (G >> 8) == 1 ? 1 : 2;                               // G + 256: half rounds (one row DMA per wave and round)
+    G &= 0xFF;
     if (nrow < 0 || rowptr == NULL || (G != 2 && G != 4) || !nteam || !tpanel || !tinfo || !trec || !nrecwords || !tvoff || !tval || !nwords || !tgrid || !ngrid)
         return -1;
     crp::PanelHost h;
     crp::build_panels(nrow, rowptr, colidx, val, 8, &h, false, false);
     crp::Team2RHost th;
     th.G = G;
+    th.rowdma = rowdma;
     crp::build_team2r(h, nrow, rowptr, colidx, &th);
     *nteam = th.nteam;
     if (lattice) *lattice = th.lattice ? 1 : 0;

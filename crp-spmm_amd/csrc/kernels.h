@@ -106,6 +106,7 @@ struct Team2NArgs         // panel_format.h, Team2NHost
     const long long *tvoff;    // 8 * nteam
     const double   *tval;
     uint32_t       *tent;      // team2r: the entry table (Team2RHost::tent), or nullptr
+    int             rowdma = 2; // team2r: row DMAs of a wave per round (Team2RHost::rowdma)
 };
 
 // narrow_kernel.hip: row-panel format, n <= 64 (several entries of a panel per instruction)

@@ -2076,7 +2076,10 @@ void build_team2r(const PanelHost &p, int nrow, const int *rowptr, const int *co
     constexpr int W = 8, T = 8;
     const int G = out->G == 2 ? 2 : 4;
     out->G = G;
-    const int S = 16 * G, SLOTB = 1024 / G, PERW = 2 * G;                   // slots of a round, bytes of a slot, slots a wave fetches
+    const int RD = out->rowdma == 1 ? 1 : 2;
+    out->rowdma = RD;
+    const int S = 8 * G * RD, SLOTB = 1024 / G, PERW = G * RD;              // slots of a round, bytes of a slot, slots a wave fetches
+    const int ZERO = team2r_zero(RD);
     PhaseClock clk;
     released_async<TeamHost> th_owner;
     TeamHost &th = *th_owner;
@@ -2287,7 +2290,7 @@ void build_team2r(const PanelHost &p, int nrow, const int *rowptr, const int *co
                     }
                     double *vals = &out->tval[(size_t) (w0 + at16 * 2)];                         // [8][Lp]
                     uint16_t *offs = reinterpret_cast<uint16_t *>(vals + (size_t) 8 * Lp);       // [8][Lp]
-                    for (int i = 0; i < 8 * Lp; i++) offs[i] = (uint16_t) TEAM2R_ZERO;
+                    for (int i = 0; i < 8 * Lp; i++) offs[i] = (uint16_t) ZERO;
                     int fill[8] = {0, 0, 0, 0, 0, 0, 0, 0};
                     for (int i = to.iptr[(size_t) r * W + (size_t) w]; i < to.iptr[(size_t) r * W + (size_t) w + 1]; i++)
                     {

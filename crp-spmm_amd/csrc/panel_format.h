@@ -232,8 +232,8 @@ void build_team2n(const PanelHost &p, int nrow, const int *rowptr, const int *co
 // that has run out of nonzeros in this round gets the value 0.0 and the offset of a slice of zeros (TEAM2R_ZERO) -- so an absent
 // (row, column) pair still is never multiplied with a B entry.  ~1.1 instructions per nonzero where the masked-row step of the
 // narrow kernels spends 57 per four panel entries = 7.7 per nonzero when an entry holds 1.84 of 8 rows (nlpkkt).
-// A round has 16 KiB of slices: S = 16 G slots of 1024 / G bytes; wave w fetches slots 2 G w .. 2 G w + 2 G - 1 with two DMA
-// instructions.  What a wave owns of a round: Lp steps (a multiple of 4, at most TEAM2R_LCAP: the scheduler closes a round before a
+// A round has 16 KiB of slices (rowdma = 2; 8 KiB with rowdma = 1): S = 8 G rowdma slots of 1024 / G bytes; wave w fetches slots
+// G rowdma w .. G rowdma (w + 1) - 1 with rowdma DMA instructions.  What a wave owns of a round: Lp steps (a multiple of 4, at most TEAM2R_LCAP: the scheduler closes a round before a
 // row would pass it), stored as a BLOCK of the wave's stream: [8 rows][Lp] values (doubles), [8 rows][Lp] offsets (uint16), and a
 // 64-byte HEADER = the wave's record of round r + 2 of the same team (zeros past the team's last round): the kernel issues the DMAs
 // of round r + 2 while it consumes round r, and finds what to fetch in the block that has just landed -- no load on its path.
@@ -244,10 +244,15 @@ void build_team2n(const PanelHost &p, int nrow, const int *rowptr, const int *co
 // tent[(e * 8 + w) * 32]: [0] rounds (0 = no team: the run ends), [1] panel, [2], [3] tvoff (low, high), [4 .. 14) record of round 0,
 // [14 .. 24) record of round 1 (its first 10 words), [24 .. 32) the C rows of the panel's 8 rows (filled on the device from the row map).
 constexpr int TEAM2R_LCAP = 12;
-constexpr int TEAM2R_ZERO = 16384;              // LDS byte offset of the zero slice inside a ring set
+// rowdma = 1: HALF rounds -- 8 G slots of 1024 / G bytes (8 KiB), one row DMA per wave and round: the ring of a workgroup is 26 KiB
+// instead of 50 and three workgroups fit a CU instead of two.  The zero slice sits behind the slots of a set: offset 8192 * rowdma.
+// (Measured: 0.634 / 1.322 ms against 0.475 / 0.969 at n = 32 / 64 on the nlpkkt stand-in, 9.72 / 21.7 against 7.7 / 17 at nlpkkt240
+//  size -- what a round costs beside its FMAs does not halve with its slots.  An option: CRPSPMM_T2R_ROWDMA=1.)
+inline int team2r_zero(int rowdma) { return 8192 * rowdma; }
 struct Team2RHost
 {
     int G = 4;
+    int rowdma = 2;                  // row DMA instructions of a wave per round: 2 (16 G slots) or 1 (8 G slots); set before build_team2r
     int nteam = 0;
     bool lattice = false;
     std::vector<int>       tpanel, torder, tgrid, tinfo;

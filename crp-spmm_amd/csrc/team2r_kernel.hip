@@ -42,9 +42,11 @@ namespace {
 typedef double d2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u2 __attribute__((ext_vector_type(2)));
-constexpr int T2R_NSET = 3, T2R_SETB = 16384 + 512, T2R_VALB = 64 * TEAM2R_LCAP, T2R_BLKB = 80 * TEAM2R_LCAP + 64, T2R_WBLK = T2R_NSET * T2R_BLKB;
-constexpr int T2R_LDS = T2R_NSET * T2R_SETB + 8 * T2R_WBLK;
-static_assert(TEAM2R_ZERO == 16384 && T2R_BLKB == 1024 && 2 * T2R_LDS <= 160 * 1024, "ring set / block layout, two workgroups per CU");
+constexpr int T2R_NSET = 3, T2R_BLKB = 80 * TEAM2R_LCAP + 64, T2R_WBLK = T2R_NSET * T2R_BLKB;
+constexpr int t2r_setb(int rd) { return 8192 * rd + 512; }                  // slots + the slice of zeros (512 bytes: a slice of the G = 2 instance)
+constexpr int t2r_lds(int rd) { return T2R_NSET * t2r_setb(rd) + 8 * T2R_WBLK; }
+static_assert(T2R_BLKB == 1024 && 5 * TEAM2R_LCAP + 4 <= 64 && 2 * t2r_lds(2) <= 160 * 1024 && 3 * t2r_lds(1) <= 160 * 1024,
+              "block layout; two (full rounds) or three (half rounds) workgroups per CU");
 #define T2R_GPTR(p) ((const __attribute__((address_space(1))) void *) (p))
 #define T2R_LPTR(p) ((__attribute__((address_space(3))) void *) (p))
 // One chunk = four steps of TWO rows' accumulators (lane group q's rows h0 G + q and (h0 + 1) G + q), all in one asm statement
@@ -98,13 +100,14 @@ static_assert(TEAM2R_ZERO == 16384 && T2R_BLKB == 1024 && 2 * T2R_LDS <= 160 * 1
 struct T2RRec { uint32_t w[10]; };                                          // Lp, block offset, up to 8 columns
 struct T2RTeam { int nr; long long vb; T2RRec r0, r1; };
 
-template <int G, bool HAS_B1>
+template <int G, bool HAS_B1, int RD>
 __global__ __launch_bounds__(512, 4) void spmm_team2r_kernel(const int ngrid, const uint32_t *__restrict__ tent, const double *__restrict__ tval,
                                                              const int n, const double *__restrict__ B0, const int64_t ldB0,
                                                              const double *__restrict__ B1, const int64_t ldB1, double *__restrict__ C,
                                                              const int64_t ldC, const int stagger, unsigned long long *dbg)
 {
-    constexpr int LPG = 64 / G, SLOTB = 1024 / G, PERW = 2 * G, NH = 8 / G;
+    constexpr int LPG = 64 / G, SLOTB = 1024 / G, PERW = RD * G, NH = 8 / G;
+    constexpr int T2R_SETB = t2r_setb(RD), ZERO = 8192 * RD;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
@@ -118,7 +121,7 @@ __global__ __launch_bounds__(512, 4) void spmm_team2r_kernel(const int ngrid, co
     const uint32_t blk0 = (uint32_t) (T2R_NSET * T2R_SETB + wave * T2R_WBLK);            // relative to lds (DMA destinations), + lds0 for reads
     // the slices of zeros (one per ring set: offsets are relative to the set; 512 bytes: a slice of the G = 2 instance)
     if (threadIdx.x < T2R_NSET * 32)
-        *reinterpret_cast<d2 *>(lds + (threadIdx.x >> 5) * T2R_SETB + TEAM2R_ZERO + (threadIdx.x & 31) * 16) = d2{0.0, 0.0};
+        *reinterpret_cast<d2 *>(lds + (threadIdx.x >> 5) * T2R_SETB + ZERO + (threadIdx.x & 31) * 16) = d2{0.0, 0.0};
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                      // written before this wave reaches the first round's barrier
     double a[NH][2], pa[NH][2];
 #pragma unroll
@@ -147,7 +150,7 @@ __global__ __launch_bounds__(512, 4) void spmm_team2r_kernel(const int ngrid, co
     auto fetch = [&](const T2RRec &R, const int set, const long long vb) {  // the four DMAs of a round
         const int Lp = (int) R.w[0];
 #pragma unroll
-        for (int j = 0; j < 2; j++)
+        for (int j = 0; j < RD; j++)
         {
             // (readfirstlane: or the optimiser turns the selection into a per-lane load of R.w[2 + j G + q] from a stack copy)
             int col = __builtin_amdgcn_readfirstlane((int) R.w[2 + j * G]);
@@ -164,12 +167,12 @@ __global__ __launch_bounds__(512, 4) void spmm_team2r_kernel(const int ngrid, co
         }
         const char *bsrc = reinterpret_cast<const char *>(tval) + vb + (size_t) R.w[1] * 16;
         char *bdst = lds + blk0 + set * T2R_BLKB;
-        // values: 64 Lp bytes; offsets and the header: 16 Lp + 64 bytes (the count of DMAs per round is fixed: one lane at least)
-        if (lane < max(1, 4 * Lp)) __builtin_amdgcn_global_load_lds(T2R_GPTR(bsrc + lane * 16), T2R_LPTR(bdst), 16, 0, 0);
-        if (lane < Lp + 4) __builtin_amdgcn_global_load_lds(T2R_GPTR(bsrc + 64 * Lp + lane * 16), T2R_LPTR(bdst + T2R_VALB), 16, 0, 0);
+        // the block as it lies in the stream: values (64 Lp bytes), offsets (16 Lp), header (64) = 5 Lp + 4 lanes of ONE instruction
+        // (Lp <= 12: 64 lanes; every DMA instruction costs a wave ~170 cycles of issue here)
+        if (lane < 5 * Lp + 4) __builtin_amdgcn_global_load_lds(T2R_GPTR(bsrc + lane * 16), T2R_LPTR(bdst), 16, 0, 0);
     };
     auto header = [&](const int set, const int Lp) {                        // the record behind the block in ring set `set`
-        const uint32_t ad = lds0 + blk0 + (uint32_t) (set * T2R_BLKB + T2R_VALB + 16 * Lp);
+        const uint32_t ad = lds0 + blk0 + (uint32_t) (set * T2R_BLKB + 80 * Lp);
         u4 h0, h1;
         u2 h2;
         asm volatile("ds_read_b128 %[h0], %[ad]\n\tds_read_b128 %[h1], %[ad] offset:16\n\tds_read_b64 %[h2], %[ad] offset:32\n\ts_waitcnt lgkmcnt(0)"
@@ -279,9 +282,13 @@ __global__ __launch_bounds__(512, 4) void spmm_team2r_kernel(const int ngrid, co
     while (ahead > 0)
     {
         T2R_CLK(c0);
-        // this wave's four DMAs of the round to consume have landed (those of the round behind it may still fly; stores of the
+        // this wave's DMAs of the round to consume (RD rows + the block) have landed (those of the round behind it may still fly; stores of the
         // last flush count too, which can only make this wait longer: loads complete in order) ...
-        if (ahead > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (ahead > 1)
+        {
+            if constexpr (RD == 2) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        }
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // ... and everybody's; every wave is also done reading the round before, whose set the next issue takes
         T2R_CLK(c1);
@@ -302,7 +309,7 @@ __global__ __launch_bounds__(512, 4) void spmm_team2r_kernel(const int ngrid, co
         const int Lp = f0 & 0xFF;
         const uint32_t rs = lds0 + (uint32_t) (sc * T2R_SETB + l * 16);
         const uint32_t vs = lds0 + blk0 + (uint32_t) (sc * T2R_BLKB);
-        const uint32_t os = vs + T2R_VALB;
+        const uint32_t os = vs + 64u * (uint32_t) Lp;
         if (Lp > 0)
         {
 #pragma unroll
@@ -416,25 +423,32 @@ hipError_t spmm_rm_f64_team2r(const Team2NArgs &t, const SpmmArgs &a, hipStream_
         (void) hipMemcpy(h, dbg_buf, 64, hipMemcpyDeviceToHost);
         (void) hipMemset(dbg_buf, 0, 64);
         if (h[5] > 0)
-            fprintf(stderr, "[t2r dbg] wave-rounds %llu: per round  wait %.0f  barrier %.0f  issue %.0f (record %.0f, four DMAs %.0f)  flush %.0f  consume %.0f (s_memtime ticks)\n", h[5],
+            fprintf(stderr, "[t2r dbg] wave-rounds %llu: per round  wait %.0f  barrier %.0f  issue %.0f (record %.0f, DMAs %.0f)  flush %.0f  consume %.0f (s_memtime ticks)\n", h[5],
                     (double) h[0] / h[5], (double) h[1] / h[5], (double) h[2] / h[5], (double) h[6] / h[5], (double) h[7] / h[5], (double) h[3] / h[5], (double) h[4] / h[5]);
     }
     dbg = dbg_buf;
 #endif
-#define CRP_T2R_GO(G_, HB1_)                                                                                                                        \
+#define CRP_T2R_GO(G_, HB1_, RD_)                                                                                                                   \
     do                                                                                                                                              \
     {                                                                                                                                               \
         static bool once = false;                                                                                                                   \
         if (!once)                                                                                                                                  \
         {                                                                                                                                           \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&spmm_team2r_kernel<G_, HB1_>), hipFuncAttributeMaxDynamicSharedMemorySize, T2R_LDS); \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&spmm_team2r_kernel<G_, HB1_, RD_>), hipFuncAttributeMaxDynamicSharedMemorySize, t2r_lds(RD_)); \
             if (e != hipSuccess) return e;                                                                                                          \
             once = true;                                                                                                                            \
         }                                                                                                                                           \
-        hipLaunchKernelGGL((spmm_team2r_kernel<G_, HB1_>), grid, dim3(512), T2R_LDS, s, t.ngrid, t.tent, t.tval, a.n, a.B0, a.ldB0, a.B1, a.ldB1, a.C, a.ldC, stagger, dbg); \
+        hipLaunchKernelGGL((spmm_team2r_kernel<G_, HB1_, RD_>), grid, dim3(512), t2r_lds(RD_), s, t.ngrid, t.tent, t.tval, a.n, a.B0, a.ldB0, a.B1, a.ldB1, a.C, a.ldC, stagger, dbg); \
     } while (0)
-    if (t.G == 4) { if (has_b1) CRP_T2R_GO(4, true); else CRP_T2R_GO(4, false); }
-    else { if (has_b1) CRP_T2R_GO(2, true); else CRP_T2R_GO(2, false); }
+#define CRP_T2R_PICK(RD_)                                                                                       \
+    do                                                                                                          \
+    {                                                                                                           \
+        if (t.G == 4) { if (has_b1) CRP_T2R_GO(4, true, RD_); else CRP_T2R_GO(4, false, RD_); }                  \
+        else { if (has_b1) CRP_T2R_GO(2, true, RD_); else CRP_T2R_GO(2, false, RD_); }                           \
+    } while (0)
+    if (t.rowdma == 1) CRP_T2R_PICK(1);
+    else CRP_T2R_PICK(2);
+#undef CRP_T2R_PICK
 #undef CRP_T2R_GO
     return hipGetLastError();
 }

@@ -208,8 +208,9 @@ def team2n_format_host(rowptr, colidx, val, G=4):
                 rounds=int(stats[0]), parts=int(stats[1]), slots_filled=int(stats[2]))
 
 
-def team2r_format_host(rowptr, colidx, val, G=4):
-    """crp_team2r_format_host -> dict(G, nteam, lattice, tpanel[nteam, 8], tinfo[nteam, 2], trec[rounds, 8, 16] (uint32), tvoff (units
+def team2r_format_host(rowptr, colidx, val, G=4, rowdma=2):
+    """rowdma = 1: half rounds (8 G slots per round, crp_team2r_format_host with G + 256).
+    crp_team2r_format_host -> dict(G, nteam, lattice, tpanel[nteam, 8], tinfo[nteam, 2], trec[rounds, 8, 16] (uint32), tvoff (units
     of 16 bytes), tval (the streams as float64 words; view as uint16 for the offsets), tgrid[8, -1], vmap, rounds, steps, slots_filled, nnz)."""
     lib = L.load()
     rp = np.ascontiguousarray(rowptr, dtype=np.int32)
@@ -226,7 +227,7 @@ def team2r_format_host(rowptr, colidx, val, G=4):
     nrw, nwd = C.c_longlong(), C.c_longlong()
     stats = (C.c_longlong * 4)()
     L.check(lib.crp_team2r_format_host(rp.size - 1, rp.ctypes.data_as(L.c_int_p), ci.ctypes.data_as(L.c_int_p), va.ctypes.data_as(L.c_dbl_p),
-                                       int(G), C.byref(nteam), C.byref(lat), C.byref(tp), C.byref(ti), C.byref(tr), C.byref(nrw), C.byref(tv),
+                                       int(G) + (256 if int(rowdma) == 1 else 0), C.byref(nteam), C.byref(lat), C.byref(tp), C.byref(ti), C.byref(tr), C.byref(nrw), C.byref(tv),
                                        C.byref(tval), C.byref(nwd), C.byref(tg), C.byref(ng), C.byref(vm), stats, C.byref(te)), "crp_team2r_format_host")
     nt = nteam.value
 
@@ -234,7 +235,7 @@ def team2r_format_host(rowptr, colidx, val, G=4):
         out = np.ctypeslib.as_array(ptr, (max(cnt, 1),))[:cnt].astype(dt).copy()
         L.c_free(C.cast(ptr, C.c_void_p))
         return out
-    return dict(G=int(G), nteam=nt, lattice=bool(lat.value), tpanel=take(tp, 8 * nt, np.int32).reshape(nt, 8),
+    return dict(G=int(G), rowdma=2 if int(rowdma) != 1 else 1, nteam=nt, lattice=bool(lat.value), tpanel=take(tp, 8 * nt, np.int32).reshape(nt, 8),
                 tinfo=take(ti, 2 * nt, np.int32).reshape(nt, 2), trec=take(tr, nrw.value, np.uint32).reshape(-1, 8, 16),
                 tvoff=take(tv, 8 * nt + 1, np.int64), tval=take(tval, nwd.value, np.float64),
                 tgrid=take(tg, ng.value, np.int32).reshape(8, -1), vmap=take(vm, nnz, np.uint32),

@@ -206,13 +206,13 @@ int crp_team2n_format_host(int nrow, const int *rowptr, const int *colidx, const
                            int **tgrid, int *ngrid, unsigned **vmap, long long *stats);
 
 /* Host-only: the streams variant 7 ("team2r-R8", csrc/team2r_kernel.hip: the row-owner team kernel for operands of 24 .. 64 fp64
- * columns) consumes.  Teams as variant 5.  A round has 16 G ring slots of 1024 / G bytes (G = 4: n <= 32, 2: n <= 64); wave w fetches
- * slots 2 G w .. 2 G w + 2 G - 1.  Round r (from tinfo[2g + 1] on, tinfo[2g] rounds), wave w owns trec[(r * 8 + w) * 16 ..]: [0] Lp =
+ * columns) consumes.  Teams as variant 5.  A round has 8 G d ring slots of 1024 / G bytes (G = 4: n <= 32, 2: n <= 64; d = 2 row DMA
+ * instructions per wave and round, or -- G + 256 passed as G -- d = 1: half rounds); wave w fetches slots G d w .. G d (w + 1) - 1.  Round r (from tinfo[2g + 1] on, tinfo[2g] rounds), wave w owns trec[(r * 8 + w) * 16 ..]: [0] Lp =
  * steps (multiple of 4, <= 12); [1] first 16-byte unit of its block inside the wave's stream, which starts at byte 16 * tvoff[8g + w]
- * of tval; [2 .. 2 + 2 G) the columns of the slots the wave fetches for this round.  A block = [8 rows][Lp] doubles, then
+ * of tval; [2 .. 2 + G d) the columns of the slots the wave fetches for this round.  A block = [8 rows][Lp] doubles, then
  * [8 rows][Lp] uint16, then a 64-byte header = the record of round r + 2 of the same team and wave (zeros past the last round):
  * step s of row i multiplies the value with the B row slice at that byte offset of the round's ring set (slot * 1024 / G);
- * 16384 = the slice of zeros (padding, value 0.0).  vmap[nz] = 8-byte word of tval that holds CSR nonzero nz.
+ * 8192 d = the slice of zeros (padding, value 0.0).  vmap[nz] = 8-byte word of tval that holds CSR nonzero nz.
  * tent (may be NULL): per entry e of tgrid and wave w 32 words at tent[(e * 8 + w) * 32]: [0] rounds (0: no team), [1] panel, [2], [3]
  * tvoff, [4 .. 14) record of round 0, [14 .. 24) of round 1, [24 .. 32) 0xFFFFFFFF (the C rows, filled on the device).
  * stats (4, may be NULL): rounds, steps (sum of Lp), filled slots, nonzeros.  malloc'd copies (caller frees). */

@@ -1093,3 +1093,31 @@ def test_team2n_kernel(crp, orc, gpu, n, variant):
     B = np.random.default_rng(n + 2).normal(size=(m, n))
     got = _spmm(crp, gpu, rp, ci, va, m, B, n, variant=variant)
     assert orc.rel_fro_err(orc.spmm_csr(rp, ci, va, B), got) <= FP64_TOL
+
+
+@pytest.mark.parametrize("n", [24, 32, 40, 64])
+def test_team2r_half_rounds(crp, orc, gpu, monkeypatch, n):
+    """Variant 7 on half rounds (CRPSPMM_T2R_ROWDMA=1: 8 KiB ring sets, one row DMA per wave and round, three workgroups per CU):
+    the kernel instance and the format of that layout against the oracle, two-source index included."""
+    from crp_spmm_amd import gen
+    monkeypatch.setenv("CRPSPMM_T2R_ROWDMA", "1")
+    cases = [gen.random_csr(777, 1234, 70, seed=n, empty_every=13), gen.kkt3d(12), gen.banded_fem(5000, offsets=(1, 2, 3, 40, 41, 900), seed=n),
+             gen.random_csr(13, 40, 5, seed=1)]
+    for rp, ci, va in cases:
+        m = len(rp) - 1
+        k = max(int(ci.max()) + 1, 1) if ci.size else 1
+        B = np.random.default_rng(n).uniform(-2, 2, size=(k, n))
+        ref = orc.spmm_csr(rp, ci, va, B)
+        for ldpad in (0, 2):
+            got = _spmm(crp, gpu, rp, ci, va, k, B, n, ldpad=ldpad, variant=7)
+            assert orc.rel_fro_err(ref, got) <= FP64_TOL, (m, ldpad)
+    m, k = 500, 900
+    rp, ci, va = gen.random_csr(m, k, 30, seed=2)
+    lo, hi = 300, 650
+    remote_rows = np.concatenate([np.arange(0, lo), np.arange(hi, k)])
+    pos = np.full(k, -1)
+    pos[remote_rows] = np.arange(remote_rows.size)
+    c2 = np.where((ci >= lo) & (ci < hi), ci - lo, ~pos[ci]).astype(np.int32)
+    B = np.random.default_rng(n + 1).normal(size=(k, n))
+    got = _spmm(crp, gpu, rp, c2, va, hi - lo, B[lo:hi], n, B1=B[remote_rows], variant=7)
+    assert orc.rel_fro_err(orc.spmm_csr(rp, ci, va, B), got) <= FP64_TOL

@@ -833,8 +833,8 @@ def test_team2n_streams_replay(crp, orc, G):
 
 def _replay_team2r(t, m, B, va):
     """What csrc/team2r_kernel.hip does with the streams of crp_team2r_format_host, in numpy (B1-less)."""
-    G = t["G"]
-    S, slotb, perw = 16 * G, 1024 // G, 2 * G
+    G, rd = t["G"], t["rowdma"]
+    S, slotb, perw, zero = 8 * G * rd, 1024 // G, G * rd, 8192 * rd
     out = np.zeros((m, B.shape[1]))
     done = np.zeros(m, dtype=np.int64)
     assert np.array_equal(t["tval"][t["vmap"]], va)
@@ -875,7 +875,7 @@ def _replay_team2r(t, m, B, va):
                 for rr in range(8):
                     for st in range(Lp):
                         o = int(offs[rr, st])
-                        if o == 16384:
+                        if o == zero:
                             assert vals[rr, st] == 0.0                    # padding: the slice of zeros, never a B row
                             continue
                         assert o % slotb == 0 and o // slotb < S
@@ -897,8 +897,9 @@ def _replay_team2r(t, m, B, va):
     return out
 
 
+@pytest.mark.parametrize("rowdma", [2, 1])
 @pytest.mark.parametrize("G", [4, 2])
-def test_team2r_streams_replay(crp, orc, G):
+def test_team2r_streams_replay(crp, orc, G, rowdma):
     """The streams of the row-owner team kernel (variant 7), replayed in numpy: every row is produced once and equals the oracle's
     product; padding steps carry the value 0.0 and the offset of the slice of zeros."""
     from crp_spmm_amd import gen, hip
@@ -920,7 +921,7 @@ def test_team2r_streams_replay(crp, orc, G):
     for name, rp, ci, va in cases:
         m = len(rp) - 1
         k = int(ci.max()) + 1 if ci.size else 1
-        t = hip.team2r_format_host(rp, ci, va, G=G)
+        t = hip.team2r_format_host(rp, ci, va, G=G, rowdma=rowdma)
         assert np.array_equal(np.sort(t["tpanel"][t["tpanel"] >= 0]), np.arange((m + 7) // 8)), name
         B = rng.uniform(-1, 1, size=(k, 3))
         got = _replay_team2r(t, m, B, va)
