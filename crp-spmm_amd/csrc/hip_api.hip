@@ -450,7 +450,7 @@ static int ensure_team2r(crp_csr_dev *A, hipStream_t stream, int G)
         colpos.resize(A->perm.size());
         for (size_t i = 0; i < A->perm.size(); i++) colpos[(size_t) A->perm[i]] = (int) i;
     }
-    crp::build_team2r(h, A->nrow, fmt_rowptr(A), fmt_colidx(A), &th, colpos.empty() ? nullptr : colpos.data());
+    if (!crp::build_team2r(h, A->nrow, fmt_rowptr(A), fmt_colidx(A), &th, colpos.empty() ? nullptr : colpos.data())) return -6;   // too large for this format
     clk.lap("ensure_team2r: build_team2n");
     t.G = th.G;
     t.rowdma = th.rowdma;
@@ -1012,6 +1012,12 @@ int crp_spmm_csr_f64(crp_csr_dev_p A, int layout, int n, const double *B0, long 
         A->last_variant = 7;
         const int G = n <= 32 ? 4 : 2;
         const int rc = ensure_team2r(A, (hipStream_t) stream, G);
+        if (rc == -6 && variant == 0)
+        {
+            // the streams of this matrix would pass their 32-bit offsets: variant 0 goes on with the row-panel kernels, for good
+            A->team2r_pays = false;
+            return crp_spmm_csr_f64(A, layout, n, B0, ldB0, B1, ldB1, C, ldC, (getenv("CRPSPMM_TEAM2R") != NULL) ? 3 : 0, stream);
+        }
         if (rc != 0) return rc;
         Team2NDev &d = A->team2r[G == 2 ? 1 : 0];
         crp::Team2NArgs t;
@@ -1224,7 +1230,7 @@ int crp_team2r_format_host(int nrow, const int *rowptr, const int *colidx, const
     crp::Team2RHost th;
     th.G = G;
     th.rowdma = rowdma;
-    crp::build_team2r(h, nrow, rowptr, colidx, &th);
+    if (!crp::build_team2r(h, nrow, rowptr, colidx, &th)) return -6;
     *nteam = th.nteam;
     if (lattice) *lattice = th.lattice ? 1 : 0;
     auto dup = [](const void *src, size_t bytes) {

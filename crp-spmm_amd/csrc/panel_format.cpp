@@ -2071,7 +2071,7 @@ void build_team2n(const PanelHost &p, int nrow, const int *rowptr, const int *co
 }
 
 // ---- team2r streams (panel_format.h) ----------------------------------------------------------------------
-void build_team2r(const PanelHost &p, int nrow, const int *rowptr, const int *colidx, Team2RHost *out, const int *colpos)
+bool build_team2r(const PanelHost &p, int nrow, const int *rowptr, const int *colidx, Team2RHost *out, const int *colpos)
 {
     constexpr int W = 8, T = 8;
     const int G = out->G == 2 ? 2 : 4;
@@ -2246,7 +2246,7 @@ void build_team2r(const PanelHost &p, int nrow, const int *rowptr, const int *co
     }
     out->tvoff[(size_t) nteam * W] = run;
     out->nwords = run * 2;
-    if (rec0 >= (1LL << 31) / 128 || run >= (1LL << 31)) { fprintf(stderr, "[FATAL] team2r format: streams too long for 32-bit offsets\n"); abort(); }
+    if (rec0 >= (1LL << 31) / 128 || run >= (1LL << 31)) return false;     // (the caller falls back to the row-panel kernels)
     {
         std::vector<int> cut(9, nteam);
         long long total = 0;
@@ -2349,6 +2349,7 @@ void build_team2r(const PanelHost &p, int nrow, const int *rowptr, const int *co
         for (long long nz = b; nz < e; nz++) out->vmap[(size_t) nz] = slot_of[(size_t) p.pmap[(size_t) nz]];
     });
     clk.lap("build_team2r: value-update map");
+    return true;
 }
 
 void apply_team_schedule(PanelHost *p, const TeamHost &t)

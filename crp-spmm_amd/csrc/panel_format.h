@@ -263,7 +263,8 @@ struct Team2RHost
     std::vector<uint32_t>  vmap;     // per CSR nonzero: its 8-byte word in tval
     long long nwords = 0, rounds = 0, steps = 0, nnz = 0, slots_filled = 0;   // steps = sum of Lp over (round, wave)
 };
-void build_team2r(const PanelHost &p, int nrow, const int *rowptr, const int *colidx, Team2RHost *out, const int *colpos = nullptr);
+// false: the streams would pass what their 32-bit offsets address (34 GB); nothing usable in *out then
+bool build_team2r(const PanelHost &p, int nrow, const int *rowptr, const int *colidx, Team2RHost *out, const int *colpos = nullptr);
 
 // Number of panel entries (before padding) a given R would need: cheap pass used
 // to pick R.  colidx may carry the two-source encoding.

@@ -170,7 +170,7 @@ int main()
                     if (tn.vmap[p2] >= tn.tval.size() || tn.tval[tn.vmap[p2]] != a.va[p2]) { printf("FAIL team2n vmap entry %zu\n", p2); return 1; }
                 crp::Team2RHost tr;
                 tr.G = G;
-                crp::build_team2r(h8, a.m, a.rp.data(), a.ci.data(), &tr, pos.empty() ? nullptr : pos.data());
+                if (!crp::build_team2r(h8, a.m, a.rp.data(), a.ci.data(), &tr, pos.empty() ? nullptr : pos.data())) { printf("FAIL team2r refused\n"); return 1; }
                 if (tr.tgrid.size() % 8 || tr.tent.size() != tr.tgrid.size() * 256 || (long long) tr.tval.size() < tr.nwords || tr.vmap.size() != a.ci.size())
                 { printf("FAIL team2r sizes\n"); return 1; }
                 for (size_t p2 = 0; p2 < tr.vmap.size(); p2++)
