@@ -392,9 +392,11 @@ bool spmm_team2r_applicable(const Team2NArgs &t, const SpmmArgs &a)
 hipError_t spmm_rm_f64_team2r(const Team2NArgs &t, const SpmmArgs &a, hipStream_t s)
 {
     const bool has_b1 = a.B1 != nullptr;
-    // persistent workgroups: two fit a CU (the LDS of one is 73.5 KiB); four times as many are launched, so that the hardware's
-    // dispatcher evens out what round-robin chains of teams leave uneven (nlpkkt stand-in n = 32 / 64: 0.490 / 0.986 ms against
-    // 0.510 / 0.998 with exactly the resident number); eight XCD runs; never more workgroups than teams of a run
+    // Persistent workgroups: two fit a CU (the LDS of one is 73.5 KiB), but enough are launched that each takes a chain of about
+    // seven teams (and never fewer than are resident): the resident workgroups then work on neighbouring teams -- chains that run
+    // for the whole launch drift apart, and with them the B rows their teams share (nlpkkt240 size, n = 32: 7.64 ms with 512
+    // workgroups, 7.36 with 2048, 6.90 with 16384, 6.63 with 65536 = chains of 6.7 teams, 7.06 with one team per workgroup).
+    // Eight XCD runs; CRPSPMM_T2R_WGS overrides.
     static int ncu = 0;
     if (ncu == 0)
     {
@@ -404,7 +406,8 @@ hipError_t spmm_rm_f64_team2r(const Team2NArgs &t, const SpmmArgs &a, hipStream_
         ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
     const int wgs_env = getenv("CRPSPMM_T2R_WGS") ? atoi(getenv("CRPSPMM_T2R_WGS")) : 0;
-    const int per_xcd = std::max(1, std::min(t.ngrid / 8, (wgs_env > 0 ? wgs_env : 8 * ncu) / 8));
+    const int run = t.ngrid / 8;                                            // entries of an XCD's run
+    const int per_xcd = std::max(1, std::min(run, wgs_env > 0 ? wgs_env / 8 : std::max(2 * ncu / 8, (run + 6) / 7)));
     dim3 grid(per_xcd * 8);
     unsigned long long *dbg = nullptr;
     const int stagger = getenv("CRPSPMM_T2R_STAGGER") ? atoi(getenv("CRPSPMM_T2R_STAGGER")) : 1;
