@@ -104,7 +104,7 @@ template <int G, bool HAS_B1, int RD>
 __global__ __launch_bounds__(512, 4) void spmm_team2r_kernel(const int ngrid, const uint32_t *__restrict__ tent, const double *__restrict__ tval,
                                                              const int n, const double *__restrict__ B0, const int64_t ldB0,
                                                              const double *__restrict__ B1, const int64_t ldB1, double *__restrict__ C,
-                                                             const int64_t ldC, const int stagger, unsigned long long *dbg)
+                                                             const int64_t ldC, const int stagger, const int chain_k, unsigned long long *dbg)
 {
     constexpr int LPG = 64 / G, SLOTB = 1024 / G, PERW = RD * G, NH = 8 / G;
     constexpr int T2R_SETB = t2r_setb(RD), ZERO = 8192 * RD;
@@ -112,8 +112,11 @@ __global__ __launch_bounds__(512, 4) void spmm_team2r_kernel(const int ngrid, co
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
     const int cpx = ngrid >> 3;                                             // entries per XCD run (ngrid is a multiple of 8)
-    const int wx = (int) (gridDim.x >> 3);                                  // workgroups per XCD
-    const int e_end = (int) ((blockIdx.x & 7) + 1) * cpx;
+    const int wx0 = (int) (gridDim.x >> 3);                                 // workgroups per XCD
+    // a workgroup's chain of entries: every wx0-th of its XCD's run (chain_k = 0), or chain_k consecutive ones
+    const int wx = chain_k > 0 ? 1 : wx0;
+    const int e_first = (int) (blockIdx.x & 7) * cpx + (chain_k > 0 ? (int) (blockIdx.x >> 3) * chain_k : (int) (blockIdx.x >> 3));
+    const int e_end = chain_k > 0 ? min((int) ((blockIdx.x & 7) + 1) * cpx, e_first + chain_k) : (int) ((blockIdx.x & 7) + 1) * cpx;
     const int q = lane / LPG, l = lane % LPG, l16 = lane & 15;
     const int lo = (2 * l + 1 < n) ? l * 16 : 0;                           // lanes past n fetch the row's first bytes: valid, never stored
     // LDS byte addresses for the asm reads: the dynamic LDS's own offset (0 while this kernel has no static LDS) + ...
@@ -218,7 +221,7 @@ __global__ __launch_bounds__(512, 4) void spmm_team2r_kernel(const int ngrid, co
 
     // The round to issue next: entry ie, round ir of its team (cnr rounds, stream at byte cvb of tval).  tm = the table row loaded
     // last: the team at ie until its rounds 0 and 1 have been issued, then (reloaded at once) the team at ie + wx, one team ahead.
-    int ie = (int) (blockIdx.x & 7) * cpx + (int) (blockIdx.x >> 3), ir = 0;
+    int ie = e_first, ir = 0;
     T2RTeam tm = load_team(ie);
     int cnr = tm.nr;
     long long cvb = tm.vb;
@@ -409,6 +412,8 @@ hipError_t spmm_rm_f64_team2r(const Team2NArgs &t, const SpmmArgs &a, hipStream_
     const int run = t.ngrid / 8;                                            // entries of an XCD's run
     const int per_xcd = std::max(1, std::min(run, wgs_env > 0 ? wgs_env / 8 : std::max(2 * ncu / 8, (run + 6) / 7)));
     dim3 grid(per_xcd * 8);
+    // CRPSPMM_T2R_BLOCKED=1 (experiment): a workgroup's chain = consecutive entries of the run instead of every per_xcd-th
+    const int chain_k = (getenv("CRPSPMM_T2R_BLOCKED") && atoi(getenv("CRPSPMM_T2R_BLOCKED"))) ? (run + per_xcd - 1) / per_xcd : 0;
     unsigned long long *dbg = nullptr;
     const int stagger = getenv("CRPSPMM_T2R_STAGGER") ? atoi(getenv("CRPSPMM_T2R_STAGGER")) : 1;
 #ifdef T2R_DBG
@@ -441,7 +446,7 @@ hipError_t spmm_rm_f64_team2r(const Team2NArgs &t, const SpmmArgs &a, hipStream_
             if (e != hipSuccess) return e;                                                                                                          \
             once = true;                                                                                                                            \
         }                                                                                                                                           \
-        hipLaunchKernelGGL((spmm_team2r_kernel<G_, HB1_, RD_>), grid, dim3(512), t2r_lds(RD_), s, t.ngrid, t.tent, t.tval, a.n, a.B0, a.ldB0, a.B1, a.ldB1, a.C, a.ldC, stagger, dbg); \
+        hipLaunchKernelGGL((spmm_team2r_kernel<G_, HB1_, RD_>), grid, dim3(512), t2r_lds(RD_), s, t.ngrid, t.tent, t.tval, a.n, a.B0, a.ldB0, a.B1, a.ldB1, a.C, a.ldC, stagger, chain_k, dbg); \
     } while (0)
 #define CRP_T2R_PICK(RD_)                                                                                       \
     do                                                                                                          \
