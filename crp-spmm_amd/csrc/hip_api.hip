@@ -781,8 +781,8 @@ int crp_csr_dev_create(int nrow, int ncol, const int *rowptr, const int *colidx,
         {
             A->team2_min_n = TEAM2_MIN_N_SPARSE;
             // ... and at 24 .. 64 columns such panels go to the row-owner team kernel (variant 7, csrc/team2r_kernel.hip): nlpkkt
-            // stand-in 0.500 / 1.017 ms at n = 32 / 64 against 0.586 / 1.110 of the narrow and row-panel kernels, at nlpkkt240 size
-            // 7.83 / 17.3 against 8.92 / 18.2 (pwtk stand-in, fill 0.61: 0.075 against 0.062 -- stays).  CRPSPMM_TEAM2R=0|1 forces.
+            // stand-in 0.388 / 0.839 ms at n = 32 / 64 against 0.546 / 1.04 of the narrow and row-panel kernels, at nlpkkt240 size
+            // 6.58 / 14.0 against 8.85 / 18.2 (pwtk stand-in, fill 0.61: 0.075 against 0.062 -- stays).  CRPSPMM_TEAM2R=0|1 forces.
             A->team2r_pays = true;
         }
     }

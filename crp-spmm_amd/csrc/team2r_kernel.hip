@@ -21,7 +21,8 @@
 // workgroups with one pipeline across their teams (below).
 //
 // MEASURED (round 3, same box as the kernels it replaces): nlpkkt stand-in kkt3d(96) n = 32 / 64: 0.500 / 1.017 ms against 0.586 /
-// 1.110 of the narrow and row-panel kernels; at nlpkkt240 size 8.00 / 16.95 against 8.85 / 18.2; pwtk stand-in (filled panels) 0.075
+// 1.110 of the narrow and row-panel kernels (0.388 / 0.839 in bench.py's harness with the launch rule of spmm_rm_f64_team2r); at
+// nlpkkt240 size 6.58 / 14.0 against 8.85 / 18.2; pwtk stand-in (filled panels) 0.075
 // against 0.062: not taken there.  The teams are team2's (primal and dual panels of a KKT system together: with teams of one kind
 // the B rows both kinds share come from beyond L2 twice and the gain is gone at nlpkkt240 size), the union entries of a team go
 // to its rounds in natural order (dealt like cards they balance the waves of a round and cost 15 %).  A round takes ~3000 cycles of
