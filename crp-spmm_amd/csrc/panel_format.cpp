@@ -2201,7 +2201,7 @@ bool build_team2r(const PanelHost &p, int nrow, const int *rowptr, const int *co
                 {
                     int mx = 0;
                     for (int r = 0; r < 8; r++) mx = std::max(mx, cnt[w][r]);
-                    to.lp.push_back((unsigned char) ((mx + 3) / 4 * 4));
+                    to.lp.push_back((unsigned char) ((mx + 1) / 2 * 2));           // steps come in pairs (the kernel's half chunk)
                     to.items.insert(to.items.end(), wl[(size_t) w].begin(), wl[(size_t) w].end());
                     to.iptr.push_back((int) to.items.size());
                 }

@@ -233,7 +233,7 @@ void build_team2n(const PanelHost &p, int nrow, const int *rowptr, const int *co
 // (row, column) pair still is never multiplied with a B entry.  ~1.1 instructions per nonzero where the masked-row step of the
 // narrow kernels spends 57 per four panel entries = 7.7 per nonzero when an entry holds 1.84 of 8 rows (nlpkkt).
 // A round has 16 KiB of slices (rowdma = 2; 8 KiB with rowdma = 1): S = 8 G rowdma slots of 1024 / G bytes; wave w fetches slots
-// G rowdma w .. G rowdma (w + 1) - 1 with rowdma DMA instructions.  What a wave owns of a round: Lp steps (a multiple of 4, at most TEAM2R_LCAP: the scheduler closes a round before a
+// G rowdma w .. G rowdma (w + 1) - 1 with rowdma DMA instructions.  What a wave owns of a round: Lp steps (a multiple of 2, at most TEAM2R_LCAP: the scheduler closes a round before a
 // row would pass it), stored as a BLOCK of the wave's stream: [8 rows][Lp] values (doubles), [8 rows][Lp] offsets (uint16), and a
 // 64-byte HEADER = the wave's record of round r + 2 of the same team (zeros past the team's last round): the kernel issues the DMAs
 // of round r + 2 while it consumes round r, and finds what to fetch in the block that has just landed -- no load on its path.

@@ -57,8 +57,8 @@ static_assert(T2R_BLKB == 1024 && 5 * TEAM2R_LCAP + 4 <= 64 && 2 * t2r_lds(2) <=
 #define T2R_SD(SEL) " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:" #SEL "\n\t"
 #define T2R_FMA(ACC, V, BREG, K) "v_fmac_f64_dpp %[" #ACC "], %[" #V "], " BREG " row_newbcast:" #K " row_mask:0xf bank_mask:0xf\n\t"
 #define T2R_CHUNK(OFF, K0, K1, K2, K3, AX0, AY0, AX1, AY1, V0, V1, OA0, OA1, RS)                                                  \
-    asm volatile("ds_read_b64 v[88:89], %[oa0] offset:" #OFF "\n\t"                                                               \
-                 "ds_read_b64 v[90:91], %[oa1] offset:" #OFF "\n\t"                                                               \
+    asm volatile("ds_read2_b32 v[88:89], %[oa0] offset0:" #OFF " offset1:" #OFF "+1\n\t"                                            \
+                 "ds_read2_b32 v[90:91], %[oa1] offset0:" #OFF " offset1:" #OFF "+1\n\t"                                            \
                  "s_waitcnt lgkmcnt(1)\n\t"                                                                                        \
                  "v_add_u32_sdwa v92, %[rs], v88" T2R_SD(WORD_0) "v_add_u32_sdwa v93, %[rs], v88" T2R_SD(WORD_1)                    \
                  "v_add_u32_sdwa v94, %[rs], v89" T2R_SD(WORD_0) "v_add_u32_sdwa v95, %[rs], v89" T2R_SD(WORD_1)                    \
@@ -86,6 +86,27 @@ static_assert(T2R_BLKB == 1024 && 5 * TEAM2R_LCAP + 4 <= 64 && 2 * t2r_lds(2) <=
                  : "memory", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", \
                    "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", \
                    "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127")
+// ... and its half: two steps (Lp is a multiple of 2; OFF counts dwords of the offset rows, as in T2R_CHUNK)
+#define T2R_CHUNK2(OFF, K0, K1, AX0, AY0, AX1, AY1, V0, V1, OA0, OA1, RS)                                                          \
+    asm volatile("ds_read_b32 v88, %[oa0] offset:4*" #OFF "\n\t"                                                                    \
+                 "ds_read_b32 v90, %[oa1] offset:4*" #OFF "\n\t"                                                                    \
+                 "s_waitcnt lgkmcnt(1)\n\t"                                                                                        \
+                 "v_add_u32_sdwa v92, %[rs], v88" T2R_SD(WORD_0) "v_add_u32_sdwa v93, %[rs], v88" T2R_SD(WORD_1)                    \
+                 "ds_read_b128 v[96:99], v92\n\t"                                                                                  \
+                 "ds_read_b128 v[100:103], v93\n\t"                                                                                \
+                 "s_waitcnt lgkmcnt(2)\n\t"                                                                                        \
+                 "v_add_u32_sdwa v92, %[rs], v90" T2R_SD(WORD_0) "v_add_u32_sdwa v93, %[rs], v90" T2R_SD(WORD_1)                    \
+                 "ds_read_b128 v[112:115], v92\n\t"                                                                                \
+                 "ds_read_b128 v[116:119], v93\n\t"                                                                                \
+                 "s_waitcnt lgkmcnt(3)\n\t" T2R_FMA(ax0, v0, "v[96:97]", K0) T2R_FMA(ay0, v0, "v[98:99]", K0)                      \
+                 "s_waitcnt lgkmcnt(2)\n\t" T2R_FMA(ax0, v0, "v[100:101]", K1) T2R_FMA(ay0, v0, "v[102:103]", K1)                  \
+                 "s_waitcnt lgkmcnt(1)\n\t" T2R_FMA(ax1, v1, "v[112:113]", K0) T2R_FMA(ay1, v1, "v[114:115]", K0)                  \
+                 "s_waitcnt lgkmcnt(0)\n\t" T2R_FMA(ax1, v1, "v[116:117]", K1) T2R_FMA(ay1, v1, "v[118:119]", K1)                  \
+                 : [ax0] "+v"(AX0), [ay0] "+v"(AY0), [ax1] "+v"(AX1), [ay1] "+v"(AY1)                                               \
+                 : [v0] "v"(V0), [v1] "v"(V1), [oa0] "v"(OA0), [oa1] "v"(OA1), [rs] "v"(RS)                                         \
+                 : "memory", "v88", "v90", "v92", "v93", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v112", "v113",  \
+                   "v114", "v115", "v116", "v117", "v118", "v119")
+
 }  // namespace
 
 // Persistent workgroups: XCD x (= blockIdx & 7) owns entries [x cpx, (x + 1) cpx) of the launch grid (its teams, in processing
@@ -326,9 +347,13 @@ __global__ __launch_bounds__(512, 4) void spmm_team2r_kernel(const int ngrid, co
                              : [a0] "v"(vs + ((row0 * (uint32_t) Lp + (uint32_t) l16) << 3)), [a1] "v"(vs + ((row1 * (uint32_t) Lp + (uint32_t) l16) << 3))
                              : "memory");
                 const uint32_t oa0 = os + ((row0 * (uint32_t) Lp) << 1), oa1 = os + ((row1 * (uint32_t) Lp) << 1);
-                T2R_CHUNK(0, 0, 1, 2, 3, a[h0][0], a[h0][1], a[h0 + 1][0], a[h0 + 1][1], v0, v1, oa0, oa1, rs);
-                if (Lp > 4) T2R_CHUNK(8, 4, 5, 6, 7, a[h0][0], a[h0][1], a[h0 + 1][0], a[h0 + 1][1], v0, v1, oa0, oa1, rs);
-                if (Lp > 8) T2R_CHUNK(16, 8, 9, 10, 11, a[h0][0], a[h0][1], a[h0 + 1][0], a[h0 + 1][1], v0, v1, oa0, oa1, rs);
+                // steps four at a time, then a pair (Lp is even): OFF = dword of the offset row
+                if (Lp >= 4) T2R_CHUNK(0, 0, 1, 2, 3, a[h0][0], a[h0][1], a[h0 + 1][0], a[h0 + 1][1], v0, v1, oa0, oa1, rs);
+                if (Lp >= 8) T2R_CHUNK(2, 4, 5, 6, 7, a[h0][0], a[h0][1], a[h0 + 1][0], a[h0 + 1][1], v0, v1, oa0, oa1, rs);
+                if (Lp >= 12) T2R_CHUNK(4, 8, 9, 10, 11, a[h0][0], a[h0][1], a[h0 + 1][0], a[h0 + 1][1], v0, v1, oa0, oa1, rs);
+                if (Lp == 2) T2R_CHUNK2(0, 0, 1, a[h0][0], a[h0][1], a[h0 + 1][0], a[h0 + 1][1], v0, v1, oa0, oa1, rs);
+                else if (Lp == 6) T2R_CHUNK2(2, 4, 5, a[h0][0], a[h0][1], a[h0 + 1][0], a[h0 + 1][1], v0, v1, oa0, oa1, rs);
+                else if (Lp == 10) T2R_CHUNK2(4, 8, 9, a[h0][0], a[h0][1], a[h0 + 1][0], a[h0 + 1][1], v0, v1, oa0, oa1, rs);
             }
         }
         if (!early && cnr > 0) issue_next();

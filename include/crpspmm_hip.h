@@ -208,7 +208,7 @@ int crp_team2n_format_host(int nrow, const int *rowptr, const int *colidx, const
 /* Host-only: the streams variant 7 ("team2r-R8", csrc/team2r_kernel.hip: the row-owner team kernel for operands of 24 .. 64 fp64
  * columns) consumes.  Teams as variant 5.  A round has 8 G d ring slots of 1024 / G bytes (G = 4: n <= 32, 2: n <= 64; d = 2 row DMA
  * instructions per wave and round, or -- G + 256 passed as G -- d = 1: half rounds); wave w fetches slots G d w .. G d (w + 1) - 1.  Round r (from tinfo[2g + 1] on, tinfo[2g] rounds), wave w owns trec[(r * 8 + w) * 16 ..]: [0] Lp =
- * steps (multiple of 4, <= 12); [1] first 16-byte unit of its block inside the wave's stream, which starts at byte 16 * tvoff[8g + w]
+ * steps (multiple of 2, <= 12); [1] first 16-byte unit of its block inside the wave's stream, which starts at byte 16 * tvoff[8g + w]
  * of tval; [2 .. 2 + G d) the columns of the slots the wave fetches for this round.  A block = [8 rows][Lp] doubles, then
  * [8 rows][Lp] uint16, then a 64-byte header = the record of round r + 2 of the same team and wave (zeros past the last round):
  * step s of row i multiplies the value with the B row slice at that byte offset of the round's ring set (slot * 1024 / G);

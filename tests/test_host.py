@@ -862,7 +862,7 @@ def _replay_team2r(t, m, B, va):
             assert np.all(cols >= 0) and np.all(cols < B.shape[0])
             for w in range(8):
                 Lp, at16 = int(recs[w, 0]), int(recs[w, 1])
-                assert Lp % 4 == 0 and Lp <= 12
+                assert Lp % 2 == 0 and Lp <= 12
                 w0 = 2 * (int(t["tvoff"][8 * g + w]) + at16)              # first 8-byte word of the block
                 assert w0 + 10 * Lp + 8 <= 2 * int(t["tvoff"][8 * g + w + 1])
                 vals = t["tval"][w0:w0 + 8 * Lp].reshape(8, Lp)
