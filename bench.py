@@ -460,7 +460,7 @@ def measure(args, matrix, mtx, steps, lib, torch, dist, comm, dev, world, rank, 
     if distributed:
         # every native RCCL communicator this rank holds (world, grid row, grid column): ranks and creation time
         from crp_spmm_amd import comm as crp_comm
-        res["rccl"] = [{"ranks": c.device_ranks(), "create_s": c.device_create_seconds()} for c in list(crp_comm._live.values())
+        res["rccl"] = [{"ranks": c.device_ranks(), "create_s": c.device_create_seconds(), "issue": c.device_issue()} for c in list(crp_comm._live.values())
                        if hasattr(c, "device_ranks")]
     eng.free()
     del B, Cmat

@@ -125,6 +125,7 @@ SIGNATURES = {
     "crp_stream_wait_event": (_I, [_V, _V]),
     "crp_event_elapsed_ms": (_I, [_V, _V, C.POINTER(C.c_float)]),
     "crp_csr_dev_create": (_I, [_I, _I, c_int_p, c_int_p, c_dbl_p, C.POINTER(_V)]),
+    "crp_csr_dev_create_dv": (_I, [_I, _I, c_int_p, c_int_p, c_dbl_p, _V, c_int_p, C.POINTER(_V)]),
     "crp_csr_dev_destroy": (_I, [C.POINTER(_V)]),
     "crp_csr_dev_update_values": (_I, [_V, _V, _V]),
     "crp_csr_dev_set_rowmap": (_I, [_V, c_int_p, _I]),
@@ -147,6 +148,7 @@ SIGNATURES = {
     "crp_team2_waves": (_I, []),
     "crp_team2_panels_per_wave": (_I, []),
     "crp_team2_format_host_grid": (_I, [C.POINTER(c_int_p), c_int_p]),
+    "crp_team2_format_host_chains": (_I, [C.POINTER(c_int_p), c_int_p, C.POINTER(c_int_p), c_int_p]),
     "crp_team2_format_host_compact": (_I, []),
     "crp_team2_format_host": (_I, [_I, c_int_p, c_int_p, c_dbl_p, c_int_p, c_int_p, C.POINTER(c_int_p), C.POINTER(c_int_p),
                                    C.POINTER(c_int_p), C.POINTER(C.POINTER(C.c_uint)), C.POINTER(_LL),
@@ -171,6 +173,8 @@ SIGNATURES = {
     "crp_comm_self": (C.POINTER(CrpComm), []),
     # crp_engine.h
     "crp_rp_spmm_init": (None, [_I, _I, c_int_p, c_int_p, c_dbl_p, c_int_p, _I, C.POINTER(CrpComm), C.POINTER(_V)]),
+    "crp_rp_spmm_init_dv": (None, [_I, _I, c_int_p, c_int_p, c_dbl_p, _V, c_int_p, _I, C.POINTER(CrpComm), C.POINTER(_V)]),
+    "crp_rp_spmm_values_from_device": (_I, [_V]),
     "crp_rp_spmm_init_plan_only": (None, [_I, _I, c_int_p, c_int_p, c_dbl_p, c_int_p, _I, C.POINTER(CrpComm),
                                           C.POINTER(_V)]),
     "crp_rp_spmm_free": (None, [C.POINTER(_V)]),
@@ -187,6 +191,9 @@ SIGNATURES = {
     "crp_rccl_destroy": (_I, [C.POINTER(_V)]),
     "crp_rccl_nranks": (_I, [_V]),
     "crp_rccl_create_seconds": (C.c_double, [_V]),
+    "crp_rccl_is_blocking": (_I, [_V]),
+    "crp_rccl_issue_seconds": (C.c_double, [_V, C.POINTER(C.c_longlong)]),
+    "crp_rp_spmm_exchange_host_seconds": (C.c_double, [_V]),
     "crp_rccl_rank": (_I, [_V]),
     "crp_rccl_alltoallv_f64": (_I, [_V, _V, c_ll_p, c_ll_p, _V, c_ll_p, c_ll_p, _V]),
     "crp_rccl_allgatherv": (_I, [_V, _V, C.c_size_t, _V, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), _V]),
@@ -195,6 +202,7 @@ SIGNATURES = {
     "crp_rccl_comm_alltoallv_dev_f64": (None, [_V, _V, c_ll_p, c_ll_p, _V, c_ll_p, c_ll_p, _V]),
     "crp_rccl_comm_allgatherv_dev": (None, [_V, _V, C.c_size_t, _V, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), _V]),
     "crp_para2d_spmm_replicated_on_device": (_I, [_V]),
+    "crp_para2d_spmm_value_uploads": (_I, [_V]),
     "crp_rp_spmm_set_variant": (None, [_V, _I]),
     "crp_rp_spmm_kernel_info": (None, [_V, c_int_p, c_int_p, c_int_p]),
     "crp_rp_spmm_alg_bytes": (_LL, [_V]),

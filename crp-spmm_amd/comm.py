@@ -178,6 +178,16 @@ class TorchComm:
         """Wall time the creation of that communicator took on this rank, or None."""
         return float(L.load().crp_rccl_create_seconds(self._rccl)) if self._rccl else None
 
+    def device_issue(self):
+        """(host seconds inside the device collectives' calls so far, calls, blocking communicator?) or None: what issuing the
+        grouped sends / receives costs the host per exec (csrc/crp_rccl.cpp)."""
+        if not self._rccl:
+            return None
+        lib = L.load()
+        calls = C.c_longlong(0)
+        sec = float(lib.crp_rccl_issue_seconds(self._rccl, C.byref(calls)))
+        return {"host_s": sec, "calls": int(calls.value), "blocking": bool(lib.crp_rccl_is_blocking(self._rccl))}
+
     # ---- host control plane ---------------------------------------------------
     @_fatal_on_error
     def _alltoall_i32(self, ctx, send, recv, count):

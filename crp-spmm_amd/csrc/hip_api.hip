@@ -6,11 +6,13 @@
 #include <stdlib.h>
 #include <string.h>
 #include <new>
+#include <algorithm>
 #include <vector>
 #include "crpspmm_hip.h"
 #include "kernels.h"
 #include "panel_format.h"
 #include "locality.h"
+#include "knobs.h"
 
 // device copy of one row-panel format (panel_format.h)
 struct PanelDev
@@ -72,6 +74,11 @@ struct Team2Dev
     unsigned *gsync = nullptr;
     int gsync_tiles = 0, gsync_ngen = 0, wgs = 64;
     int nreal[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // chains (Team2Host::chain > 0): the streams are laid out for the persistent kernel (team2p_kernel.hip); nteam = chains
+    int chain = 0, nmember = 0;
+    int *cptr = nullptr, *cteam = nullptr, *trows = nullptr;
+    long long rows_epoch = -1;     // the row map trows was filled for
+    const int *rows_map = nullptr;
 };
 
 struct Team2NDev              // panel_format.h, Team2NHost: the narrow-operand team kernel's streams (variant 6)
@@ -326,6 +333,10 @@ static int ensure_team2(crp_csr_dev *A, hipStream_t stream, int pw)
     }
     t.tw = th.T / pw;
     t.pw = pw;
+    // Chains of teams for persistent workgroups (team2p_kernel.hip): CRPSPMM_T2_CHAIN = teams per chain at most; 0, the default =
+    // one workgroup per team (team2_kernel.hip).  Measured (profiles/r04_chains_ab.txt): chains are 2 - 8 % SLOWER on every
+    // stand-in -- the start-up they remove was hidden behind the CU's second workgroup, and hardware dispatch balances better.
+    th.chain = pw == 1 ? crp::knobs().t2_chain : 0;
     std::vector<int> colpos;                    // position of every row in the processing order (square, re-ordered matrices)
     if (!A->perm.empty())
     {
@@ -334,7 +345,9 @@ static int ensure_team2(crp_csr_dev *A, hipStream_t stream, int pw)
     }
     crp::build_team2(h, A->nrow, fmt_rowptr(A), fmt_colidx(A), &th, colpos.empty() ? nullptr : colpos.data());
     clk.lap("ensure_team2: build_team2");
-    t.nteam = th.nteam;
+    t.chain = th.chain;
+    t.nteam = th.chain > 0 ? (int) th.cptr.size() - 1 : th.nteam;
+    t.nmember = (int) th.cteam.size();
     t.entries = th.real_entries;
     t.lattice = th.lattice;
     auto up = [](void **dst, const void *src, size_t bytes, size_t pad) -> hipError_t {
@@ -355,6 +368,15 @@ static int ensure_team2(crp_csr_dev *A, hipStream_t stream, int pw)
     // the kernel requests 256 bytes per wave and round: up to four groups past a wave's last part
     if (e == hipSuccess) e = up((void **) &t.tval, th.tval.data(), sizeof(double) * th.tval.size(), 4096);
     if (e == hipSuccess) e = up((void **) &t.tmap, th.vmap.data(), sizeof(uint32_t) * th.vmap.size(), 4);
+    if (e == hipSuccess && th.chain > 0)
+    {
+        e = up((void **) &t.cptr, th.cptr.data(), sizeof(int) * th.cptr.size(), 4);
+        if (e == hipSuccess) e = up((void **) &t.cteam, th.cteam.data(), sizeof(int) * th.cteam.size(), 4);
+        // (+ one team's worth: the FLUSH of a chain's last team requests the rows "of the next team")
+        if (e == hipSuccess) e = hipMalloc((void **) &t.trows, sizeof(int) * ((size_t) th.cteam.size() + 1) * (size_t) t.tw * 8);
+        if (e == hipSuccess) e = hipMemset(t.trows, 0xFF, sizeof(int) * ((size_t) th.cteam.size() + 1) * (size_t) t.tw * 8);
+        t.rows_epoch = -1;
+    }
     t.wgs = th.wgs;
     {
         const int cpx = t.ngrid / 8;
@@ -379,6 +401,24 @@ static int ensure_team2(crp_csr_dev *A, hipStream_t stream, int pw)
     if (A->host_vals_stale && A->nnz > 0) CRP_TRY(crp::scatter_vals_f64(A->nnz, t.tmap, A->val, t.tval, stream));
     clk.lap("ensure_team2: upload");
     t.built = true;
+    return 0;
+}
+
+// The argument block of the team kernels from a built format; with chains the C rows of the chains' panels are (re)filled when the
+// row map they were filled for is not the one of this launch.
+static int team2_args(crp_csr_dev *A, Team2Dev &d, const int *rowmap, hipStream_t stream, crp::Team2Args *t)
+{
+    t->nteam = d.nteam; t->ngrid = d.ngrid; t->tw = d.tw; t->pw = d.pw; t->compact = d.compact; t->torder = d.torder; t->tpanel = d.tpanel;
+    t->tinfo = d.tinfo; t->tpro = d.tpro; t->trec = d.trec; t->tvoff = d.tvoff; t->tval = d.tval; t->tval32 = d.tval32;
+    t->gsync = d.gsync; t->gsync_tiles = d.gsync_tiles; t->gsync_ngen = d.gsync_ngen; t->wgs = d.wgs;
+    for (int x = 0; x < 8; x++) t->nreal[x] = d.nreal[x];
+    t->chain = d.chain; t->nmember = d.nmember; t->cptr = d.cptr; t->cteam = d.cteam; t->trows = d.trows;
+    if (d.chain > 0 && (d.rows_epoch != A->rowmap_epoch || d.rows_map != rowmap))
+    {
+        CRP_TRY(crp::team2p_fill_rows(*t, A->nrow, rowmap, stream));
+        d.rows_epoch = A->rowmap_epoch;
+        d.rows_map = rowmap;
+    }
     return 0;
 }
 
@@ -668,8 +708,39 @@ int crp_event_elapsed_ms(void *start, void *stop, float *ms)
 }
 
 // ---------------------------------------------------------------------------
+// dst_val[dst_rowptr[t] + k] = src_val[src_start[t] + k]: the values of selected rows of a matrix whose values already sit in
+// HBM (crp_csr_dev_create_dv); one wave per row
+__global__ void gather_row_vals_kernel(const int nrow, const int *__restrict__ dst_rowptr, const int *__restrict__ src_start,
+                                       const double *__restrict__ src_val, double *__restrict__ dst_val)
+{
+    const int lane = threadIdx.x & 63;
+    const long long wave0 = ((long long) blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwave = ((long long) gridDim.x * blockDim.x) >> 6;
+    for (long long t = wave0; t < nrow; t += nwave)
+    {
+        const int d0 = dst_rowptr[t], len = dst_rowptr[t + 1] - d0;
+        const long long s0 = src_start[t];
+        for (int k = lane; k < len; k += 64) dst_val[(long long) d0 + k] = src_val[s0 + k];
+    }
+}
+
+static int csr_dev_create_impl(int nrow, int ncol, const int *rowptr, const int *colidx, const double *val, const double *val_dev,
+                               const int *src_start, crp_csr_dev_p *out);
+
 int crp_csr_dev_create(int nrow, int ncol, const int *rowptr, const int *colidx, const double *val,
                        crp_csr_dev_p *out)
+{
+    return csr_dev_create_impl(nrow, ncol, rowptr, colidx, val, nullptr, nullptr, out);
+}
+
+int crp_csr_dev_create_dv(int nrow, int ncol, const int *rowptr, const int *colidx, const double *val_host, const double *val_dev,
+                          const int *src_start, crp_csr_dev_p *out)
+{
+    if (val_dev == NULL) return -1;
+    return csr_dev_create_impl(nrow, ncol, rowptr, colidx, val_host, val_dev, src_start, out);
+}
+
+static int csr_dev_create_impl(int nrow, int ncol, const int *rowptr, const int *colidx, const double *val, const double *val_dev,
+                               const int *src_start, crp_csr_dev_p *out)
 {
     if (out == NULL) return -1;
     *out = NULL;
@@ -689,7 +760,26 @@ int crp_csr_dev_create(int nrow, int ncol, const int *rowptr, const int *colidx,
     if (e == hipSuccess) e = hipMalloc((void **) &A->val, sizeof(double) * (size_t) (nnz > 0 ? nnz : 1));
     if (e == hipSuccess) e = hipMemcpy(A->rowptr, rowptr, sizeof(int) * ((size_t) nrow + 1), hipMemcpyHostToDevice);
     if (e == hipSuccess && nnz > 0) e = hipMemcpy(A->colidx, colidx, sizeof(int) * (size_t) nnz, hipMemcpyHostToDevice);
-    if (e == hipSuccess && nnz > 0) e = hipMemcpy(A->val, val, sizeof(double) * (size_t) nnz, hipMemcpyHostToDevice);
+    if (e == hipSuccess && nnz > 0 && val_dev == nullptr) e = hipMemcpy(A->val, val, sizeof(double) * (size_t) nnz, hipMemcpyHostToDevice);
+    if (e == hipSuccess && nnz > 0 && val_dev != nullptr)
+    {
+        // the values are in HBM already (a panel replicated between devices): no second trip over PCIe
+        if (src_start == nullptr) e = hipMemcpy(A->val, val_dev, sizeof(double) * (size_t) nnz, hipMemcpyDeviceToDevice);
+        else
+        {
+            int *d_start = nullptr;
+            e = hipMalloc((void **) &d_start, sizeof(int) * (size_t) (nrow > 0 ? nrow : 1));
+            if (e == hipSuccess && nrow > 0) e = hipMemcpy(d_start, src_start, sizeof(int) * (size_t) nrow, hipMemcpyHostToDevice);
+            if (e == hipSuccess && nrow > 0)
+            {
+                const int blocks = (int) std::min<long long>(((long long) nrow + 3) / 4, 65536);
+                hipLaunchKernelGGL(gather_row_vals_kernel, dim3(blocks), dim3(256), 0, 0, nrow, A->rowptr, d_start, val_dev, A->val);
+                e = hipGetLastError();
+                if (e == hipSuccess) e = hipDeviceSynchronize();
+            }
+            if (d_start) (void) hipFree(d_start);
+        }
+    }
     if (e != hipSuccess)
     {
         crp_csr_dev_p tmp = A;
@@ -837,6 +927,9 @@ int crp_csr_dev_destroy(crp_csr_dev_p *A_)
         if (t2->tmap) (void) hipFree(t2->tmap);
         if (t2->tval32) (void) hipFree(t2->tval32);
         if (t2->gsync) (void) hipFree(t2->gsync);
+        if (t2->cptr) (void) hipFree(t2->cptr);
+        if (t2->cteam) (void) hipFree(t2->cteam);
+        if (t2->trows) (void) hipFree(t2->trows);
     }
     for (Team2NDev *tnp : {&A->team2n[0], &A->team2n[1], &A->team2r[0], &A->team2r[1]})
     {
@@ -985,12 +1078,11 @@ int crp_spmm_csr_f64(crp_csr_dev_p A, int layout, int n, const double *B0, long 
         const int pw = team2_pw(n > 128 ? 2 : 1);
         const int rc = ensure_team2(A, (hipStream_t) stream, pw);
         if (rc != 0) return rc;
-        const Team2Dev &d = pw == 2 ? A->team2p : A->team2;
+        Team2Dev &d = pw == 2 ? A->team2p : A->team2;
         crp::Team2Args t;
-        t.nteam = d.nteam; t.ngrid = d.ngrid; t.tw = d.tw; t.pw = d.pw; t.compact = d.compact; t.torder = d.torder; t.tpanel = d.tpanel; t.tinfo = d.tinfo;
-        t.tpro = d.tpro; t.trec = d.trec; t.tvoff = d.tvoff; t.tval = d.tval; t.tval32 = nullptr;
-        t.gsync = d.gsync; t.gsync_tiles = d.gsync_tiles; t.gsync_ngen = d.gsync_ngen; t.wgs = d.wgs;
-        for (int x = 0; x < 8; x++) t.nreal[x] = d.nreal[x];
+        const int ra = team2_args(A, d, a.rowmap, (hipStream_t) stream, &t);
+        if (ra != 0) return ra;
+        if (d.chain > 0) return (int) crp::spmm_rm_f64_team2p(t, a, (hipStream_t) stream);
         return (int) crp::spmm_rm_f64_team2(t, a, (hipStream_t) stream);
     }
     if (v == 6)
@@ -1098,10 +1190,9 @@ int crp_spmm_csr_f32(crp_csr_dev_p A, int n, const float *B0, long long ldB0, co
     }
     if (A->rowmap_fmt != nullptr) a.rowmap = A->rowmap_fmt;
     crp::Team2Args t;
-    t.nteam = d.nteam; t.ngrid = d.ngrid; t.tw = d.tw; t.pw = d.pw; t.compact = d.compact; t.torder = d.torder; t.tpanel = d.tpanel; t.tinfo = d.tinfo;
-    t.tpro = d.tpro; t.trec = d.trec; t.tvoff = d.tvoff; t.tval = d.tval; t.tval32 = d.tval32;
-    t.gsync = d.gsync; t.gsync_tiles = d.gsync_tiles; t.gsync_ngen = d.gsync_ngen; t.wgs = d.wgs;
-    for (int x = 0; x < 8; x++) t.nreal[x] = d.nreal[x];
+    const int ra = team2_args(A, d, a.rowmap, (hipStream_t) stream, &t);
+    if (ra != 0) return ra;
+    if (d.chain > 0) return (int) crp::spmm_rm_f32_team2p(t, a, (hipStream_t) stream);
     return (int) crp::spmm_rm_f32_team2(t, a, (hipStream_t) stream);
 }
 
@@ -1173,6 +1264,18 @@ int crp_team_format_host(int nrow, const int *rowptr, const int *colidx, const d
 int crp_team2_panels_per_wave(void) { return getenv("CRPSPMM_TEAM2_FORMAT_PW") && atoi(getenv("CRPSPMM_TEAM2_FORMAT_PW")) == 2 && team2_waves() == 8 ? 2 : 1; }
 int crp_team2_waves(void) { return team2_waves(); }
 
+static std::vector<int> g_last_cptr, g_last_cteam;   // chains of the last crp_team2_format_host() (empty: one workgroup per team)
+int crp_team2_format_host_chains(int **cptr, int *nchain, int **cteam, int *nmember)
+{
+    if (cptr == NULL || nchain == NULL || cteam == NULL || nmember == NULL) return -1;
+    *nchain = g_last_cptr.empty() ? 0 : (int) g_last_cptr.size() - 1;
+    *nmember = (int) g_last_cteam.size();
+    *cptr = (int *) malloc(sizeof(int) * (g_last_cptr.size() + 1));
+    *cteam = (int *) malloc(sizeof(int) * (g_last_cteam.size() + 1));
+    if (!g_last_cptr.empty()) memcpy(*cptr, g_last_cptr.data(), sizeof(int) * g_last_cptr.size());
+    if (!g_last_cteam.empty()) memcpy(*cteam, g_last_cteam.data(), sizeof(int) * g_last_cteam.size());
+    return 0;
+}
 static std::vector<int> g_last_tgrid;       // launch grid of the last crp_team2_format_host() (planning / test helper)
 static int g_last_compact = 1;              // ... and whether its value blocks are compact
 int crp_team2_format_host_compact(void) { return g_last_compact; }
@@ -1269,8 +1372,12 @@ int crp_team2_format_host(int nrow, const int *rowptr, const int *colidx, const 
     th.T = pw == 2 ? 16 : team2_waves();
     th.P = pw;
     th.compact = getenv("CRPSPMM_TEAM2_COMPACT") ? atoi(getenv("CRPSPMM_TEAM2_COMPACT")) != 0 : h.fill() < 0.4;
+    // (the test helper reads CRPSPMM_T2_CHAIN per call: the product reads it once, crp::knobs())
+    th.chain = pw == 1 ? (getenv("CRPSPMM_T2_CHAIN") ? atoi(getenv("CRPSPMM_T2_CHAIN")) : crp::knobs().t2_chain) : 0;
     crp::build_team2(h, nrow, rowptr, colidx, &th);
     g_last_compact = th.compact ? 1 : 0;
+    g_last_cptr = th.cptr;
+    g_last_cteam = th.cteam;
     clk.lap("crp_team2_format_host: build_team2");
     g_last_tgrid = th.tgrid;
     *nteam = th.nteam;

@@ -92,6 +92,12 @@ struct Team2Args          // panel_format.h, Team2Host
     int             gsync_ngen;    // generations per run it covers
     int             wgs;           // teams of a generation (workgroups resident on an XCD)
     int             nreal[8];      // real teams of every run (the -1 entries sit at its end)
+    // chains (Team2Host::chain > 0; team2p_kernel.hip): torder / tinfo / tpro / tvoff are per chain, nteam = chains
+    int             chain = 0;
+    int             nmember = 0;   // entries of cteam
+    const int      *cptr = nullptr;    // chains + 1
+    const int      *cteam = nullptr;   // the teams of the chains
+    int            *trows = nullptr;   // nmember * tw * 8: C rows (team2p_fill_rows)
 };
 
 struct Team2NArgs         // panel_format.h, Team2NHost
@@ -135,6 +141,11 @@ bool spmm_team2_applicable(const SpmmArgs &a);
 hipError_t spmm_rm_f64_team2(const Team2Args &t, const SpmmArgs &a, hipStream_t s);
 bool spmm_team2_applicable_f32(const SpmmArgsF32 &a);
 hipError_t spmm_rm_f32_team2(const Team2Args &t, const SpmmArgsF32 &a, hipStream_t s);
+
+// team2p_kernel.hip: the same streams laid out in chains, persistent workgroups
+hipError_t spmm_rm_f64_team2p(const Team2Args &t, const SpmmArgs &a, hipStream_t s);
+hipError_t spmm_rm_f32_team2p(const Team2Args &t, const SpmmArgsF32 &a, hipStream_t s);
+hipError_t team2p_fill_rows(const Team2Args &t, int nrow, const int *rowmap, hipStream_t s);   // the C rows of the chains' panels: once per row map
 
 // spmm_f32.hip: CSR row-group kernel of the fp32 path (any width, both sources)
 hipError_t spmm_rm_f32_rowgroup(const SpmmArgsF32 &a, hipStream_t s);

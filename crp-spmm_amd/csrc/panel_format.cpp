@@ -1295,6 +1295,9 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
         // (round, wave) was 126 M heap allocations on the nlpkkt240-size matrix)
         std::vector<Part> ownp;
         std::vector<unsigned char> ownc;
+        // chains only: per round, 1 = the last round of a team of the chain (FLUSH); the team every round belongs to
+        std::vector<unsigned char> rfl;
+        std::vector<int> rmem;
     };
     std::vector<TeamOut> res((size_t) nteam);
     // real union entries of team g
@@ -1692,11 +1695,87 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
     }
 
     clk.lap("build_team2: rounds (phase sort, list scheduler)");
+    // ---- chains (panel_format.h): the teams of every XCD's run are dealt to chains of at most CH teams.  A run is cut into
+    // super-generations of about WGS * CH teams; inside one, chain j takes teams j, j + nch, j + 2 nch ... -- so the nch <= WGS
+    // workgroups that work through a super-generation are on neighbouring teams of the order at any time, as consecutive
+    // workgroups of a one-team-per-workgroup launch are.  From here on a UNIT is a chain (or a team, without chains).
+    const int CH = (out->chain > 0 && P == 1) ? out->chain : 0;
+    out->chain = CH;
+    out->cptr.clear();
+    out->cteam.clear();
+    std::vector<TeamOut> cres;
+    std::vector<int> ccut(9, 0);                                        // chains of run q: [ccut[q], ccut[q + 1])
+    if (CH > 0)
+    {
+        out->cptr.push_back(0);
+        for (int q = 0; q < 8; q++)
+        {
+            const int t0 = cut[(size_t) q], tx = cut[(size_t) q + 1] - cut[(size_t) q];
+            const int nsg = (int) (((long long) tx + (long long) WGS * CH - 1) / ((long long) WGS * CH));
+            for (int sg = 0; sg < nsg; sg++)
+            {
+                // (cuts on multiples of a generation: under the bisection order a generation is a leaf of the team graph)
+                auto sgcut = [&](int k) { return k >= nsg ? tx : (int) std::min<long long>(tx, ((long long) tx * k / nsg + WGS / 2) / WGS * WGS); };
+                const int b = sgcut(sg), e = sgcut(sg + 1);
+                if (e <= b) continue;
+                const int nch = std::min(WGS, e - b);
+                for (int j = 0; j < nch; j++)
+                {
+                    for (int i = b + j; i < e; i += nch) out->cteam.push_back(out->torder[(size_t) (t0 + i)]);
+                    out->cptr.push_back((int) out->cteam.size());
+                }
+            }
+            ccut[(size_t) q + 1] = (int) out->cptr.size() - 1;
+        }
+        // a column every empty slot of an empty team may fetch (a valid row: the matrix has nonzeros when this format is used)
+        int global_any = 0;
+        for (int g = 0; g < nteam; g++)
+            if (res[(size_t) g].filled > 0) { global_any = res[(size_t) g].anycol; break; }
+        const int nchain = (int) out->cptr.size() - 1;
+        cres.resize((size_t) nchain);
+        parallel_chunks(nchain, 16, [&](long long b, long long e, int) {
+            for (long long c = b; c < e; c++)
+            {
+                TeamOut &co = cres[(size_t) c];
+                co.anycol = global_any;
+                bool have_any = false;
+                for (int k = out->cptr[(size_t) c]; k < out->cptr[(size_t) c + 1]; k++)
+                {
+                    const int g = out->cteam[(size_t) k];
+                    TeamOut &to = res[(size_t) g];
+                    if (to.nr == 0)
+                    {
+                        // (no entries: one round of empty slots, so that the rows of C are cleared at its FLUSH)
+                        to.col.assign((size_t) W, TEAM2_NOCOL);
+                        to.ownp.assign((size_t) W * CAP, Part());
+                        to.ownc.assign((size_t) W, 0);
+                        to.nr = 1;
+                    }
+                    if (!have_any && to.filled > 0) { co.anycol = to.anycol; have_any = true; }
+                    co.col.insert(co.col.end(), to.col.begin(), to.col.begin() + (size_t) to.nr * W);
+                    co.ownp.insert(co.ownp.end(), to.ownp.begin(), to.ownp.begin() + (size_t) to.nr * W * CAP);
+                    co.ownc.insert(co.ownc.end(), to.ownc.begin(), to.ownc.begin() + (size_t) to.nr * W);
+                    co.nr += to.nr;
+                    co.filled += to.filled;
+                    co.nparts += to.nparts;
+                    co.rfl.resize((size_t) co.nr, 0);
+                    co.rfl[(size_t) co.nr - 1] = 1;
+                    co.rmem.resize((size_t) co.nr, g);
+                    std::vector<int>().swap(to.col);
+                    std::vector<Part>().swap(to.ownp);
+                    std::vector<unsigned char>().swap(to.ownc);
+                }
+            }
+        });
+        clk.lap("build_team2: chains");
+    }
+    const int nunit = CH > 0 ? (int) cres.size() : nteam;
+    std::vector<TeamOut> &ures = CH > 0 ? cres : res;
     // ---- layout: record blocks, value streams
-    out->tinfo.assign((size_t) nteam * 4, 0);
-    out->tpro.assign((size_t) nteam * D * W * 2, 0);
-    out->tvoff.assign((size_t) nteam * W + 1, 0);
-    std::vector<int> blk0((size_t) nteam + 1, 0);
+    out->tinfo.assign((size_t) nunit * 4, 0);
+    out->tpro.assign((size_t) nunit * D * W * 2, 0);
+    out->tvoff.assign((size_t) nunit * W + 1, 0);
+    std::vector<int> blk0((size_t) nunit + 1, 0);
     long long run = 0;
     out->real_entries = out->slots = out->parts = 0;
     // value units (TEAM2_VUNIT values) of a round of a wave: its parts' rows, padded
@@ -1707,11 +1786,11 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
         return (nv + TEAM2_VUNIT - 1) / TEAM2_VUNIT;
     };
     {
-        std::vector<long long> wunits((size_t) nteam * W, 0);
-        parallel_chunks(nteam, 256, [&](long long b, long long e, int) {
+        std::vector<long long> wunits((size_t) nunit * W, 0);
+        parallel_chunks(nunit, 256, [&](long long b, long long e, int) {
             for (long long g = b; g < e; g++)
             {
-                const TeamOut &to = res[(size_t) g];
+                const TeamOut &to = ures[(size_t) g];
                 for (int w = 0; w < W; w++)
                 {
                     long long u = 0;
@@ -1720,9 +1799,9 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
                 }
             }
         });
-        for (int g = 0; g < nteam; g++)
+        for (int g = 0; g < nunit; g++)
         {
-            const TeamOut &to = res[(size_t) g];
+            const TeamOut &to = ures[(size_t) g];
             blk0[(size_t) g + 1] = blk0[(size_t) g] + (to.nr + 7) / 8;
             out->tinfo[(size_t) g * 4] = to.nr;
             out->tinfo[(size_t) g * 4 + 1] = blk0[(size_t) g];
@@ -1738,9 +1817,19 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
             }
         }
     }
-    out->tvoff[(size_t) nteam * W] = run;
+    out->tvoff[(size_t) nunit * W] = run;
     out->nvalues = run * TEAM2_VUNIT;
     // launch grid: run x of tgrid = what XCD x processes, in order (the cuts computed above)
+    if (CH > 0)
+    {
+        // (chains: run x = the chains of XCD x, super-generation after super-generation)
+        int cpx = 1;
+        for (int q = 0; q < 8; q++) cpx = std::max(cpx, ccut[(size_t) q + 1] - ccut[(size_t) q]);
+        out->tgrid.assign((size_t) cpx * 8, -1);
+        for (int q = 0; q < 8; q++)
+            for (int i = ccut[(size_t) q]; i < ccut[(size_t) q + 1]; i++) out->tgrid[(size_t) q * cpx + (size_t) (i - ccut[(size_t) q])] = i;
+    }
+    else
     {
         int cpx = 1;
         for (int q = 0; q < 8; q++) cpx = std::max(cpx, cut[(size_t) q + 1] - cut[(size_t) q]);
@@ -1748,15 +1837,15 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
         for (int q = 0; q < 8; q++)
             for (int i = cut[(size_t) q]; i < cut[(size_t) q + 1]; i++) out->tgrid[(size_t) q * cpx + (size_t) (i - cut[(size_t) q])] = out->torder[(size_t) i];
     }
-    parallel_fill(out->trec, (size_t) blk0[(size_t) nteam] * blkw + blkw, 0u);
+    parallel_fill(out->trec, (size_t) blk0[(size_t) nunit] * blkw + blkw, 0u);
     parallel_fill(out->tval, (size_t) run * TEAM2_VUNIT, 0.0);
     // vmap through the panel format's slot map: pmap[nz] = q * 8 + row of the panel format
     big_vector<uint32_t> slot_of;                                          // panel-format value slot -> tval slot
     slot_of.resize(p.pcol.size() * 8);          // (only the (entry, row) pairs that exist are written below and read through pmap)
-    parallel_chunks(nteam, 32, [&](long long b, long long e, int) {
+    parallel_chunks(nunit, 32, [&](long long b, long long e, int) {
         for (long long g = b; g < e; g++)
         {
-            const TeamOut &to = res[(size_t) g];
+            const TeamOut &to = ures[(size_t) g];
             for (int w = 0; w < W; w++)
             {
                 // value units of every round of this wave (prefix), then the records
@@ -1821,6 +1910,24 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
                     if (r + D - 1 >= to.nr) rec[0] |= 1u << (fbase + 1);                           // TAIL: fewer than D-1 younger rounds in flight
                     if (r == to.nr - 1) rec[0] |= 1u << (fbase + 2);                               // LAST
                     if (w == 0 && (r & 7) == 0 && (r >> 3) + 1 < (to.nr + 7) / 8) rec[0] |= 1u << (fbase + 3);   // RECS: fetch the next record block
+                    if (CH > 0)
+                    {
+                        if (to.rfl[(size_t) r]) rec[0] |= 1u << (fbase + 4);                     // FLUSH: the last round of a team of the chain
+                        // the rounds behind a FLUSH have the wave's C stores in their vmcnt queue: exactly 8 NV of them (+ the load of
+                        // the next panel's rows) when the panel had its 8 rows -- POSTFLUSH --, an unknown number otherwise, or when
+                        // two teams ended within D rounds: TAIL (wait for everything)
+                        int nfl = 0;
+                        bool exact = true;
+                        for (int f = std::max(0, r - D); f < r; f++)
+                            if (to.rfl[(size_t) f])
+                            {
+                                nfl++;
+                                const int pnl = out->tpanel[(size_t) to.rmem[(size_t) f] * W + (size_t) w];
+                                if (pnl < 0 || (long long) pnl * 8 + 8 > (long long) nrow) exact = false;
+                            }
+                        if (nfl == 1 && exact) rec[0] |= 1u << 31;
+                        else if (nfl > 0) rec[0] |= 1u << (fbase + 1);
+                    }
                 }
                 for (int d = 0; d < D; d++)
                 {
@@ -1839,13 +1946,15 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
     });
     clk.lap("build_team2: value-update map");
     // (hundreds of thousands of small vectors: released by all threads, not by the one that leaves the function)
-    parallel_chunks(nteam, 1024, [&](long long b, long long e, int) {
+    parallel_chunks(nunit, 1024, [&](long long b, long long e, int) {
         for (long long g = b; g < e; g++)
         {
-            TeamOut &to = res[(size_t) g];
+            TeamOut &to = ures[(size_t) g];
             std::vector<int>().swap(to.col);
             std::vector<Part>().swap(to.ownp);
             std::vector<unsigned char>().swap(to.ownc);
+            std::vector<unsigned char>().swap(to.rfl);
+            std::vector<int>().swap(to.rmem);
         }
     });
     clk.lap("build_team2: release");

@@ -144,8 +144,8 @@ void apply_team_schedule(PanelHost *p, const TeamHost &t);
 // (W = 8; W = 16 in brackets):
 //   word 0 : bits 0-2 = number of parts c (0..4); bits 4+3i .. [4+4i ..] = ring slot of part i; flags from bit 16 [20]:
 //            ISSUE (r + D < rounds), TAIL (r + D - 1 >= rounds), LAST round, RECS (wave 0, r % 8 == 0 and a further record
-//            block exists: fetch it now), one spare; bits 21-26 [25-30] = value position of part 0; bits 27 + i = bank (panel of
-//            the wave, P = 2) of part i
+//            block exists: fetch it now), FLUSH (chains, below); bits 21-26 [25-30] = value position of part 0; bits 27 + i = bank
+//            (panel of the wave, P = 2) of part i; bit 31 = POSTFLUSH (chains)
 //   word 1 : bits 6i .. 6i+5 = range of part i as first * 8 + len - 1; bits 24-29 = value position of part 1;
 //            bits 30-31 = size class q of the value block of round r + TEAM2_D (at most 8 (q + 1) values)
 //   word 2 : bits 0-19 = offset, inside the wave's value stream and in units of TEAM2_VUNIT values, of the block of
@@ -184,6 +184,17 @@ struct Team2Host
     bool absolute = false;           // rounds are generation-wide absolute rounds (build_team2): the kernel's generation barrier applies
     int wgs = 64;                    // teams of a generation: the workgroups resident on an XCD (T = 16: 32)
     long long nvalues = 0;           // values in tval (compact streams, blocks padded to TEAM2_VUNIT)
+    // CHAINS (chain > 0, set before build_team2; P = 1 only): what a PERSISTENT workgroup of csrc/team2p_kernel.hip works through.
+    // A chain is up to `chain` teams of one XCD's run (strided: the resident workgroups of the XCD are on neighbouring teams at
+    // any time); its rounds are the rounds of its teams one after the other in ONE pipeline -- the first rounds of the next team
+    // are in flight during the last rounds of this one.  The last round of every team of a chain carries the FLUSH flag (the wave
+    // stores its panel's C rows, clears its accumulators and turns to its panel of the next team); the three rounds after a
+    // FLUSH carry POSTFLUSH when the wave's panel had all of its 8 rows (the C stores then count exactly 8 NV in the wave's
+    // vmcnt queue) and TAIL otherwise.  A team without entries is given one empty round, so that its rows of C are written.
+    // With chains tinfo / tpro / tvoff / tgrid are PER CHAIN (cptr.size() - 1 of them), records and value streams are laid out
+    // chain by chain; tpanel / torder stay per team.
+    int chain = 0;
+    std::vector<int>       cptr, cteam;   // chain c = teams cteam[cptr[c] .. cptr[c + 1])
     long long real_entries = 0;      // union entries (filled slots)
     long long slots = 0;             // slots including the empty ones of partly filled rounds
     long long parts = 0;

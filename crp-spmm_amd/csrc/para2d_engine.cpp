@@ -24,6 +24,7 @@ struct crp_para2d_spmm
     crp_comm_t   *comm_col = nullptr;   // owned
     size_t rA_cost = 0;
     double t_init = 0.0, t_ag_A = 0.0;
+    int    value_uploads = 1;              // times the panel's values went host -> device (0: filled from the device all-gather)
     bool   replicated_on_device = false;   // the panel's colidx / val were all-gathered between device buffers
 };
 
@@ -52,6 +53,7 @@ static void para2d_init_common(crp_comm_t *comm, int pm, int pn, const int *A0_r
     const int p_nrow  = A0_rowptr[(pi + 1) * pn] - p_srow;
     std::vector<int>    p_rowptr((size_t) p_nrow + 1, 0), p_colidx;
     std::vector<double> p_val;
+    void *panel_val_dev = NULL;                    // the panel's values in HBM, when the replication left them there
     if (pn > 1)
     {
         std::vector<size_t> cnt(pn), dsp(pn);
@@ -90,9 +92,8 @@ static void para2d_init_common(crp_comm_t *comm, int pm, int pn, const int *A0_r
             // other whatever streams they are given, so no overlap between them is claimed --, and the panel comes back
             // through pinned memory: the plan is built on the host from the column indices, and the values are a public
             // host field of the engine (struct rowpara_spmm::A_val, /root/reference/src/rowpara_spmm.h:8-40), so the copy
-            // down is owed to the API.  What could still be saved is the second upload of the values by
-            // crp_csr_dev_create (8 bytes per nonzero over PCIe: 2.3 GB, about 50 ms, for an nlpkkt240 panel of a 2 x 4
-            // grid, against the seconds of the format build that follows); not done.
+            // down is owed to the API.  The gathered VALUES stay in HBM until the 1D engine has been built: its device
+            // matrices are filled from them (crp_rp_spmm_init_dv), not uploaded a second time.
             void *s_i = NULL, *s_v = NULL, *d_ci = NULL, *d_va = NULL, *d_ci_all = NULL, *d_va_all = NULL, *h_ci = NULL, *h_va = NULL;
             int rc = crp_stream_create(&s_i);
             if (rc == 0) rc = crp_stream_create(&s_v);
@@ -120,7 +121,8 @@ static void para2d_init_common(crp_comm_t *comm, int pm, int pn, const int *A0_r
             memcpy(p_colidx.data(), h_ci, sizeof(int) * (size_t) p_nnz);
             memcpy(p_val.data(), h_va, sizeof(double) * (size_t) p_nnz);
             crp_host_free(h_ci); crp_host_free(h_va);
-            crp_dev_free(d_ci_all); crp_dev_free(d_va_all);
+            crp_dev_free(d_ci_all);
+            panel_val_dev = d_va_all;              // (freed below, after crp_rp_spmm_init_dv)
             crp_stream_destroy(s_i); crp_stream_destroy(s_v);
             e->replicated_on_device = true;
         }
@@ -157,9 +159,16 @@ static void para2d_init_common(crp_comm_t *comm, int pm, int pn, const int *A0_r
     if (plan_only)
         crp_rp_spmm_init_plan_only(p_srow, p_nrow, p_rowptr.data(), p_colidx.data(), p_val.data(), B_rowptr, n_loc,
                                    e->comm_col, &e->rp);
+    else if (panel_val_dev != NULL)
+    {
+        crp_rp_spmm_init_dv(p_srow, p_nrow, p_rowptr.data(), p_colidx.data(), p_val.data(), (const double *) panel_val_dev, B_rowptr, n_loc,
+                            e->comm_col, &e->rp);
+        e->value_uploads = 0;
+    }
     else
         crp_rp_spmm_init(p_srow, p_nrow, p_rowptr.data(), p_colidx.data(), p_val.data(), B_rowptr, n_loc,
                          e->comm_col, &e->rp);
+    if (panel_val_dev != NULL) crp_dev_free(panel_val_dev);
     e->t_init += get_wtime_sec() - t0;
     comm_row->free(comm_row);
     *out = e;
@@ -203,6 +212,7 @@ void crp_para2d_spmm_exec_ex(crp_para2d_spmm_p e, int BC_layout, const double *B
 }
 
 int crp_para2d_spmm_replicated_on_device(crp_para2d_spmm_p e) { return (e && e->replicated_on_device) ? 1 : 0; }
+int crp_para2d_spmm_value_uploads(crp_para2d_spmm_p e) { return e ? e->value_uploads : -1; }
 
 void crp_para2d_spmm_print_stat(crp_para2d_spmm_p e)
 {

@@ -34,6 +34,8 @@ struct crp_rp_spmm
     size_t rB_recv_size = 0;
     int    n_exec = 0;
     double t_init = 0, t_pack = 0, t_a2a = 0, t_unpack = 0, t_spmm = 0, t_exec = 0;
+    bool vals_from_device = false;   // the device matrices took their values from a device copy (no second upload)
+    double t_a2a_host = 0;           // host time inside the exchange CALL (issuing the sends / receives), whatever the timing mode
     crp_comm_t *comm = nullptr;
 
     // ---- device side
@@ -211,7 +213,9 @@ static void build_plan(crp_rp_spmm *e, int A_nrow, const int *A_rowptr, const in
 
 // Upload A: whole, or split by rows into interior / boundary parts when an exchange exists and
 // both parts are worth a launch (CRPSPMM_OVERLAP=0 keeps the single product).
-static void build_device_matrices(crp_rp_spmm *e)
+// A_val_dev (optional): the values of the rank's panel, in the panel's order, already in device memory (para2d_engine.cpp: the
+// device all-gather of the panel) -- the device matrices then take their values from there, not from a second upload.
+static void build_device_matrices(crp_rp_spmm *e, const double *A_val_dev)
 {
     const int m = e->A_nrow;
     int overlap = 1;
@@ -229,16 +233,20 @@ static void build_device_matrices(crp_rp_spmm *e)
     // a part smaller than 1/16 of the rows does not pay for a second launch
     if (rows_int.size() < (size_t) m / 16 || rows_bnd.empty())
     {
-        HIP_OK(crp_csr_dev_create(m, e->loc_B_nrow, e->A_rowptr.data(), e->dev_colidx_host.data(), e->A_val.data(), &e->A_dev));
+        if (A_val_dev != nullptr && !e->A_val.empty())
+            HIP_OK(crp_csr_dev_create_dv(m, e->loc_B_nrow, e->A_rowptr.data(), e->dev_colidx_host.data(), e->A_val.data(), A_val_dev, nullptr, &e->A_dev));
+        else
+            HIP_OK(crp_csr_dev_create(m, e->loc_B_nrow, e->A_rowptr.data(), e->dev_colidx_host.data(), e->A_val.data(), &e->A_dev));
         return;
     }
     auto make = [&](const std::vector<int> &rows, std::vector<long long> &src, crp_csr_dev_p *out) {
-        std::vector<int> rp(rows.size() + 1, 0), ci;
+        std::vector<int> rp(rows.size() + 1, 0), ci, start(rows.size(), 0);
         std::vector<double> va;
         src.clear();
         for (size_t t = 0; t < rows.size(); t++)
         {
             const int i = rows[t];
+            start[t] = e->A_rowptr[i];
             for (int p = e->A_rowptr[i]; p < e->A_rowptr[i + 1]; p++)
             {
                 ci.push_back(e->dev_colidx_host[p]);
@@ -247,8 +255,12 @@ static void build_device_matrices(crp_rp_spmm *e)
             }
             rp[t + 1] = (int) ci.size();
         }
+        const bool have = !ci.empty();
         if (ci.empty()) { ci.push_back(0); va.push_back(0.0); }
-        HIP_OK(crp_csr_dev_create((int) rows.size(), e->loc_B_nrow, rp.data(), ci.data(), va.data(), out));
+        if (A_val_dev != nullptr && have)
+            HIP_OK(crp_csr_dev_create_dv((int) rows.size(), e->loc_B_nrow, rp.data(), ci.data(), va.data(), A_val_dev, start.data(), out));
+        else
+            HIP_OK(crp_csr_dev_create((int) rows.size(), e->loc_B_nrow, rp.data(), ci.data(), va.data(), out));
         HIP_OK(crp_csr_dev_set_rowmap(*out, rows.data(), m));
     };
     make(rows_int, e->int_src, &e->A_int);
@@ -260,7 +272,7 @@ static void build_device_matrices(crp_rp_spmm *e)
 
 static void rp_init_common(int A_nrow, const int *A_rowptr, const int *A_colidx, const double *A_val,
                            const int *B_row_displs, int glb_n, crp_comm_t *comm, crp_rp_spmm_p *out,
-                           bool plan_only)
+                           bool plan_only, const double *A_val_dev = nullptr)
 {
     ASSERT_PRINTF(out != NULL && comm != NULL && A_rowptr != NULL && B_row_displs != NULL && A_nrow >= 0 && glb_n >= 0,
                   "invalid arguments to rp_spmm_init\n");
@@ -270,7 +282,8 @@ static void rp_init_common(int A_nrow, const int *A_rowptr, const int *A_colidx,
     build_plan(e, A_nrow, A_rowptr, A_colidx, A_val, B_row_displs, glb_n, comm);
     if (!plan_only)
     {
-        build_device_matrices(e);
+        build_device_matrices(e, A_val_dev);
+        e->vals_from_device = (A_val_dev != nullptr);
         HIP_OK(crp_stream_create(&e->stream));
         void *p = NULL;
         if (e->n_send_rows > 0)
@@ -300,6 +313,15 @@ void crp_rp_spmm_init(int A_srow, int A_nrow, const int *A_rowptr, const int *A_
     (void) A_srow;   // never read by the reference either (src/rowpara_spmm.c:20-24)
     rp_init_common(A_nrow, A_rowptr, A_colidx, A_val, B_row_displs, glb_n, comm, rp_spmm, false);
 }
+
+void crp_rp_spmm_init_dv(int A_srow, int A_nrow, const int *A_rowptr, const int *A_colidx, const double *A_val,
+                         const double *A_val_dev, const int *B_row_displs, int glb_n, crp_comm_t *comm, crp_rp_spmm_p *rp_spmm)
+{
+    (void) A_srow;
+    rp_init_common(A_nrow, A_rowptr, A_colidx, A_val, B_row_displs, glb_n, comm, rp_spmm, false, A_val_dev);
+}
+
+int crp_rp_spmm_values_from_device(crp_rp_spmm_p e) { return (e && e->vals_from_device) ? 1 : 0; }
 
 void crp_rp_spmm_init_plan_only(int A_srow, int A_nrow, const int *A_rowptr, const int *A_colidx,
                                 const double *A_val, const int *B_row_displs, int glb_n, crp_comm_t *comm,
@@ -418,21 +440,32 @@ void crp_rp_spmm_exec_ex(crp_rp_spmm_p e, int BC_layout, const double *B, long l
     const bool split = (e->A_int != nullptr);
     if (split && !timing)
     {
-        // the exchange runs on its own stream beside the interior rows' product
+        // The exchange runs on its own stream beside the interior rows' product.  The product is ENQUEUED FIRST: it does not
+        // depend on the exchange, and issuing a group of sends / receives can hold the host for a while (a non-blocking RCCL
+        // communicator is polled until the group is on the stream) -- with the exchange first, the whole interior product
+        // (0.06 - 0.2 ms per GPU at pwtk size) could have passed before its launch was even issued.
         HIP_OK(crp_event_record(e->ev_packed, s));
-        HIP_OK(crp_stream_wait_event(e->xstream, e->ev_packed));
-        e->comm->alltoallv_dev_f64(e->comm->ctx, e->sendbuf_dev, e->rB_scnts.data(), e->rB_sdispls.data(),
-                                   e->recvbuf_dev, e->rB_rcnts.data(), e->rB_rdispls.data(), e->xstream);
-        HIP_OK(crp_event_record(e->ev_landed, e->xstream));
         HIP_OK(crp_spmm_csr_f64(e->A_int, 0, n, Bd, ldBd, e->recvbuf_dev, n, Cd, ldCd, e->variant, s));
+        HIP_OK(crp_stream_wait_event(e->xstream, e->ev_packed));
+        {
+            const double tx0 = get_wtime_sec();
+            e->comm->alltoallv_dev_f64(e->comm->ctx, e->sendbuf_dev, e->rB_scnts.data(), e->rB_sdispls.data(),
+                                       e->recvbuf_dev, e->rB_rcnts.data(), e->rB_rdispls.data(), e->xstream);
+            e->t_a2a_host += get_wtime_sec() - tx0;
+        }
+        HIP_OK(crp_event_record(e->ev_landed, e->xstream));
         HIP_OK(crp_stream_wait_event(s, e->ev_landed));
         HIP_OK(crp_spmm_csr_f64(e->A_bnd, 0, n, Bd, ldBd, e->recvbuf_dev, n, Cd, ldCd, e->variant, s));
     }
     else
     {
         if (e->nproc > 1)
+        {
+            const double tx0 = get_wtime_sec();
             e->comm->alltoallv_dev_f64(e->comm->ctx, e->sendbuf_dev, e->rB_scnts.data(), e->rB_sdispls.data(),
                                        e->recvbuf_dev, e->rB_rcnts.data(), e->rB_rdispls.data(), s);
+            e->t_a2a_host += get_wtime_sec() - tx0;
+        }
         if (timing)
         {
             HIP_OK(crp_stream_sync(s));
@@ -516,14 +549,14 @@ void crp_rp_spmm_print_stat(crp_rp_spmm_p e)
     const int n_exec = e->n_exec;
     if (n_exec == 0) return;
     uint64_t recv = (uint64_t) e->rB_recv_size, recv_max = 0, recv_sum = 0;
-    double raw[6] = {e->t_init, e->t_pack, e->t_a2a, e->t_unpack, e->t_spmm, e->t_exec}, tmax[6], tavg[6];
+    double raw[7] = {e->t_init, e->t_pack, e->t_a2a, e->t_unpack, e->t_spmm, e->t_exec, e->t_a2a_host}, tmax[7], tavg[7];
     crp_comm_t *c = e->comm;
     c->reduce_u64(c->ctx, &recv, &recv_max, 1, CRP_OP_MAX);
     c->reduce_u64(c->ctx, &recv, &recv_sum, 1, CRP_OP_SUM);
-    c->reduce_f64(c->ctx, raw, tmax, 6, CRP_OP_MAX);
-    c->reduce_f64(c->ctx, raw, tavg, 6, CRP_OP_SUM);
+    c->reduce_f64(c->ctx, raw, tmax, 7, CRP_OP_MAX);
+    c->reduce_f64(c->ctx, raw, tavg, 7, CRP_OP_SUM);
     if (e->my_rank != 0) return;
-    for (int i = 1; i <= 5; i++)
+    for (int i = 1; i <= 6; i++)
     {
         tmax[i] /= n_exec;
         tavg[i] /= ((double) n_exec * e->nproc);
@@ -543,6 +576,7 @@ void crp_rp_spmm_print_stat(crp_rp_spmm_p e)
     // additive to the reference's block: the device kernels finish in well under a millisecond
     printf("Local SpMM (us)                %9.1f   %9.1f\n", tavg[4] * 1e6, tmax[4] * 1e6);
     printf("Total rp_spmm_exec() (us)      %9.1f   %9.1f\n", tavg[5] * 1e6, tmax[5] * 1e6);
+    if (e->nproc > 1) printf("Exchange call, host side (us)  %9.1f   %9.1f\n", tavg[6] * 1e6, tmax[6] * 1e6);
     printf("\n");
     fflush(stdout);
 }
@@ -551,7 +585,7 @@ void crp_rp_spmm_clear_stat(crp_rp_spmm_p e)
 {
     if (e == NULL) return;
     e->n_exec = 0;
-    e->t_pack = e->t_a2a = e->t_unpack = e->t_spmm = e->t_exec = 0.0;
+    e->t_pack = e->t_a2a = e->t_unpack = e->t_spmm = e->t_exec = e->t_a2a_host = 0.0;
 }
 
 void crp_rp_spmm_get_plan(crp_rp_spmm_p e, crp_rp_plan_view_t *v)
@@ -572,6 +606,8 @@ void crp_rp_spmm_get_plan(crp_rp_spmm_p e, crp_rp_plan_view_t *v)
     v->t_init = e->t_init; v->t_pack = e->t_pack; v->t_a2a = e->t_a2a; v->t_unpack = e->t_unpack;
     v->t_spmm = e->t_spmm; v->t_exec = e->t_exec;
 }
+
+double crp_rp_spmm_exchange_host_seconds(crp_rp_spmm_p e) { return e ? e->t_a2a_host : -1.0; }
 
 void crp_rp_spmm_update_values(crp_rp_spmm_p e, const double *A_val)
 {

@@ -226,6 +226,12 @@ class Para2dSpmm:
         return bool(self._lib.crp_para2d_spmm_replicated_on_device(self.handle))
 
     @property
+    def value_uploads(self):
+        """Times the panel's values crossed PCIe towards the device: 0 when the engine's matrices were filled from the device
+        all-gather (crp_para2d_spmm_value_uploads)."""
+        return int(self._lib.crp_para2d_spmm_value_uploads(self.handle))
+
+    @property
     def t_ag_A(self):
         return float(self._lib.crp_para2d_spmm_t_ag_A(self.handle))
 

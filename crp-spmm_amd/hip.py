@@ -140,7 +140,8 @@ def team_format_host(rowptr, colidx, val):
 def team2_format_host(rowptr, colidx, val):
     """crp_team2_format_host -> dict(nteam, waves W (8 or 16), panels_per_wave P (1; 2 with CRPSPMM_TEAM2_FORMAT_PW=2: wave w owns
     panels tpanel[g, 2w] and tpanel[g, 2w + 1]), lattice, tpanel[nteam, W * P], tinfo[nteam, 4], tpro[nteam, 3, W, 2],
-    trec (uint32 words), tvoff (units of 4 values), tval (compact value streams), torder, vmap, tgrid[8, entries per XCD])."""
+    trec (uint32 words), tvoff (units of 4 values), tval (compact value streams), torder, vmap, tgrid[8, entries per XCD]).
+    With chains (nchain > 0; cptr, cteam) tinfo / tpro / tvoff / tgrid are per chain."""
     lib = L.load()
     rp = np.ascontiguousarray(rowptr, dtype=np.int32)
     ci = np.ascontiguousarray(colidx, dtype=np.int32)
@@ -163,14 +164,18 @@ def team2_format_host(rowptr, colidx, val):
     W = 8 if P == 2 else int(lib.crp_team2_waves())
     tg, ng = L.c_int_p(), C.c_int()
     L.check(lib.crp_team2_format_host_grid(C.byref(tg), C.byref(ng)), "crp_team2_format_host_grid")
+    cp, ct, nch, nmem = L.c_int_p(), L.c_int_p(), C.c_int(), C.c_int()
+    L.check(lib.crp_team2_format_host_chains(C.byref(cp), C.byref(nch), C.byref(ct), C.byref(nmem)), "crp_team2_format_host_chains")
 
     def take(ptr, cnt, dt):
         out = np.ctypeslib.as_array(ptr, (max(cnt, 1),))[:cnt].astype(dt).copy()
         L.c_free(C.cast(ptr, C.c_void_p))
         return out
-    return dict(nteam=nt, waves=W, panels_per_wave=P, compact=bool(lib.crp_team2_format_host_compact()), lattice=bool(lat.value), tpanel=take(tp, W * P * nt, np.int32).reshape(nt, W * P),
-                tinfo=take(ti, 4 * nt, np.int32).reshape(nt, 4), tpro=take(tpr, 6 * W * nt, np.int32).reshape(nt, 3, W, 2),
-                trec=take(tr, nrw.value, np.uint32), tvoff=take(tv, W * nt + 1, np.int64),
+    nu = nch.value if nch.value > 0 else nt                     # units the per-unit arrays describe: chains, or teams
+    return dict(nteam=nt, nchain=nch.value, cptr=take(cp, nch.value + 1 if nch.value > 0 else 0, np.int32), cteam=take(ct, nmem.value, np.int32),
+                waves=W, panels_per_wave=P, compact=bool(lib.crp_team2_format_host_compact()), lattice=bool(lat.value), tpanel=take(tp, W * P * nt, np.int32).reshape(nt, W * P),
+                tinfo=take(ti, 4 * nu, np.int32).reshape(nu, 4), tpro=take(tpr, 6 * W * nu, np.int32).reshape(nu, 3, W, 2),
+                trec=take(tr, nrw.value, np.uint32), tvoff=take(tv, W * nu + 1, np.int64),
                 tval=take(tval, nve.value, np.float64), torder=take(to, nt, np.int32),
                 vmap=take(vm, nnz, np.uint32), tgrid=take(tg, ng.value, np.int32).reshape(8, -1))
 

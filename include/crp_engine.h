@@ -83,7 +83,18 @@ void crp_rp_spmm_exec_ex(crp_rp_spmm_p rp_spmm, int BC_layout, const double *B, 
                          double *C, long long ldC, void *stream);
 void crp_rp_spmm_print_stat(crp_rp_spmm_p rp_spmm);
 void crp_rp_spmm_clear_stat(crp_rp_spmm_p rp_spmm);
+/* rp_spmm_init for a caller that ALSO holds the values in device memory, in the order of A_val (A_val_dev: the panel a
+ * device all-gather produced, csrc/para2d_engine.cpp): the engine's device matrices take them from there and nothing is
+ * uploaded a second time.  A_val (host) is still required: the plan and the derived formats are built on the host and
+ * struct rowpara_spmm::A_val is a public host field (/root/reference/src/rowpara_spmm.h:8-40).  A_val_dev may be freed
+ * when the call returns.  crp_rp_spmm_values_from_device(): 1 when an engine was built that way. */
+void crp_rp_spmm_init_dv(int A_srow, int A_nrow, const int *A_rowptr, const int *A_colidx, const double *A_val,
+                         const double *A_val_dev, const int *B_row_displs, int glb_n, crp_comm_t *comm, crp_rp_spmm_p *rp_spmm);
+int crp_rp_spmm_values_from_device(crp_rp_spmm_p rp_spmm);
 void crp_rp_spmm_get_plan(crp_rp_spmm_p rp_spmm, crp_rp_plan_view_t *view);
+/* Host seconds spent INSIDE the B exchange call (issuing the grouped sends / receives) since the last clear_stat, summed
+ * over the execs -- accumulated in every timing mode; print_stat reports it per exec when there is more than one rank. */
+double crp_rp_spmm_exchange_host_seconds(crp_rp_spmm_p rp_spmm);
 /* timing = 1 (default): every phase is bracketed by stream synchronisation and
  * billed to t_pack / t_a2a / t_unpack / t_spmm like the reference; 0: fully
  * asynchronous exec, only t_exec (host enqueue time) is accumulated. */
@@ -126,6 +137,9 @@ crp_rp_spmm_p crp_para2d_spmm_rp(crp_para2d_spmm_p para2d_spmm);
 /* 1 when init replicated the panel's column indices and values between device buffers (the communicator's
  * allgatherv_dev: RCCL; CRPSPMM_REPLICATE=host forces the host path), 0 when it went through allgatherv_bytes. */
 int crp_para2d_spmm_replicated_on_device(crp_para2d_spmm_p para2d_spmm);
+/* How often the values of the replicated panel crossed PCIe towards the device: 0 = never (they were all-gathered between
+ * device buffers and the engine's matrices were filled from that copy), 1 = once (host replication, or one grid column). */
+int crp_para2d_spmm_value_uploads(crp_para2d_spmm_p para2d_spmm);
 size_t crp_para2d_spmm_rA_cost(crp_para2d_spmm_p para2d_spmm);
 double crp_para2d_spmm_t_ag_A(crp_para2d_spmm_p para2d_spmm);
 

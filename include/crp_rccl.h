@@ -34,6 +34,11 @@ int crp_rccl_get_unique_id(void *id);
 int crp_rccl_create(const void *id, int nranks, int rank, crp_rccl_p *out);
 /* wall time crp_rccl_create() took on this rank (reported by bench.py) */
 double crp_rccl_create_seconds(crp_rccl_p h);
+/* 1 when the communicator was created with the classic blocking ncclCommInitRank (CRPSPMM_RCCL_BLOCKING=1: the known
+ * fallback; a peer that dies before its own call then leaves the others inside theirs), 0 = non-blocking and polled */
+int crp_rccl_is_blocking(crp_rccl_p h);
+/* host seconds spent inside the collectives' calls of this handle so far (issuing the groups), and how many calls */
+double crp_rccl_issue_seconds(crp_rccl_p h, long long *calls);
 int crp_rccl_destroy(crp_rccl_p *h);
 int crp_rccl_nranks(crp_rccl_p h);
 int crp_rccl_rank(crp_rccl_p h);

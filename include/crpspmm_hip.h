@@ -82,6 +82,12 @@ int crp_event_elapsed_ms(void *start, void *stop, float *ms);
  * count of B0 (used for argument checking only).  Blocking. */
 int crp_csr_dev_create(int nrow, int ncol, const int *rowptr, const int *colidx,
                        const double *val, crp_csr_dev_p *out);
+/* The same, for a matrix whose VALUES already sit in device memory (a row panel replicated between GPUs,
+ * /root/reference/src/para2d_spmm.c:56-86): val_host is still read (the derived formats are built on the host), but the
+ * device CSR takes its values from val_dev instead of a second upload.  src_start = NULL: val_dev holds the nnz values in
+ * order; else row t's values start at val_dev[src_start[t]] (host array of nrow entries: a row subset of a larger matrix). */
+int crp_csr_dev_create_dv(int nrow, int ncol, const int *rowptr, const int *colidx, const double *val_host,
+                          const double *val_dev, const int *src_start, crp_csr_dev_p *out);
 int crp_csr_dev_destroy(crp_csr_dev_p *A);
 /* New values for the same sparsity pattern (val in the order given at create; host or device
  * pointer): refreshes the CSR copy and every derived format on `stream`. */
@@ -187,6 +193,10 @@ int crp_team2_format_host(int nrow, const int *rowptr, const int *colidx, const 
  * of *ngrid / 8 entries, run x = the teams XCD x processes, in order (-1 = none); a generation = 64 (W = 16: 32)
  * consecutive entries of a run.  Slots of a round that hold no B row name a row of the team (fetched, not read). */
 int crp_team2_format_host_grid(int **tgrid, int *ngrid);
+/* The chains of those streams (CRPSPMM_T2_CHAIN > 0, the default; csrc/team2p_kernel.hip): chain c = teams
+ * cteam[cptr[c] .. cptr[c + 1]).  With chains tinfo / tpro / tvoff and the launch grid are per CHAIN (*nchain of them) and a
+ * chain's rounds are its teams' rounds one after the other (record flag FLUSH = a team's last round).  *nchain = 0: none. */
+int crp_team2_format_host_chains(int **cptr, int *nchain, int **cteam, int *nmember);
 /* 1 when the value blocks of those streams are compact (a part of len rows holds len values), 0 when every part holds 8
  * values, row r of part i at 8 i + r of the round's block (panels filled to 40 % and more; CRPSPMM_TEAM2_COMPACT=0|1 forces) */
 int crp_team2_format_host_compact(void);

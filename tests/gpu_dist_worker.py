@@ -85,6 +85,8 @@ def main():
             # the panel was replicated between device buffers (staged all-gather in this rehearsal mode, RCCL with a
             # GPU per rank) whenever a grid row has more than one rank and something to gather
             assert e2.replicated_on_device == (pn > 1), (pm, pn, e2.replicated_on_device)
+            # the values gathered between devices fill the engine's matrices: no second upload (src/para2d_spmm.c:56-86,111-125)
+            assert e2.value_uploads == (0 if pn > 1 else 1), (pm, pn, e2.value_uploads)
             e2.rp.set_timing(False)
             Bl = torch.from_numpy(np.ascontiguousarray(B[ac[pi]:ac[pi + 1], bc[pj]:bc[pj + 1]])).to(dev)
             Cl = torch.full((int(ac[pi + 1] - ac[pi]), int(bc[pj + 1] - bc[pj])), float("nan"), dtype=torch.float64, device=dev)

@@ -611,45 +611,71 @@ def _range_of_code(code):
 
 
 def _replay_team2(t, m, B, va=None):
-    """Replays the team2 streams the way csrc/team2_kernel.hip walks them: per team and wave, round by round;
-    the column behind ring slot e of round r is what wave e fetched for that round (tpro for the first 3
-    rounds, the record of round r - 3 afterwards); the parts of round r take their values from the wave's stream
-    at the offset the record of round r - 3 (or tpro) announced.  W = 8 or 16 waves per team."""
+    """Replays the team2 streams the way csrc/team2_kernel.hip / team2p_kernel.hip walk them: per unit (a team, or a CHAIN of
+    teams) and wave, round by round; the column behind ring slot e of round r is what wave e fetched for that round (tpro for
+    the first 3 rounds, the record of round r - 3 afterwards); the parts of round r take their values from the wave's stream
+    at the offset the record of round r - 3 (or tpro) announced.  W = 8 or 16 waves per team.  Chains: the rounds of the
+    chain's teams follow each other; a round with FLUSH is the last of a team -- the wave stores the rows of its panel of THAT
+    team and clears its accumulators; the three rounds behind a FLUSH carry POSTFLUSH (exactly 8 rows stored) or TAIL."""
     W, P, compact = t["waves"], t.get("panels_per_wave", 1), t.get("compact", True)
     sbits, fbase = (3, 16) if W == 8 else (4, 20)
+    nchain = t.get("nchain", 0)
     C_out = np.zeros((m, B.shape[1]))
     written = np.zeros(m, dtype=bool)
     rec = t["trec"].reshape(-1, 8, W, 4)          # [block][round in block][wave][word]
-    for g in range(t["nteam"]):
-        nr, blk0 = int(t["tinfo"][g, 0]), int(t["tinfo"][g, 1])
+    units = [list(t["cteam"][t["cptr"][c]:t["cptr"][c + 1]]) for c in range(nchain)] if nchain else [[g] for g in range(t["nteam"])]
+    if nchain:
+        assert P == 1 and sorted(int(g) for u in units for g in u) == list(range(t["nteam"]))
+        # the launch grid names every chain once
+        tg = t["tgrid"].reshape(-1)
+        assert sorted(int(c) for c in tg[tg >= 0]) == list(range(nchain))
+    for u, members in enumerate(units):
+        nr, blk0 = int(t["tinfo"][u, 0]), int(t["tinfo"][u, 1])
+        if nchain:
+            assert nr >= len(members)
         cols = np.zeros((nr, W), dtype=np.int64)
         voffs = np.zeros((nr, W), dtype=np.int64)
         for r in range(nr):
             for w in range(W):
                 if r < 3:
-                    cols[r, w], voffs[r, w] = t["tpro"][g, r, w]
+                    cols[r, w], voffs[r, w] = t["tpro"][u, r, w]
                 else:
                     cols[r, w] = np.int32(rec[blk0 + ((r - 3) >> 3), (r - 3) & 7, w, 3])
                     voffs[r, w] = rec[blk0 + ((r - 3) >> 3), (r - 3) & 7, w, 2]
         parts_total = 0
+        flush_rounds = None
         for w in range(W):
-            panels = [int(t["tpanel"][g, w * P + j]) for j in range(P)]
-            panel = max(panels)                                         # (-1 only when the wave owns nothing)
-            k0 = int(t["tvoff"][W * g + w])
+            k0 = int(t["tvoff"][W * u + w])
             k = 0
             acc = np.zeros((P, 8, B.shape[1]))
+            member = 0
+            my_flush = []
             for r in range(nr):
+                g = int(members[member])
+                panels = [int(t["tpanel"][g, w * P + j]) for j in range(P)]
+                panel = max(panels)                                         # (-1 only when the wave owns nothing)
                 x, y = int(rec[blk0 + (r >> 3), r & 7, w, 0]), int(rec[blk0 + (r >> 3), r & 7, w, 1])
                 cnt = x & 7
                 assert cnt <= 4 and (x & 8) == 0
-                # flags: ISSUE while a round r + 3 exists, TAIL near the end, LAST on the last round
+                flush = bool(x >> (fbase + 4) & 1)
+                # flags: ISSUE while a round r + 3 exists, LAST on the last round
                 assert bool(x >> fbase & 1) == (r + 3 < nr) and bool(x >> (fbase + 2) & 1) == (r == nr - 1)
-                assert bool(x >> (fbase + 1) & 1) == (r + 2 >= nr)
+                tail = bool(x >> (fbase + 1) & 1)
+                recent = [f for f in my_flush if r - 3 <= f[0] < r]
+                if not nchain:
+                    assert not flush and not (x >> 31) and tail == (r + 2 >= nr)
+                else:
+                    # behind ONE flush of a whole panel: POSTFLUSH; behind anything else (or near the chain's end): TAIL
+                    post = bool(x >> 31)
+                    want_post = len(recent) == 1 and recent[0][1]
+                    assert post == want_post, (u, w, r)
+                    assert tail == (r + 2 >= nr or (len(recent) > 0 and not want_post)), (u, w, r)
+                    assert flush or r < nr - 1
                 if panel < 0:
                     assert cnt == 0
                 z = int(rec[blk0 + (r >> 3), r & 7, w, 2])
                 if cnt:
-                    assert (voffs[r, w] & 0xFFFFF) == k, (g, w, r)         # the announced offset (units of 4 values) is where the stream stands
+                    assert (voffs[r, w] & 0xFFFFF) == k, (u, w, r)         # the announced offset (units of 4 values) is where the stream stands
                 prefix = 0
                 for i in range(cnt):
                     slot = (x >> (4 + sbits * i)) & (W - 1)
@@ -658,7 +684,7 @@ def _replay_team2(t, m, B, va=None):
                     assert first + ln <= 8
                     pos = ((x >> (fbase + 5)) & 63, (y >> 24) & 63, (z >> 20) & 63, (z >> 26) & 63)[i]
                     # compact blocks: the part's values follow those of the parts before it; full groups: 8 per part
-                    assert pos == ((prefix + 7 - first) if compact else (8 * i + 7)), (g, w, r, i)
+                    assert pos == ((prefix + 7 - first) if compact else (8 * i + 7)), (u, w, r, i)
                     c = int(cols[r, slot])
                     assert 0 <= c < B.shape[0]
                     bank = (x >> (fbase + 11 + i)) & 1
@@ -670,26 +696,42 @@ def _replay_team2(t, m, B, va=None):
                 if r >= 3 and cnt:
                     # the size class announced three rounds earlier covers this round's values
                     y3 = int(rec[blk0 + ((r - 3) >> 3), (r - 3) & 7, w, 1])
-                    assert 8 * ((y3 >> 30) + 1) >= prefix > 8 * (y3 >> 30), (g, w, r)
+                    assert 8 * ((y3 >> 30) + 1) >= prefix > 8 * (y3 >> 30), (u, w, r)
                 k += (prefix + 3) // 4
                 parts_total += cnt
-            if panel >= 0:
-                assert k0 + k == int(t["tvoff"][W * g + w + 1]), (g, w)
-            for j in range(P):
-                if panels[j] < 0:
-                    continue
-                lo, hi = panels[j] * 8, min(m, panels[j] * 8 + 8)
-                C_out[lo:hi] = acc[j, :hi - lo]
-                assert not written[lo:hi].any()
-                written[lo:hi] = True
-        assert parts_total == int(t["tinfo"][g, 2])
+                if flush or (not nchain and r == nr - 1):
+                    for j in range(P):
+                        if panels[j] < 0:
+                            continue
+                        lo, hi = panels[j] * 8, min(m, panels[j] * 8 + 8)
+                        C_out[lo:hi] = acc[j, :hi - lo]
+                        assert not written[lo:hi].any()
+                        written[lo:hi] = True
+                    whole = panel >= 0 and panel * 8 + 8 <= m
+                    my_flush.append((r, whole))
+                    acc[:] = 0.0
+                    member += 1
+            if nr == 0:                                                    # (a team without entries, one workgroup per team: rows of zeros)
+                g = int(members[0])
+                for j in range(P):
+                    pj = int(t["tpanel"][g, w * P + j])
+                    if pj >= 0:
+                        written[pj * 8:min(m, pj * 8 + 8)] = True
+                member = 1
+            assert member == len(members), (u, w)
+            if flush_rounds is None:
+                flush_rounds = [f[0] for f in my_flush]
+            assert flush_rounds == [f[0] for f in my_flush]                 # every wave ends its teams in the same rounds
+            if any(int(t["tpanel"][int(g), w * P + j]) >= 0 for g in members for j in range(P)):
+                assert k0 + k == int(t["tvoff"][W * u + w + 1]), (u, w)
+        assert parts_total == int(t["tinfo"][u, 2])
     assert written.all()
     if va is not None:                             # the value-update map names every nonzero's slot
         assert np.array_equal(t["tval"].reshape(-1)[t["vmap"]], va)
     return C_out
 
 
-@pytest.mark.parametrize("order", ["default", "bisect", "two-panels", "compact", "full-groups"])
+@pytest.mark.parametrize("order", ["default", "bisect", "two-panels", "compact", "full-groups", "chains", "chains-of-2"])
 def test_team2_streams_replay(crp, orc, monkeypatch, order):
     """The streams of the LDS-sharing kernel (variant 5), replayed in numpy: every row is produced once and
     equals the oracle's product -- for a stride-lattice matrix (teams of 4 x 2 teeth), a random matrix (8
@@ -701,6 +743,9 @@ def test_team2_streams_replay(crp, orc, monkeypatch, order):
     if order in ("compact", "full-groups"):
         # value blocks without the holes / with 8 values per part, whatever the fill (the default picks by fill)
         monkeypatch.setenv("CRPSPMM_TEAM2_COMPACT", "1" if order == "compact" else "0")
+    if order in ("chains", "chains-of-2"):
+        # persistent workgroups (team2p_kernel.hip) / short chains: teams end close to each other and to the chain's end
+        monkeypatch.setenv("CRPSPMM_T2_CHAIN", "8" if order == "chains" else "2")
     if order == "two-panels":
         # teams of 16 panels on 8 waves, two panels (accumulator banks) per wave: the narrow-operand instance
         monkeypatch.setenv("CRPSPMM_TEAM2_FORMAT_PW", "2")
