@@ -53,7 +53,12 @@ def find_mtx(args):
 
 
 def build_matrix(name, mtx=None):
-    """-> (label, data, m, k, rowptr, colidx, val); data = "real" for a Matrix-Market file, else "synthetic"."""
+    """-> (label, data, m, k, rowptr, colidx, val); data = "real" for a Matrix-Market file, else "synthetic".
+    A name of the form  base@l2  is the DIAGNOSTIC variant of `base` with every column folded into the first 1024 rows of B (2 MiB
+    at n = 256: B is always L2-resident) -- same rows, same teams' sizes, no B traffic beyond L2: the design's ceiling."""
+    if mtx is None and name.endswith("@l2"):
+        label, data, m, k, rp, ci, va = build_matrix(name[:-3], None)
+        return label + " with columns mod 1024 (L2-resident B; diagnostic)", data, m, k, rp, (ci % 1024).astype(np.int32), va
     from crp_spmm_amd import gen
     if mtx is not None:
         from crp_spmm_amd import mmio

@@ -16,6 +16,7 @@ const Knobs &knobs()
     static const Knobs k = [] {
         Knobs x;
         x.t2_chain = std::max(0, std::min(64, env_int("CRPSPMM_T2_CHAIN", 0)));
+        x.t2_latorder = env_int("CRPSPMM_T2_LATORDER", 1) != 0;
         return x;
     }();
     return k;

@@ -7,6 +7,7 @@ namespace crp {
 struct Knobs
 {
     int t2_chain;          // CRPSPMM_T2_CHAIN: teams per chain of the persistent team kernel (0, the default = one workgroup per team: measured faster, profiles/r04_chains_ab.txt)
+    bool t2_latorder;      // CRPSPMM_T2_LATORDER: lattice teams: search the processing order against the L2 model (default 1; 0 = strips along the teeth)
 };
 
 const Knobs &knobs();

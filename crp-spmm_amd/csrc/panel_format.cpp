@@ -7,6 +7,7 @@
 #include "locality.h"
 #include "panel_format.h"
 #include "team_order.h"
+#include "knobs.h"
 #include "par.h"
 #include <time.h>
 
@@ -839,6 +840,12 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
     }
     const int nteam = (int) tk.size();
     out->nteam = nteam;
+    out->lat_key.clear();
+    if (lattice)
+    {
+        out->lat_key.resize((size_t) nteam * 3);
+        for (int g = 0; g < nteam; g++) { out->lat_key[(size_t) g * 3] = tk[(size_t) g].a; out->lat_key[(size_t) g * 3 + 1] = tk[(size_t) g].b; out->lat_key[(size_t) g * 3 + 2] = tk[(size_t) g].t; }
+    }
 
     // union entry lists: 4-way merge by (column key, occurrence inside the panel)
     std::vector<int> cnt((size_t) nteam, 0);
@@ -1603,12 +1610,13 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
     out->absolute = absolute;
     out->wgs = WGS;
     std::vector<int> cut(9, nteam);
-    {
-        std::vector<int> nn((size_t) nteam, 0);
-        parallel_chunks(nteam, 256, [&](long long b, long long e, int) {
-            std::vector<int> nodes;
-            for (long long g = b; g < e; g++) { team_nodes((int) g, nodes); nn[(size_t) g] = (int) nodes.size(); }
-        });
+    std::vector<int> nn((size_t) nteam, 0);
+    parallel_chunks(nteam, 256, [&](long long b, long long e, int) {
+        std::vector<int> nodes;
+        for (long long g = b; g < e; g++) { team_nodes((int) g, nodes); nn[(size_t) g] = (int) nodes.size(); }
+    });
+    auto compute_cut = [&]() {
+        for (int q = 0; q <= 8; q++) cut[(size_t) q] = nteam;
         long long total = 0;
         for (int g = 0; g < nteam; g++) total += (nn[(size_t) g] + W - 1) / W + 4;
         cut[0] = 0;
@@ -1625,7 +1633,8 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
                 const int c = (cut[(size_t) q] + WGS / 2) / WGS * WGS;
                 cut[(size_t) q] = std::max(cut[(size_t) q - 1], std::min(nteam, c));
             }
-    }
+    };
+    compute_cut();
     if (!absolute)
         parallel_chunks(nteam, 32, [&](long long b, long long e, int) {
             std::vector<int> nodes;
@@ -1695,6 +1704,22 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
     }
 
     clk.lap("build_team2: rounds (phase sort, list scheduler)");
+    // ---- lattice teams: the processing order by search over block orders against an L2 model (team_order.h).  CRPSPMM_T2_LATORDER=0
+    // keeps the round-2 order (strips of team columns swept along the teeth).
+    if (th.lattice && !absolute && th.lat_key.size() == (size_t) nteam * 3 && knobs().t2_latorder)
+    {
+        std::vector<const int *> cols((size_t) nteam);
+        std::vector<int> nrs((size_t) nteam);
+        for (int g = 0; g < nteam; g++) { cols[(size_t) g] = res[(size_t) g].col.data(); nrs[(size_t) g] = res[(size_t) g].nr; }
+        LatticeOrderInfo li;
+        // an XCD's 4 MiB of L2 in row slices of the widest tile (2 KiB); a generation = the workgroups resident on an XCD
+        const bool changed = lattice_block_order(nteam, th.lat_key.data(), W, WGS, 2048, TEAM2_NOCOL, cols.data(), nrs.data(), &out->torder, &li);
+        if (clk.on)
+            fprintf(stderr, "[crpspmm timing] lattice order: %d candidates, model misses %.0f (given) -> %.0f (boxes %d x %d, blocks %d x %d x %d, flags %d)%s\n",
+                    li.candidates, li.miss_given, li.miss_best, li.pa, li.pb, li.bt, li.ba, li.bb, li.flags, changed ? "" : " -- kept the given order");
+        if (changed) compute_cut();
+        clk.lap("build_team2: lattice order search");
+    }
     // ---- chains (panel_format.h): the teams of every XCD's run are dealt to chains of at most CH teams.  A run is cut into
     // super-generations of about WGS * CH teams; inside one, chain j takes teams j, j + nch, j + 2 nch ... -- so the nch <= WGS
     // workgroups that work through a super-generation are on neighbouring teams of the order at any time, as consecutive

@@ -120,6 +120,7 @@ struct TeamHost
     big_vector<int>       tsrc;    // T per union entry: the panel-format entry of wave w behind it, or -1
     long long real_entries = 0;    // union entries before padding
     bool bisected = false;         // torder = recursive bisection of the team graph (team_order.h): a generation = 64 (T = 16: 32) consecutive teams
+    std::vector<int>      lat_key; // lattice teams: 3 per team -- team column (a, b) and position t along the teeth (team_order.h, lattice_block_order)
 };
 // colpos (optional, matrices in a locality order): position of row c of A in the order the panels were built on.
 // balanced = false: the union entries of a team stay in column order (the caller orders them itself).

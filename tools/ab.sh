@@ -20,7 +20,7 @@ import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 k = d["roofline"]["kernel"]
 ms = k[k.rfind(",") + 1:].strip().split(" ")[0]
-print("%-22s %-60s step %.4f ms  kernel %s ms  frac %.3f  first %.2f s" % (sys.argv[2], sys.argv[3], d["ms_per_step"], ms, d["roofline"]["frac"], d["config"].get("first_exec_s", 0)))
+print("%-22s %-60s step %.4f ms  kernel %s ms  frac %.3f  first %.2f s" % (sys.argv[2], sys.argv[3], d["ms_per_step"], ms, d["roofline"]["frac"], d["config"].get("first_exec_s") or 0))
 PY
     j=$((j+1))
   done
