@@ -36,8 +36,8 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s 
 
 # kernel symbol behind every variant name (what rocprofv3 --kernel-trace shows for it)
 KERNEL_SYMBOL = {"csr-rowgroup": "crp::spmm_rm_f64_kernel<LPR,VW,NV>", "rowpanel-R4": "crp::spmm_panel_f64_kernel<4,...>",
-                 "rowpanel-R8": "crp::spmm_panel_f64_kernel<8,...>", "team-R8": "crp::spmm_team_f64_kernel",
-                 "team2-R8": "crp::spmm_team2_kernel<double,NV,HAS_B1>"}
+                 "rowpanel-R8": "crp::spmm_panel_f64_kernel<8,...>",
+                 "team2-R8": "crp::spmm_team2_kernel<double,NV,HAS_B1,COMPACT>", "team2r-R8": "crp::spmm_team2r_kernel<G,HAS_B1,2>"}
 
 
 def find_mtx(args):
@@ -436,7 +436,7 @@ def measure(args, matrix, mtx, steps, lib, torch, dist, comm, dev, world, rank, 
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
     ki = rp_eng.kernel_info()
     kname = KERNEL_SYMBOL.get(ki["variant_name"], str(ki["variant_name"]))
-    if ki["variant_name"] == "rowpanel-R8" and 24 <= n // pn <= 32 and (n // pn) % 2 == 0 and os.environ.get("CRPSPMM_NARROW", "1") != "0":
+    if ki["variant_name"] == "rowpanel-R8" and 24 <= n // pn <= 32 and (n // pn) % 2 == 0:
         kname = "crp::spmm_narrow_f64_kernel<NP,HAS_B1,OFF32> (row-panel format, four entries per instruction)"
     traffic, tsrc = measured_traffic(matrix, data, n, world, ki["variant_name"])
     free_b, total_b = torch.cuda.mem_get_info()

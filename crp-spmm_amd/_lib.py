@@ -145,18 +145,12 @@ SIGNATURES = {
     "crp_probe_copy": (_I, [C.c_longlong, _V, _V, _I, _V, _V]),
     "crp_probe_stamp": (_I, [_V, _V]),
     "crp_stream_create_cu_mask": (_I, [C.POINTER(_V), _I, C.POINTER(C.c_uint)]),
-    "crp_team2_waves": (_I, []),
-    "crp_team2_panels_per_wave": (_I, []),
     "crp_team2_format_host_grid": (_I, [C.POINTER(c_int_p), c_int_p]),
-    "crp_team2_format_host_chains": (_I, [C.POINTER(c_int_p), c_int_p, C.POINTER(c_int_p), c_int_p]),
     "crp_team2_format_host_compact": (_I, []),
     "crp_team2_format_host": (_I, [_I, c_int_p, c_int_p, c_dbl_p, c_int_p, c_int_p, C.POINTER(c_int_p), C.POINTER(c_int_p),
                                    C.POINTER(c_int_p), C.POINTER(C.POINTER(C.c_uint)), C.POINTER(_LL),
                                    C.POINTER(C.POINTER(_LL)), C.POINTER(c_dbl_p), C.POINTER(_LL), C.POINTER(c_int_p),
                                    C.POINTER(C.POINTER(C.c_uint))]),
-    "crp_team2n_format_host": (_I, [_I, c_int_p, c_int_p, c_dbl_p, _I, c_int_p, c_int_p, C.POINTER(c_int_p), C.POINTER(c_int_p),
-                                    C.POINTER(C.POINTER(C.c_uint)), C.POINTER(_LL), C.POINTER(C.POINTER(_LL)), C.POINTER(c_dbl_p),
-                                    C.POINTER(_LL), C.POINTER(c_int_p), c_int_p, C.POINTER(C.POINTER(C.c_uint)), C.POINTER(_LL)]),
     "crp_team2r_format_host": (_I, [_I, c_int_p, c_int_p, c_dbl_p, _I, c_int_p, c_int_p, C.POINTER(c_int_p), C.POINTER(c_int_p),
                                     C.POINTER(C.POINTER(C.c_uint)), C.POINTER(_LL), C.POINTER(C.POINTER(_LL)), C.POINTER(c_dbl_p),
                                     C.POINTER(_LL), C.POINTER(c_int_p), c_int_p, C.POINTER(C.POINTER(C.c_uint)), C.POINTER(_LL),

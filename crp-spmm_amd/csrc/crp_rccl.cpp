@@ -6,6 +6,7 @@
 #include <string.h>
 #include <new>
 #include "crp_rccl.h"
+#include "knobs.h"
 
 static_assert(sizeof(ncclUniqueId) <= CRP_RCCL_ID_BYTES, "unique id does not fit CRP_RCCL_ID_BYTES");
 
@@ -34,21 +35,12 @@ static double now_s()
 // "did everybody succeed" vote is then never reached.  Non-blocking calls return ncclInProgress and are polled here under a
 // deadline (CRPSPMM_RCCL_TIMEOUT seconds, default 120 for the creation; the hot-path collectives poll without one, like a
 // blocking call would -- spinning, not sleeping: wait_comm).  CRPSPMM_RCCL_BLOCKING=1 selects the classic blocking communicator.
-static double rccl_deadline_s()
-{
-    const char *e = getenv("CRPSPMM_RCCL_TIMEOUT");
-    const double v = e ? atof(e) : 120.0;
-    return v > 0.0 ? v : 120.0;
-}
+static double rccl_deadline_s() { return crp::knobs().rccl_timeout; }
 
 // CRPSPMM_RCCL_BLOCKING=1: the classic blocking communicator (ncclCommInitRank; every call returns when it is done).  The known
 // fallback for a multi-GPU box on which the non-blocking path misbehaves -- at the price named above: a peer that fails
 // before its own ncclCommInitRank leaves the others inside theirs.
-static bool rccl_blocking_env()
-{
-    const char *e = getenv("CRPSPMM_RCCL_BLOCKING");
-    return e != NULL && atoi(e) != 0;
-}
+static bool rccl_blocking_env() { return crp::knobs().rccl_blocking; }
 
 // Waits until the communicator's pending call has finished; deadline_s <= 0: no deadline.
 // hot = true (the per-multiply collectives): the group is on the stream within microseconds, and the host has kernels to

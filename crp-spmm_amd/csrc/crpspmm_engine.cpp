@@ -10,6 +10,7 @@
 #include "crp_engine.h"
 #include "spmat_part.h"
 #include "utils.h"
+#include "knobs.h"
 
 struct crp_crpspmm
 {
@@ -103,8 +104,7 @@ static void crpspmm_init_impl(int m, int n, int k, int src_A_srow, int src_A_nro
     // the reference's knob (deprecated/src/crpspmm.c:294): read and reported with the reference's
     // message; the exchange here always moves exactly the rows a panel needs, whatever it says
     GET_ENV_INT_VAR(e->v.a2a_B_finegrain, "A2A_B_FINEGRAIN", "a2a_B_finegrain", 0, 0, 1, me == 0);
-    const char *st = getenv("CRPSPMM_ENGINE_A_STATIC");
-    e->a_static = (st != NULL && atoi(st) == 1);
+    e->a_static = crp::knobs().engine_a_static == 1;
 
     // 1. global row pointer and per-row column ranges (deprecated/src/crpspmm.c:91-126)
     std::vector<int> nrow_of(P), A_rowptr((size_t) m + 1, 0), cse((size_t) 2 * (m > 0 ? m : 1), 0);

@@ -33,19 +33,6 @@ struct PanelDev
     long long cvalues = 0;
 };
 
-struct TeamDev
-{
-    bool built = false;
-    int  nteam = 0;
-    int *torder = nullptr, *tpanel = nullptr, *tptr = nullptr, *tcol = nullptr;
-    uint32_t *tmask = nullptr;
-    long long *tvoff = nullptr;
-    double   *tval = nullptr;
-    uint32_t *tmap = nullptr;      // per CSR nonzero: its slot in tval (value updates)
-    long long entries = 0;
-    bool lattice = false;
-};
-
 constexpr int TEAM2_MIN_N = 112;      // fp64 columns from which auto picks variant 5
 // ... when fewer than 35 % of the (row, entry) pairs of the R = 8 panels are present: the row-panel format then stores mostly
 // zeros (8 values per entry) while the team kernel's value streams are compact (nlpkkt stand-in, fill 0.23, n = 96: 1.26 ms
@@ -59,8 +46,6 @@ struct Team2Dev
     bool built = false;
     int  nteam = 0;
     int ngrid = 0;                 // entries of torder (= the launch grid, 8 equal runs, -1 = no team)
-    int tw = 8;                    // waves per team
-    int pw = 1;                    // panels per wave (Team2Host::P)
     bool compact = true;           // Team2Host::compact
     int *torder = nullptr, *tpanel = nullptr, *tinfo = nullptr, *tpro = nullptr;
     uint32_t *trec = nullptr;
@@ -70,30 +55,21 @@ struct Team2Dev
     float    *tval32 = nullptr;    // fp32 copy of the value groups (fp32 path), built on first use
     long long entries = 0, value_entries = 0;
     bool lattice = false;
-    // generation start barrier of the kernel (absolute schedules only): counters [tile][run][generation], never reset
-    unsigned *gsync = nullptr;
-    int gsync_tiles = 0, gsync_ngen = 0, wgs = 64;
-    int nreal[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    // chains (Team2Host::chain > 0): the streams are laid out for the persistent kernel (team2p_kernel.hip); nteam = chains
-    int chain = 0, nmember = 0;
-    int *cptr = nullptr, *cteam = nullptr, *trows = nullptr;
-    long long rows_epoch = -1;     // the row map trows was filled for
-    const int *rows_map = nullptr;
 };
 
-struct Team2NDev              // panel_format.h, Team2NHost: the narrow-operand team kernel's streams (variant 6)
+struct Team2RDev              // panel_format.h, Team2RHost: the row-owner team kernel's streams (variant 7)
 {
     bool built = false;
     int G = 4, nteam = 0, ngrid = 0;
-    int rowdma = 2;                // team2r: row DMAs of a wave per round (Team2RHost::rowdma)
     int *tgrid = nullptr, *tpanel = nullptr, *tinfo = nullptr;
     uint32_t *trec = nullptr;
     long long *tvoff = nullptr;
     double *tval = nullptr;
     uint32_t *tmap = nullptr;
-    uint32_t *tent = nullptr;      // team2r: the entry table (Team2RHost::tent); its C rows are filled for rows_epoch
+    uint32_t *tent = nullptr;      // the entry table (Team2RHost::tent); its C rows are filled for rows_epoch
     long long rows_epoch = -1;
     const int *rows_map = nullptr;
+    bool refused = false;          // the streams of this matrix would pass their 32-bit offsets: remembered, not rebuilt per product
     long long value_entries = 0;
     bool lattice = false;
 };
@@ -110,12 +86,8 @@ struct crp_csr_dev
     std::vector<int>    h_rowptr, h_colidx;
     std::vector<double> h_val;
     PanelDev pan[2];          // [0]: R = 4, [1]: R = 8
-    TeamDev  team;            // teams of four R = 8 panels (variant 4)
     Team2Dev team2;           // teams of eight R = 8 panels, LDS-shared B rows (variant 5)
-    Team2Dev team2p;          // teams of 16 panels on 8 waves, two panels per wave: variant 5 for operands of one 16-byte piece per
-                              // lane (fp64: n <= 128, fp32: n <= 256)
-    Team2NDev team2n[2];      // [0]: four entries per instruction (n <= 32), [1]: two (n <= 64)
-    Team2NDev team2r[2];      // the row-owner team kernel's streams (variant 7; Team2RHost: tvoff in units of 16 bytes, tval = the streams)
+    Team2RDev team2r[2];      // the row-owner team kernel's streams (variant 7): [0] n <= 32 (G = 4), [1] n <= 64 (G = 2); tvoff in units of 16 bytes
     int      auto_variant = 1; // what variant 0 resolves to below 96 columns (1 rowgroup, 2 panel R4, 3 panel R8)
     long long rowmap_epoch = 0;    // bumped by crp_csr_dev_set_rowmap: the team2r entry tables hold C rows
     bool     team2r_pays = false;  // narrow operands (24 .. 64 columns): the row-owner team kernel beats the row-panel kernels (panels mostly holes)
@@ -196,9 +168,8 @@ static int ensure_panel(crp_csr_dev *A, int idx, hipStream_t stream)
         if (e == hipSuccess) e = hipMalloc((void **) &d.porder, sizeof(int) * rec.size());
         if (e == hipSuccess) e = hipMemcpy(d.porder, rec.data(), sizeof(int) * rec.size(), hipMemcpyHostToDevice);
     }
-    // team schedule: the waves of a workgroup start their rounds together (CRPSPMM_TEAM_SYNC=0: free-running)
-    const bool use_sync = getenv("CRPSPMM_TEAM_SYNC") ? atoi(getenv("CRPSPMM_TEAM_SYNC")) != 0 : true;
-    if (e == hipSuccess && !h.psync.empty() && use_sync)
+    // team schedule: the waves of a workgroup start their rounds together
+    if (e == hipSuccess && !h.psync.empty())
     {
         e = hipMalloc((void **) &d.psync, sizeof(int) * (h.psync.size() + 8));
         if (e == hipSuccess) e = hipMemset(d.psync, 0, sizeof(int) * (h.psync.size() + 8));
@@ -218,10 +189,9 @@ static int ensure_panel(crp_csr_dev *A, int idx, hipStream_t stream)
         e = hipMemcpy(d.pval, h.pval.data(), sizeof(double) * h.pval.size(), hipMemcpyHostToDevice);
     // Compact values for the narrow-operand kernel when under 60 % of the panels' (row, entry) pairs exist (n = 32, compact
     // against full values: nlpkkt stand-in, fill 0.23: 0.527 against 0.599 ms; Queen stand-in, 0.57: 0.243 against 0.260; pwtk
-    // stand-in, 0.61: 0.068 against 0.067): CRPSPMM_NARROW_COMPACT=0 never, =1 whatever the fill
+    // stand-in, 0.61: 0.068 against 0.067)
     {
-        const char *ec = getenv("CRPSPMM_NARROW_COMPACT");
-        const bool want = idx == 1 && (ec ? atoi(ec) == 1 : d.fill < 0.6);
+        const bool want = idx == 1 && d.fill < 0.6;
         if (e == hipSuccess && want && A->nnz > 0 && crp::build_compact_values(&h))
         {
             d.cvalues = h.cbase.back();          // (cmap is derived from pmap, which is indexed by the caller's nonzeros already)
@@ -246,72 +216,10 @@ static int ensure_panel(crp_csr_dev *A, int idx, hipStream_t stream)
     return 0;
 }
 
-// Build (once) and upload the team format on top of the R = 8 panels. Blocking.
-static int ensure_team(crp_csr_dev *A, hipStream_t stream)
-{
-    TeamDev &t = A->team;
-    if (t.built) return 0;
-    const int rc = ensure_panel(A, 1, stream);
-    if (rc != 0) return rc;
-    crp::PanelHost h;
-    crp::build_panels(A->nrow, fmt_rowptr(A), fmt_colidx(A), fmt_val(A), 8, &h, false);
-    fmt_slotmap_to_caller(A, &h.pmap);
-    crp::TeamHost th;
-    crp::build_teams(h, A->nrow, fmt_rowptr(A), fmt_colidx(A), &th);
-    t.nteam = th.nteam;
-    t.entries = (long long) th.tcol.size();
-    t.lattice = th.lattice;
-    auto up = [](void **dst, const void *src, size_t bytes, size_t pad) -> hipError_t {
-        hipError_t e = hipMalloc(dst, bytes + pad);
-        if (e == hipSuccess && pad) e = hipMemset((char *) *dst + bytes, 0, pad);
-        if (e == hipSuccess && bytes) e = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
-        return e;
-    };
-    hipError_t e = up((void **) &t.torder, th.torder.data(), sizeof(int) * th.torder.size(), 4);
-    if (e == hipSuccess) e = up((void **) &t.tpanel, th.tpanel.data(), sizeof(int) * th.tpanel.size(), 4);
-    if (e == hipSuccess) e = up((void **) &t.tptr, th.tptr.data(), sizeof(int) * th.tptr.size(), 4);
-    if (e == hipSuccess) e = up((void **) &t.tcol, th.tcol.data(), sizeof(int) * th.tcol.size(), 256);
-    if (e == hipSuccess) e = up((void **) &t.tmask, th.tmask.data(), sizeof(uint32_t) * th.tmask.size(), 256);
-    // value streams and the update map, from the panel format's values and slot map
-    const long long nent = th.tvoff.back();
-    std::vector<double> tval((size_t) nent * 8, 0.0);
-    for (size_t q = 0; q < th.tq.size(); q++)
-        if (th.tq[q] >= 0) memcpy(&tval[(size_t) th.tq[q] * 8], &h.pval[q * 8], sizeof(double) * 8);
-    std::vector<uint32_t> tmap(h.pmap.size());
-    for (size_t pz = 0; pz < h.pmap.size(); pz++) tmap[pz] = (uint32_t) (th.tq[h.pmap[pz] >> 3] * 8 + (h.pmap[pz] & 7));
-    if (e == hipSuccess) e = up((void **) &t.tvoff, th.tvoff.data(), sizeof(long long) * th.tvoff.size(), 8);
-    if (e == hipSuccess) e = up((void **) &t.tval, tval.data(), sizeof(double) * tval.size(), 1024);
-    if (e == hipSuccess) e = up((void **) &t.tmap, tmap.data(), sizeof(uint32_t) * tmap.size(), 4);
-    if (e != hipSuccess) return (int) e;
-    if (A->host_vals_stale && A->nnz > 0) CRP_TRY(crp::scatter_vals_f64(A->nnz, t.tmap, A->val, t.tval, stream));
-    t.built = true;
-    return 0;
-}
-
 // Build (once) and upload the team2 streams on top of the R = 8 panels (column-ordered entries). Blocking.
-// CRPSPMM_TEAM2_WAVES=8|16: panels (= waves) per team of variant 5
-static int team2_waves()
+static int ensure_team2(crp_csr_dev *A, hipStream_t stream)
 {
-    static const int w = getenv("CRPSPMM_TEAM2_WAVES") && atoi(getenv("CRPSPMM_TEAM2_WAVES")) == 16 ? 16 : 8;
-    return w;
-}
-
-// Panels per wave of variant 5 for operands of `pieces` 16-byte pieces per lane and row.  CRPSPMM_TEAM2_PW=2: two (teams of 16
-// panels = 128 rows on 8 waves) when one piece covers the operand -- half the rounds, barriers and records per row and a B
-// row fetched once per 128 rows instead of 64.  Measured (profiles/r03_narrow_widths.txt, n = 128 / 96 / 64): pwtk stand-in
-// 0.210 / 0.199 / 0.193 ms against 0.225 / 0.217 / 0.206 with one panel per wave, nlpkkt stand-in 1.27 against 1.30, but the
-// Queen and shell stand-ins 8 % and 3 % slower -- below 256 columns the kernel is bound by the instructions per part, not by
-// memory (its time hardly moves from n = 64 to 128), and the second format costs its memory: one panel per wave stays the
-// default.  Teams of 16 waves (CRPSPMM_TEAM2_WAVES=16) have no two-panel instance.
-static int team2_pw(int pieces)
-{
-    const int env = getenv("CRPSPMM_TEAM2_PW") ? atoi(getenv("CRPSPMM_TEAM2_PW")) : 1;
-    return (pieces == 1 && env == 2 && team2_waves() == 8) ? 2 : 1;
-}
-
-static int ensure_team2(crp_csr_dev *A, hipStream_t stream, int pw)
-{
-    Team2Dev &t = pw == 2 ? A->team2p : A->team2;
+    Team2Dev &t = A->team2;
     if (t.built) return 0;
     crp::PhaseClock clk;
     crp::released_async<crp::PanelHost> h_owner;          // (freed by a background thread when this function returns)
@@ -321,22 +229,11 @@ static int ensure_team2(crp_csr_dev *A, hipStream_t stream, int pw)
     clk.lap("ensure_team2: build_panels (R = 8)");
     crp::released_async<crp::Team2Host> th_owner;
     crp::Team2Host &th = *th_owner;
-    th.T = pw == 2 ? 16 : team2_waves();
-    th.P = pw;
     // Value blocks: compact (only the values that exist) when under 40 % of the (row, entry) pairs of the panels exist, 8 per
     // part otherwise -- the kernel instance for full groups decodes no value position (two instructions per part and three
     // per round fewer).  Same box, compact against full groups: shell stand-in 0.2686 / 0.2649 ms, Queen stand-in 0.8597 / 0.854,
     // nlpkkt stand-in (fill 0.23) 1.91 / 2.05 and 13 GB smaller at nlpkkt240 size.  CRPSPMM_TEAM2_COMPACT=0|1 forces.
-    {
-        const char *ec = getenv("CRPSPMM_TEAM2_COMPACT");
-        th.compact = ec ? atoi(ec) != 0 : h.fill() < 0.4;
-    }
-    t.tw = th.T / pw;
-    t.pw = pw;
-    // Chains of teams for persistent workgroups (team2p_kernel.hip): CRPSPMM_T2_CHAIN = teams per chain at most; 0, the default =
-    // one workgroup per team (team2_kernel.hip).  Measured (profiles/r04_chains_ab.txt): chains are 2 - 8 % SLOWER on every
-    // stand-in -- the start-up they remove was hidden behind the CU's second workgroup, and hardware dispatch balances better.
-    th.chain = pw == 1 ? crp::knobs().t2_chain : 0;
+    th.compact = crp::knobs().team2_compact >= 0 ? crp::knobs().team2_compact != 0 : h.fill() < 0.4;
     std::vector<int> colpos;                    // position of every row in the processing order (square, re-ordered matrices)
     if (!A->perm.empty())
     {
@@ -345,9 +242,7 @@ static int ensure_team2(crp_csr_dev *A, hipStream_t stream, int pw)
     }
     crp::build_team2(h, A->nrow, fmt_rowptr(A), fmt_colidx(A), &th, colpos.empty() ? nullptr : colpos.data());
     clk.lap("ensure_team2: build_team2");
-    t.chain = th.chain;
-    t.nteam = th.chain > 0 ? (int) th.cptr.size() - 1 : th.nteam;
-    t.nmember = (int) th.cteam.size();
+    t.nteam = th.nteam;
     t.entries = th.real_entries;
     t.lattice = th.lattice;
     auto up = [](void **dst, const void *src, size_t bytes, size_t pad) -> hipError_t {
@@ -368,35 +263,6 @@ static int ensure_team2(crp_csr_dev *A, hipStream_t stream, int pw)
     // the kernel requests 256 bytes per wave and round: up to four groups past a wave's last part
     if (e == hipSuccess) e = up((void **) &t.tval, th.tval.data(), sizeof(double) * th.tval.size(), 4096);
     if (e == hipSuccess) e = up((void **) &t.tmap, th.vmap.data(), sizeof(uint32_t) * th.vmap.size(), 4);
-    if (e == hipSuccess && th.chain > 0)
-    {
-        e = up((void **) &t.cptr, th.cptr.data(), sizeof(int) * th.cptr.size(), 4);
-        if (e == hipSuccess) e = up((void **) &t.cteam, th.cteam.data(), sizeof(int) * th.cteam.size(), 4);
-        // (+ one team's worth: the FLUSH of a chain's last team requests the rows "of the next team")
-        if (e == hipSuccess) e = hipMalloc((void **) &t.trows, sizeof(int) * ((size_t) th.cteam.size() + 1) * (size_t) t.tw * 8);
-        if (e == hipSuccess) e = hipMemset(t.trows, 0xFF, sizeof(int) * ((size_t) th.cteam.size() + 1) * (size_t) t.tw * 8);
-        t.rows_epoch = -1;
-    }
-    t.wgs = th.wgs;
-    {
-        const int cpx = t.ngrid / 8;
-        for (int x = 0; x < 8; x++)
-        {
-            int c = 0;
-            for (int i = 0; i < cpx; i++) c += th.tgrid[(size_t) x * cpx + (size_t) i] >= 0;
-            t.nreal[x] = c;
-        }
-        // (off by default: see the measurements at CRPSPMM_T2_ORDER in panel_format.cpp)
-        const bool gsync_on = getenv("CRPSPMM_T2_GSYNC") != NULL && atoi(getenv("CRPSPMM_T2_GSYNC")) != 0;
-        if (e == hipSuccess && th.absolute && gsync_on && cpx > 0)
-        {
-            t.gsync_tiles = 16;                                     // operands up to 4096 fp64 columns; wider ones run without the barrier
-            t.gsync_ngen = (cpx + th.wgs - 1) / th.wgs;
-            const size_t bytes = sizeof(unsigned) * (size_t) t.gsync_tiles * 8 * (size_t) t.gsync_ngen;
-            e = hipMalloc((void **) &t.gsync, bytes);
-            if (e == hipSuccess) e = hipMemset(t.gsync, 0, bytes);
-        }
-    }
     if (e != hipSuccess) return (int) e;
     if (A->host_vals_stale && A->nnz > 0) CRP_TRY(crp::scatter_vals_f64(A->nnz, t.tmap, A->val, t.tval, stream));
     clk.lap("ensure_team2: upload");
@@ -404,75 +270,19 @@ static int ensure_team2(crp_csr_dev *A, hipStream_t stream, int pw)
     return 0;
 }
 
-// The argument block of the team kernels from a built format; with chains the C rows of the chains' panels are (re)filled when the
-// row map they were filled for is not the one of this launch.
-static int team2_args(crp_csr_dev *A, Team2Dev &d, const int *rowmap, hipStream_t stream, crp::Team2Args *t)
+static void team2_args(const Team2Dev &d, crp::Team2Args *t)
 {
-    t->nteam = d.nteam; t->ngrid = d.ngrid; t->tw = d.tw; t->pw = d.pw; t->compact = d.compact; t->torder = d.torder; t->tpanel = d.tpanel;
+    t->nteam = d.nteam; t->ngrid = d.ngrid; t->compact = d.compact; t->torder = d.torder; t->tpanel = d.tpanel;
     t->tinfo = d.tinfo; t->tpro = d.tpro; t->trec = d.trec; t->tvoff = d.tvoff; t->tval = d.tval; t->tval32 = d.tval32;
-    t->gsync = d.gsync; t->gsync_tiles = d.gsync_tiles; t->gsync_ngen = d.gsync_ngen; t->wgs = d.wgs;
-    for (int x = 0; x < 8; x++) t->nreal[x] = d.nreal[x];
-    t->chain = d.chain; t->nmember = d.nmember; t->cptr = d.cptr; t->cteam = d.cteam; t->trows = d.trows;
-    if (d.chain > 0 && (d.rows_epoch != A->rowmap_epoch || d.rows_map != rowmap))
-    {
-        CRP_TRY(crp::team2p_fill_rows(*t, A->nrow, rowmap, stream));
-        d.rows_epoch = A->rowmap_epoch;
-        d.rows_map = rowmap;
-    }
-    return 0;
-}
-
-static int ensure_team2n(crp_csr_dev *A, hipStream_t stream, int G)
-{
-    Team2NDev &t = A->team2n[G == 2 ? 1 : 0];
-    if (t.built) return 0;
-    crp::PhaseClock clk;
-    crp::released_async<crp::PanelHost> h_owner;
-    crp::PanelHost &h = *h_owner;
-    crp::build_panels(A->nrow, fmt_rowptr(A), fmt_colidx(A), fmt_val(A), 8, &h, false, false);
-    fmt_slotmap_to_caller(A, &h.pmap);
-    clk.lap("ensure_team2n: build_panels (R = 8)");
-    crp::released_async<crp::Team2NHost> th_owner;
-    crp::Team2NHost &th = *th_owner;
-    th.G = G == 2 ? 2 : 4;
-    std::vector<int> colpos;
-    if (!A->perm.empty())
-    {
-        colpos.resize(A->perm.size());
-        for (size_t i = 0; i < A->perm.size(); i++) colpos[(size_t) A->perm[i]] = (int) i;
-    }
-    crp::build_team2n(h, A->nrow, fmt_rowptr(A), fmt_colidx(A), &th, colpos.empty() ? nullptr : colpos.data());
-    clk.lap("ensure_team2n: build_team2n");
-    t.G = th.G;
-    t.nteam = th.nteam;
-    t.lattice = th.lattice;
-    t.ngrid = (int) th.tgrid.size();
-    t.value_entries = th.nvalues;
-    auto up = [](void **dst, const void *src, size_t bytes, size_t pad) -> hipError_t {
-        hipError_t e = hipMalloc(dst, bytes + pad);
-        if (e == hipSuccess && pad) e = hipMemset((char *) *dst + bytes, 0, pad);
-        if (e == hipSuccess && bytes) e = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
-        return e;
-    };
-    hipError_t e = up((void **) &t.tgrid, th.tgrid.data(), sizeof(int) * th.tgrid.size(), 4);
-    if (e == hipSuccess) e = up((void **) &t.tpanel, th.tpanel.data(), sizeof(int) * th.tpanel.size(), 4);
-    if (e == hipSuccess) e = up((void **) &t.tinfo, th.tinfo.data(), sizeof(int) * th.tinfo.size(), 16);
-    if (e == hipSuccess) e = up((void **) &t.trec, th.trec.data(), sizeof(uint32_t) * th.trec.size(), 1024);
-    if (e == hipSuccess) e = up((void **) &t.tvoff, th.tvoff.data(), sizeof(long long) * th.tvoff.size(), 8);
-    // a wave's value DMA takes whole 16-byte lanes of its block: nothing past the stream's padding is addressed
-    if (e == hipSuccess) e = up((void **) &t.tval, th.tval.data(), sizeof(double) * th.tval.size(), 4096);
-    if (e == hipSuccess) e = up((void **) &t.tmap, th.vmap.data(), sizeof(uint32_t) * th.vmap.size(), 4);
-    if (e != hipSuccess) return (int) e;
-    if (A->host_vals_stale && A->nnz > 0) CRP_TRY(crp::scatter_vals_f64(A->nnz, t.tmap, A->val, t.tval, stream));
-    clk.lap("ensure_team2n: upload");
-    t.built = true;
-    return 0;
 }
 
 static int ensure_team2r(crp_csr_dev *A, hipStream_t stream, int G)
 {
-    Team2NDev &t = A->team2r[G == 2 ? 1 : 0];
+    Team2RDev &t = A->team2r[G == 2 ? 1 : 0];
     if (t.built) return 0;
+    if (t.refused) return -6;
+    // a cheap bound first: a wave's block takes at least 10 bytes per nonzero (value + offset), and the streams address 34 GB
+    if ((double) A->nnz * 10.0 > 34.0e9) { t.refused = true; return -6; }
     crp::PhaseClock clk;
     crp::released_async<crp::PanelHost> h_owner;
     crp::PanelHost &h = *h_owner;
@@ -482,18 +292,19 @@ static int ensure_team2r(crp_csr_dev *A, hipStream_t stream, int G)
     crp::released_async<crp::Team2RHost> th_owner;
     crp::Team2RHost &th = *th_owner;
     th.G = G == 2 ? 2 : 4;
-    // half rounds (8 KiB ring sets, three workgroups per CU): CRPSPMM_T2R_ROWDMA=1
-    th.rowdma = (getenv("CRPSPMM_T2R_ROWDMA") && atoi(getenv("CRPSPMM_T2R_ROWDMA")) == 1) ? 1 : 2;
     std::vector<int> colpos;
     if (!A->perm.empty())
     {
         colpos.resize(A->perm.size());
         for (size_t i = 0; i < A->perm.size(); i++) colpos[(size_t) A->perm[i]] = (int) i;
     }
-    if (!crp::build_team2r(h, A->nrow, fmt_rowptr(A), fmt_colidx(A), &th, colpos.empty() ? nullptr : colpos.data())) return -6;   // too large for this format
+    if (!crp::build_team2r(h, A->nrow, fmt_rowptr(A), fmt_colidx(A), &th, colpos.empty() ? nullptr : colpos.data()))
+    {
+        t.refused = true;                   // too large for this format
+        return -6;
+    }
     clk.lap("ensure_team2r: build_team2n");
     t.G = th.G;
-    t.rowdma = th.rowdma;
     t.nteam = th.nteam;
     t.lattice = th.lattice;
     t.ngrid = (int) th.tgrid.size();
@@ -524,16 +335,8 @@ static int ensure_team2r(crp_csr_dev *A, hipStream_t stream, int G)
 // variant 0 on narrow operands: the row-owner team kernel where the R = 8 panels are mostly holes (CRPSPMM_TEAM2R=0|1 forces)
 static bool team2r_auto(const crp_csr_dev *A)
 {
-    const char *e = getenv("CRPSPMM_TEAM2R");
-    if (e != NULL) return atoi(e) != 0;
+    if (crp::knobs().team2r >= 0) return crp::knobs().team2r != 0;
     return A->team2r_pays;          // panels that are mostly holes (set at create)
-}
-
-// variant 0 below the team2 threshold: the narrow team kernel (CRPSPMM_TEAM2N=0 keeps the row-panel kernels)
-static bool team2n_auto()
-{
-    const char *e = getenv("CRPSPMM_TEAM2N");
-    return e != NULL && atoi(e) != 0;
 }
 
 extern "C" {
@@ -810,8 +613,7 @@ static int csr_dev_create_impl(int nrow, int ncol, const int *rowptr, const int 
     // the lattice schedules build on that.  CRPSPMM_REORDER=0 never, =1 whenever the matrix qualifies.
     if (nnz > 0 && nrow >= 2048 && nrow == ncol && A->b1_rows == 0 && nnz <= 200000000LL)    // (the graph of a larger matrix costs tens of GB)
     {
-        const char *er = getenv("CRPSPMM_REORDER");
-        const int mode = er ? atoi(er) : -1;
+        const int mode = crp::knobs().reorder;
         std::vector<int> perm;
         if (mode != 0 && crp::locality_reorder(nrow, ncol, rowptr, colidx, 8, &perm))
         {
@@ -881,8 +683,7 @@ static int csr_dev_create_impl(int nrow, int ncol, const int *rowptr, const int 
     // Erdos-Renyi 0.99, where the CSR kernel stays).
     if (nnz > 0 && nrow >= 64)
         A->team2_pays = (double) crp::count_block_union(nrow, fmt_rowptr(A), fmt_colidx(A), 64) <= 0.6 * (double) nnz;
-    const char *env = getenv("CRPSPMM_SPMM_VARIANT");
-    if (env != NULL && atoi(env) >= 1 && atoi(env) <= 3) A->auto_variant = atoi(env);
+    if (crp::knobs().spmm_variant >= 1 && crp::knobs().spmm_variant <= 3) A->auto_variant = crp::knobs().spmm_variant;
     // (the derived formats are built by the first product that uses them: a matrix multiplied by wide operands only never
     //  needs its row-panel format -- 20 GB for the nlpkkt240-size stand-in)
     *out = A;
@@ -907,15 +708,7 @@ int crp_csr_dev_destroy(crp_csr_dev_p *A_)
         if (A->pan[i].cval) (void) hipFree(A->pan[i].cval);
         if (A->pan[i].cmap) (void) hipFree(A->pan[i].cmap);
     }
-    if (A->team.torder) (void) hipFree(A->team.torder);
-    if (A->team.tpanel) (void) hipFree(A->team.tpanel);
-    if (A->team.tptr) (void) hipFree(A->team.tptr);
-    if (A->team.tcol) (void) hipFree(A->team.tcol);
-    if (A->team.tmask) (void) hipFree(A->team.tmask);
-    if (A->team.tvoff) (void) hipFree(A->team.tvoff);
-    if (A->team.tval) (void) hipFree(A->team.tval);
-    if (A->team.tmap) (void) hipFree(A->team.tmap);
-    for (Team2Dev *t2 : {&A->team2, &A->team2p})
+    for (Team2Dev *t2 : {&A->team2})
     {
         if (t2->torder) (void) hipFree(t2->torder);
         if (t2->tpanel) (void) hipFree(t2->tpanel);
@@ -926,14 +719,10 @@ int crp_csr_dev_destroy(crp_csr_dev_p *A_)
         if (t2->tval) (void) hipFree(t2->tval);
         if (t2->tmap) (void) hipFree(t2->tmap);
         if (t2->tval32) (void) hipFree(t2->tval32);
-        if (t2->gsync) (void) hipFree(t2->gsync);
-        if (t2->cptr) (void) hipFree(t2->cptr);
-        if (t2->cteam) (void) hipFree(t2->cteam);
-        if (t2->trows) (void) hipFree(t2->trows);
     }
-    for (Team2NDev *tnp : {&A->team2n[0], &A->team2n[1], &A->team2r[0], &A->team2r[1]})
+    for (Team2RDev *tnp : {&A->team2r[0], &A->team2r[1]})
     {
-        Team2NDev &tn = *tnp;
+        Team2RDev &tn = *tnp;
         if (tn.tgrid) (void) hipFree(tn.tgrid);
         if (tn.tpanel) (void) hipFree(tn.tpanel);
         if (tn.tinfo) (void) hipFree(tn.tinfo);
@@ -961,9 +750,8 @@ int crp_csr_dev_update_values(crp_csr_dev_p A, const double *val, void *stream)
     // the slot maps of the derived formats are 32-bit
     for (int i = 0; i < 2; i++)
         if (A->pan[i].built && A->pan[i].entries * (long long) A->pan[i].R >= (1LL << 32)) return -5;
-    if (A->team.built && A->team.entries * 8LL >= (1LL << 32)) return -5;
-    if ((A->team2.built && A->team2.value_entries >= (1LL << 32)) || (A->team2p.built && A->team2p.value_entries >= (1LL << 32))) return -5;
-    for (Team2NDev *tnp : {&A->team2n[0], &A->team2n[1], &A->team2r[0], &A->team2r[1]})
+    if (A->team2.built && A->team2.value_entries >= (1LL << 32)) return -5;
+    for (Team2RDev *tnp : {&A->team2r[0], &A->team2r[1]})
         if (tnp->built && tnp->value_entries >= (1LL << 32)) return -5;
     int is_dev = 0;
     crp_dev_ptr_is_device(val, &is_dev);
@@ -982,14 +770,13 @@ int crp_csr_dev_update_values(crp_csr_dev_p A, const double *val, void *stream)
             CRP_TRY(crp::scatter_vals_f64(A->nnz, A->pan[i].pmap, A->val, A->pan[i].pval, (hipStream_t) stream));
             if (A->pan[i].cmap) CRP_TRY(crp::scatter_vals_f64(A->nnz, A->pan[i].cmap, A->val, A->pan[i].cval, (hipStream_t) stream));
         }
-    if (A->team.built) CRP_TRY(crp::scatter_vals_f64(A->nnz, A->team.tmap, A->val, A->team.tval, (hipStream_t) stream));
-    for (Team2Dev *t2 : {&A->team2, &A->team2p})
+    for (Team2Dev *t2 : {&A->team2})
         if (t2->built) CRP_TRY(crp::scatter_vals_f64(A->nnz, t2->tmap, A->val, t2->tval, (hipStream_t) stream));
-    for (Team2NDev *tnp : {&A->team2n[0], &A->team2n[1], &A->team2r[0], &A->team2r[1]})
+    for (Team2RDev *tnp : {&A->team2r[0], &A->team2r[1]})
         if (tnp->built) CRP_TRY(crp::scatter_vals_f64(A->nnz, tnp->tmap, A->val, tnp->tval, (hipStream_t) stream));
     // fp32 copies follow
     if (A->val32) CRP_TRY(crp::convert_f64_f32(A->nnz, A->val, A->val32, (hipStream_t) stream));
-    for (Team2Dev *t2 : {&A->team2, &A->team2p})
+    for (Team2Dev *t2 : {&A->team2})
         if (t2->tval32) CRP_TRY(crp::convert_f64_f32(t2->value_entries, t2->tval, t2->tval32, (hipStream_t) stream));
     return 0;
 }
@@ -1027,7 +814,9 @@ int crp_csr_dev_nrow(crp_csr_dev_p A) { return A ? A->nrow : -1; }
 long long crp_csr_dev_nnz(crp_csr_dev_p A) { return A ? A->nnz : -1; }
 long long crp_csr_dev_bytes(crp_csr_dev_p A) { return A ? 12LL * A->nnz + 4LL * ((long long) A->nrow + 1) : -1; }
 
-static const char *k_variant_names[] = {"auto", "csr-rowgroup", "rowpanel-R4", "rowpanel-R8", "team-R8", "team2-R8", "team2n-R8", "team2r-R8"};
+// (4 and 6 were the round-1 LDS team kernel and the narrow team kernel of round 3: measured slower than what variant 0 picks,
+//  removed in round 4; the numbers stay so that 5 and 7 keep their meaning)
+static const char *k_variant_names[] = {"auto", "csr-rowgroup", "rowpanel-R4", "rowpanel-R8", "(removed)", "team2-R8", "(removed)", "team2r-R8"};
 int crp_spmm_variant_count(void) { return (int) (sizeof(k_variant_names) / sizeof(k_variant_names[0])); }
 const char *crp_spmm_variant_name(int variant)
 {
@@ -1040,7 +829,7 @@ int crp_spmm_csr_f64(crp_csr_dev_p A, int layout, int n, const double *B0, long 
 {
     if (A == NULL || n < 0) return -1;
     if (layout != CRP_LAYOUT_ROW_MAJOR && layout != CRP_LAYOUT_COL_MAJOR) return -1;
-    if (variant < 0 || variant >= crp_spmm_variant_count()) return -1;
+    if (variant < 0 || variant >= crp_spmm_variant_count() || variant == 4 || variant == 6) return -1;
     if (A->nrow == 0 || n == 0) return 0;
     if (C == NULL || (B0 == NULL && B1 == NULL && A->nnz > 0)) return -1;
     if (layout == CRP_LAYOUT_ROW_MAJOR && (ldC < n || (B0 && ldB0 < n) || (B1 && ldB1 < n))) return -4;
@@ -1058,14 +847,11 @@ int crp_spmm_csr_f64(crp_csr_dev_p A, int layout, int n, const double *B0, long 
     // 0.65 / 0.63; at n = 96 -- a tile of 128 columns three quarters used -- 1.17 / 1.00 / 0.94, at n = 32 1.6 x)
     if (variant == 0 && A->team2_pays && n >= A->team2_min_n && crp::spmm_team2_applicable(a)) v = 5;
     if (v == 5 && (!crp::spmm_team2_applicable(a) || A->nnz == 0 || A->nrow < 8)) v = 3;
-    // narrow operands (24 <= n <= 64): the team kernel that takes several union entries per instruction
+    // narrow operands (24 <= n <= 64) whose R = 8 panels are mostly holes: the team kernel whose lane groups own rows (variant 7)
     {
         crp::Team2NArgs tn;
         tn.G = n <= 32 ? 4 : 2;
-        if (variant == 0 && v != 5 && A->team2_pays && team2n_auto() && n <= 64 && A->nnz > 0 && A->nrow >= 8 && crp::spmm_team2n_applicable(tn, a)) v = 6;
-        if (v == 6 && (!crp::spmm_team2n_applicable(tn, a) || A->nnz == 0 || A->nrow < 8)) v = 3;
-        // ... or, where the panels are mostly holes, the one whose lane groups own rows (variant 7)
-        if (variant == 0 && v != 5 && v != 6 && A->team2_pays && team2r_auto(A) && n <= 64 && A->nnz > 0 && A->nrow >= 8 && crp::spmm_team2r_applicable(tn, a)) v = 7;
+        if (variant == 0 && v != 5 && A->team2_pays && team2r_auto(A) && n <= 64 && A->nnz > 0 && A->nrow >= 8 && crp::spmm_team2r_applicable(tn, a)) v = 7;
         if (v == 7 && (!crp::spmm_team2r_applicable(tn, a) || A->nnz == 0 || A->nrow < 8)) v = 3;
     }
     // the derived formats hold the rows in processing order: their C row map is chosen per launch, AFTER every fallback has
@@ -1075,28 +861,11 @@ int crp_spmm_csr_f64(crp_csr_dev_p A, int layout, int n, const double *B0, long 
     {
         a.rowmap = fmt_map;
         A->last_variant = 5;
-        const int pw = team2_pw(n > 128 ? 2 : 1);
-        const int rc = ensure_team2(A, (hipStream_t) stream, pw);
+        const int rc = ensure_team2(A, (hipStream_t) stream);
         if (rc != 0) return rc;
-        Team2Dev &d = pw == 2 ? A->team2p : A->team2;
         crp::Team2Args t;
-        const int ra = team2_args(A, d, a.rowmap, (hipStream_t) stream, &t);
-        if (ra != 0) return ra;
-        if (d.chain > 0) return (int) crp::spmm_rm_f64_team2p(t, a, (hipStream_t) stream);
+        team2_args(A->team2, &t);
         return (int) crp::spmm_rm_f64_team2(t, a, (hipStream_t) stream);
-    }
-    if (v == 6)
-    {
-        a.rowmap = fmt_map;
-        A->last_variant = 6;
-        const int G = n <= 32 ? 4 : 2;
-        const int rc = ensure_team2n(A, (hipStream_t) stream, G);
-        if (rc != 0) return rc;
-        const Team2NDev &d = A->team2n[G == 2 ? 1 : 0];
-        crp::Team2NArgs t;
-        t.G = d.G; t.nteam = d.nteam; t.ngrid = d.ngrid; t.tgrid = d.tgrid; t.tpanel = d.tpanel; t.tinfo = d.tinfo; t.trec = d.trec; t.tvoff = d.tvoff; t.tval = d.tval;
-        t.tent = nullptr;
-        return (int) crp::spmm_rm_f64_team2n(t, a, (hipStream_t) stream);
     }
     if (v == 7)
     {
@@ -1108,14 +877,13 @@ int crp_spmm_csr_f64(crp_csr_dev_p A, int layout, int n, const double *B0, long 
         {
             // the streams of this matrix would pass their 32-bit offsets: variant 0 goes on with the row-panel kernels, for good
             A->team2r_pays = false;
-            return crp_spmm_csr_f64(A, layout, n, B0, ldB0, B1, ldB1, C, ldC, (getenv("CRPSPMM_TEAM2R") != NULL) ? 3 : 0, stream);
+            return crp_spmm_csr_f64(A, layout, n, B0, ldB0, B1, ldB1, C, ldC, crp::knobs().team2r >= 0 ? 3 : 0, stream);
         }
         if (rc != 0) return rc;
-        Team2NDev &d = A->team2r[G == 2 ? 1 : 0];
+        Team2RDev &d = A->team2r[G == 2 ? 1 : 0];
         crp::Team2NArgs t;
         t.G = d.G; t.nteam = d.nteam; t.ngrid = d.ngrid; t.tgrid = d.tgrid; t.tpanel = d.tpanel; t.tinfo = d.tinfo; t.trec = d.trec; t.tvoff = d.tvoff; t.tval = d.tval;
         t.tent = d.tent;
-        t.rowdma = d.rowdma;
         if (d.rows_epoch != A->rowmap_epoch || d.rows_map != a.rowmap)      // the C rows of the panels, once per row map
         {
             CRP_TRY(crp::team2r_fill_rows(t, a, (hipStream_t) stream));
@@ -1124,19 +892,8 @@ int crp_spmm_csr_f64(crp_csr_dev_p A, int layout, int n, const double *B0, long 
         }
         return (int) crp::spmm_rm_f64_team2r(t, a, (hipStream_t) stream);
     }
-    if (v == 4 && (!crp::spmm_team_applicable(a) || A->b1_rows > 0)) v = 3;   // team kernel: one B source, 256-column tile
     if (v >= 2 && (!crp::spmm_panel_applicable(a) || A->nnz == 0)) v = 1;   // narrow / unaligned operands
     A->last_variant = v;
-    if (v == 4)
-    {
-        a.rowmap = fmt_map;
-        const int rc = ensure_team(A, (hipStream_t) stream);
-        if (rc != 0) return rc;
-        crp::TeamArgs t;
-        t.nteam = A->team.nteam; t.torder = A->team.torder; t.tpanel = A->team.tpanel; t.tptr = A->team.tptr;
-        t.tcol = A->team.tcol; t.tmask = A->team.tmask; t.tvoff = A->team.tvoff; t.tval = A->team.tval;
-        return (int) crp::spmm_rm_f64_team(t, a, (hipStream_t) stream);
-    }
     if (v >= 2)
     {
         a.rowmap = fmt_map;
@@ -1178,10 +935,9 @@ int crp_spmm_csr_f32(crp_csr_dev_p A, int n, const float *B0, long long ldB0, co
                       crp::spmm_team2_applicable_f32(a);
     A->last_variant = team ? 5 : 1;
     if (!team) return (int) crp::spmm_rm_f32_rowgroup(a, (hipStream_t) stream);
-    const int pw = team2_pw(n > 256 ? 2 : 1);
-    const int rc = ensure_team2(A, (hipStream_t) stream, pw);
+    const int rc = ensure_team2(A, (hipStream_t) stream);
     if (rc != 0) return rc;
-    Team2Dev &d = pw == 2 ? A->team2p : A->team2;
+    Team2Dev &d = A->team2;
     if (d.tval32 == nullptr)
     {
         CRP_TRY(hipMalloc((void **) &d.tval32, sizeof(float) * ((size_t) d.value_entries + 1024)));
@@ -1190,9 +946,7 @@ int crp_spmm_csr_f32(crp_csr_dev_p A, int n, const float *B0, long long ldB0, co
     }
     if (A->rowmap_fmt != nullptr) a.rowmap = A->rowmap_fmt;
     crp::Team2Args t;
-    const int ra = team2_args(A, d, a.rowmap, (hipStream_t) stream, &t);
-    if (ra != 0) return ra;
-    if (d.chain > 0) return (int) crp::spmm_rm_f32_team2p(t, a, (hipStream_t) stream);
+    team2_args(d, &t);
     return (int) crp::spmm_rm_f32_team2(t, a, (hipStream_t) stream);
 }
 
@@ -1208,7 +962,7 @@ int crp_csr_dev_resolved_variant(crp_csr_dev_p A, int n)
     return v;
 }
 int crp_csr_dev_last_variant(crp_csr_dev_p A) { return A ? A->last_variant : -1; }
-int crp_csr_dev_lattice(crp_csr_dev_p A) { return A ? ((A->team2.built && A->team2.lattice) || (A->team2p.built && A->team2p.lattice) || (A->team.built && A->team.lattice) ? 1 : 0) : -1; }
+int crp_csr_dev_lattice(crp_csr_dev_p A) { return A ? ((A->team2.built && A->team2.lattice) ? 1 : 0) : -1; }
 
 int crp_panel_format_host(int nrow, const int *rowptr, const int *colidx, const double *val, int R, int *npanel,
                           int **pptr, int **pcol, unsigned **pmask4, double **pval, long long *real_entries,
@@ -1260,22 +1014,6 @@ int crp_team_format_host(int nrow, const int *rowptr, const int *colidx, const d
     return 0;
 }
 
-// (host export only: the streams crp_team2_format_host builds -- CRPSPMM_TEAM2_FORMAT_PW=2: two panels per wave)
-int crp_team2_panels_per_wave(void) { return getenv("CRPSPMM_TEAM2_FORMAT_PW") && atoi(getenv("CRPSPMM_TEAM2_FORMAT_PW")) == 2 && team2_waves() == 8 ? 2 : 1; }
-int crp_team2_waves(void) { return team2_waves(); }
-
-static std::vector<int> g_last_cptr, g_last_cteam;   // chains of the last crp_team2_format_host() (empty: one workgroup per team)
-int crp_team2_format_host_chains(int **cptr, int *nchain, int **cteam, int *nmember)
-{
-    if (cptr == NULL || nchain == NULL || cteam == NULL || nmember == NULL) return -1;
-    *nchain = g_last_cptr.empty() ? 0 : (int) g_last_cptr.size() - 1;
-    *nmember = (int) g_last_cteam.size();
-    *cptr = (int *) malloc(sizeof(int) * (g_last_cptr.size() + 1));
-    *cteam = (int *) malloc(sizeof(int) * (g_last_cteam.size() + 1));
-    if (!g_last_cptr.empty()) memcpy(*cptr, g_last_cptr.data(), sizeof(int) * g_last_cptr.size());
-    if (!g_last_cteam.empty()) memcpy(*cteam, g_last_cteam.data(), sizeof(int) * g_last_cteam.size());
-    return 0;
-}
 static std::vector<int> g_last_tgrid;       // launch grid of the last crp_team2_format_host() (planning / test helper)
 static int g_last_compact = 1;              // ... and whether its value blocks are compact
 int crp_team2_format_host_compact(void) { return g_last_compact; }
@@ -1288,51 +1026,16 @@ int crp_team2_format_host_grid(int **tgrid, int *ngrid)
     return 0;
 }
 
-int crp_team2n_format_host(int nrow, const int *rowptr, const int *colidx, const double *val, int G, int *nteam, int *lattice, int **tpanel,
-                           int **tinfo, unsigned **trec, long long *nrecwords, long long **tvoff, double **tval, long long *nvalent,
-                           int **tgrid, int *ngrid, unsigned **vmap, long long *stats)
-{
-    if (nrow < 0 || rowptr == NULL || (G != 2 && G != 4) || !nteam || !tpanel || !tinfo || !trec || !nrecwords || !tvoff || !tval || !nvalent || !tgrid || !ngrid)
-        return -1;
-    crp::PanelHost h;
-    crp::build_panels(nrow, rowptr, colidx, val, 8, &h, false, false);
-    crp::Team2NHost th;
-    th.G = G;
-    crp::build_team2n(h, nrow, rowptr, colidx, &th);
-    *nteam = th.nteam;
-    if (lattice) *lattice = th.lattice ? 1 : 0;
-    auto dup = [](const void *src, size_t bytes) {
-        void *p = malloc(bytes + 8);
-        if (bytes) memcpy(p, src, bytes);
-        return p;
-    };
-    *tpanel = (int *) dup(th.tpanel.data(), sizeof(int) * th.tpanel.size());
-    *tinfo = (int *) dup(th.tinfo.data(), sizeof(int) * th.tinfo.size());
-    *tgrid = (int *) dup(th.tgrid.data(), sizeof(int) * th.tgrid.size());
-    *ngrid = (int) th.tgrid.size();
-    *trec = (unsigned *) dup(th.trec.data(), sizeof(unsigned) * th.trec.size());
-    *nrecwords = (long long) th.trec.size();
-    *tvoff = (long long *) dup(th.tvoff.data(), sizeof(long long) * th.tvoff.size());
-    *tval = (double *) dup(th.tval.data(), sizeof(double) * (size_t) th.nvalues);
-    *nvalent = th.nvalues;
-    if (vmap) *vmap = (unsigned *) dup(th.vmap.data(), sizeof(unsigned) * th.vmap.size());
-    if (stats) { stats[0] = th.rounds; stats[1] = th.parts; stats[2] = th.slots_filled; }
-    return 0;
-}
-
 int crp_team2r_format_host(int nrow, const int *rowptr, const int *colidx, const double *val, int G, int *nteam, int *lattice, int **tpanel,
                            int **tinfo, unsigned **trec, long long *nrecwords, long long **tvoff, double **tval, long long *nwords,
                            int **tgrid, int *ngrid, unsigned **vmap, long long *stats, unsigned **tent)
 {
-    const int rowdma = (G >> 8) == 1 ? 1 : 2;                               // G + 256: half rounds (one row DMA per wave and round)
-    G &= 0xFF;
     if (nrow < 0 || rowptr == NULL || (G != 2 && G != 4) || !nteam || !tpanel || !tinfo || !trec || !nrecwords || !tvoff || !tval || !nwords || !tgrid || !ngrid)
         return -1;
     crp::PanelHost h;
     crp::build_panels(nrow, rowptr, colidx, val, 8, &h, false, false);
     crp::Team2RHost th;
     th.G = G;
-    th.rowdma = rowdma;
     if (!crp::build_team2r(h, nrow, rowptr, colidx, &th)) return -6;
     *nteam = th.nteam;
     if (lattice) *lattice = th.lattice ? 1 : 0;
@@ -1368,16 +1071,10 @@ int crp_team2_format_host(int nrow, const int *rowptr, const int *colidx, const 
     crp::build_panels(nrow, rowptr, colidx, val, 8, &h, false, false);
     clk.lap("crp_team2_format_host: build_panels (R = 8)");
     crp::Team2Host th;
-    const int pw = crp_team2_panels_per_wave();
-    th.T = pw == 2 ? 16 : team2_waves();
-    th.P = pw;
+    // (the test helper reads CRPSPMM_TEAM2_COMPACT per call: the product reads it once, crp::knobs())
     th.compact = getenv("CRPSPMM_TEAM2_COMPACT") ? atoi(getenv("CRPSPMM_TEAM2_COMPACT")) != 0 : h.fill() < 0.4;
-    // (the test helper reads CRPSPMM_T2_CHAIN per call: the product reads it once, crp::knobs())
-    th.chain = pw == 1 ? (getenv("CRPSPMM_T2_CHAIN") ? atoi(getenv("CRPSPMM_T2_CHAIN")) : crp::knobs().t2_chain) : 0;
     crp::build_team2(h, nrow, rowptr, colidx, &th);
     g_last_compact = th.compact ? 1 : 0;
-    g_last_cptr = th.cptr;
-    g_last_cteam = th.cteam;
     clk.lap("crp_team2_format_host: build_team2");
     g_last_tgrid = th.tgrid;
     *nteam = th.nteam;

@@ -26,6 +26,7 @@
 #include "crpspmm.h"
 #include "rowpara_spmm.h"
 #include "utils.h"
+#include "knobs.h"
 
 namespace {
 
@@ -44,8 +45,7 @@ void rccl_setup(MpiCtx *x)
     int P, me;
     MPI_Comm_size(x->comm, &P);
     MPI_Comm_rank(x->comm, &me);
-    const char *env = getenv("CRPSPMM_EXCHANGE");
-    int want = !(env != NULL && strcmp(env, "host") == 0);
+    int want = !crp::knobs().exchange_host;
     // every rank needs a GPU of its own: compare the PCI bus ids of the ranks of this node
     char mine[64] = {0};
     if (crp_hip_device_bus_id(mine, sizeof(mine)) != 0) want = 0;

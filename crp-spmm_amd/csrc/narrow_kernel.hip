@@ -22,6 +22,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include "kernels.h"
+#include "knobs.h"
 #include "narrow_rows.inc"
 
 namespace crp {
@@ -182,14 +183,13 @@ __global__ __launch_bounds__(256, NP == 2 ? 4 : 7) void spmm_narrow_f64_kernel(
 // n <= 64, even, 16-byte aligned operands, an order laid out for four-wave workgroups (team_waves == 4), R = 8
 bool spmm_narrow_applicable(const PanelArgs &p, const SpmmArgs &a)
 {
-    static const bool on = getenv("CRPSPMM_NARROW") == NULL || atoi(getenv("CRPSPMM_NARROW")) != 0;
     // (NP = 2, i.e. 32 < n <= 64, is built but not chosen on the full-value format: 128 VGPRs leave four waves per SIMD with
     //  one step in flight each -- pwtk stand-in n = 64: 0.168 ms against 0.117 for the row-panel kernel; with 32 lanes per
     //  entry and two entries per instruction it was 0.115: no gain either; at five waves per SIMD (96 VGPRs, the epilogue's
     //  sums spilled) 0.209.  CRPSPMM_NARROW_MAX=64 selects it; p.narrow64 = panels that are mostly holes, on compact values.)
-    const int nmax_env = getenv("CRPSPMM_NARROW_MAX") ? atoi(getenv("CRPSPMM_NARROW_MAX")) : 0;
+    const int nmax_env = knobs().narrow_max;
     const int nmax = nmax_env > 0 ? nmax_env : (p.narrow64 && p.cmo != nullptr ? 64 : 32);
-    return on && p.R == 8 && p.team_waves == 4 && a.n >= 24 && a.n <= nmax && a.n <= 64 && (a.n % 2 == 0) && (a.ldB0 % 2 == 0) && (a.ldC % 2 == 0) &&
+    return p.R == 8 && p.team_waves == 4 && a.n >= 24 && a.n <= nmax && a.n <= 64 && (a.n % 2 == 0) && (a.ldB0 % 2 == 0) && (a.ldC % 2 == 0) &&
            (a.B1 == nullptr || a.ldB1 % 2 == 0) && (((uintptr_t) a.B0 | (uintptr_t) a.B1 | (uintptr_t) a.C) % 16 == 0);
 }
 
@@ -200,8 +200,7 @@ hipError_t spmm_rm_f64_narrow(const PanelArgs &p, const SpmmArgs &a, hipStream_t
     const bool has_b1 = a.B1 != nullptr && p.b1_rows > 0;
     // 32-bit byte offsets: B0 alone, every addressed byte below 4 GiB
     const bool off32 = !has_b1 && (uint64_t) p.b0_rows * (uint64_t) a.ldB0 * 8ull < (1ull << 32);
-    const bool compact_on = getenv("CRPSPMM_NARROW_COMPACT") == NULL || atoi(getenv("CRPSPMM_NARROW_COMPACT")) != 0;
-    const bool compact = compact_on && p.cmo != nullptr && p.cbase != nullptr && p.cval != nullptr;
+    const bool compact = p.cmo != nullptr && p.cbase != nullptr && p.cval != nullptr;
 #define CRP_NARROW_GO(NP_, HB1_, O32_, CP_)                                                                                            \
     hipLaunchKernelGGL((spmm_narrow_f64_kernel<NP_, HB1_, O32_, CP_>), grid, dim3(256), 0, s, p.norder, a.nrow, a.n, p.porder, p.pcol, \
                        CP_ ? p.cmo : p.pmask4, CP_ ? p.cval : p.pval, p.cbase, a.B0, a.ldB0, a.B1, a.ldB1, a.C, a.ldC, a.rowmap)

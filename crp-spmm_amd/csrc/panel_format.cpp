@@ -235,13 +235,11 @@ void build_panels(int nrow, const int *rowptr, const int *colidx, const double *
     // processing order.  CRPSPMM_PANEL_ORDER: 0 natural, 1 breadth-first groups, 2 stride lattice of panels,
     // 3 team schedule (2 and 3 only when the matrix has a stride lattice, else natural); unset = team
     // schedule (R = 8) or panel lattice (R = 4) when a lattice is detected, else breadth-first groups.
-    // CRPSPMM_PANEL_GROUP = panels per breadth-first group.
     out->porder.clear();
     out->psync.clear();
     if (!need_order) return;
-    const char *eo = getenv("CRPSPMM_PANEL_ORDER"), *eg = getenv("CRPSPMM_PANEL_GROUP");
-    const int group = (eg && atoi(eg) > 0) ? atoi(eg) : 16;
-    const int mode = eo ? atoi(eo) : -1;
+    const int group = 16;                                       // panels per breadth-first group
+    const int mode = knobs().panel_order;
     const int chunk = ((((npanel + 3) / 4) + 7) / 8) * 4;      // order positions per XCD (the kernels' block -> XCD map)
     bool done = false;
     out->psync.clear();
@@ -249,15 +247,12 @@ void build_panels(int nrow, const int *rowptr, const int *colidx, const double *
     {
         double D1, D2;
         int M;
-        static const bool force = getenv("CRPSPMM_TEAM_FORCE") != NULL;      // experiment: teams of 4 consecutive panels
-        if (detect_stride_lattice(nrow, rowptr, colidx, R, &D1, &D2, &M) || (force && mode == 3))
+        if (detect_stride_lattice(nrow, rowptr, colidx, R, &D1, &D2, &M))
         {
-            // workgroups of four waves = 2 x 2 teeth.  CRPSPMM_TEAM_WAVES=6 lays the order out for six-wave
-            // workgroups (3 x 2 teeth: fewer B rows cross L2 twice) -- measured slower, 0.44 vs 0.34 ms on the
-            // pwtk stand-in: at 3 waves per SIMD only one six-wave workgroup fits a CU
-            const int tw = getenv("CRPSPMM_TEAM_WAVES") ? atoi(getenv("CRPSPMM_TEAM_WAVES")) : 4;
+            // workgroups of four waves = 2 x 2 teeth (six-wave workgroups, 3 x 2 teeth, were measured slower in round 1: 0.44
+            // against 0.34 ms on the pwtk stand-in -- at 3 waves per SIMD only one six-wave workgroup fits a CU)
             TeamHost th;
-            build_teams(*out, nrow, rowptr, colidx, &th, tw == 6 ? 6 : 4);
+            build_teams(*out, nrow, rowptr, colidx, &th, 4);
             apply_team_schedule(out, th);
             done = true;
         }
@@ -271,24 +266,6 @@ void build_panels(int nrow, const int *rowptr, const int *colidx, const double *
         done = true;
     }
     if (!done) locality_order(*out, group, &out->porder);
-    // experiment hook: a processing order read from a file of npanel int32 (must be a permutation)
-    if (const char *ef = getenv("CRPSPMM_PANEL_ORDER_FILE"); ef != NULL && out->psync.empty())
-    {
-        std::vector<int> perm((size_t) npanel);
-        FILE *f = fopen(ef, "rb");
-        if (f != NULL && npanel > 0 && fread(perm.data(), sizeof(int), (size_t) npanel, f) == (size_t) npanel)
-        {
-            std::vector<char> seen((size_t) npanel, 0);
-            bool ok = true;
-            for (int v : perm)
-            {
-                if (v < 0 || v >= npanel || seen[(size_t) v]) { ok = false; break; }
-                seen[(size_t) v] = 1;
-            }
-            if (ok) out->porder = perm;
-        }
-        if (f != NULL) fclose(f);
-    }
 }
 
 bool detect_stride_lattice(int nrow, const int *rowptr, const int *colidx, int R, double *D1_, double *D2_, int *M_)
@@ -298,9 +275,7 @@ bool detect_stride_lattice(int nrow, const int *rowptr, const int *colidx, int R
     // 8-row buckets up to 2 M rows (the strides of a grid with short lines -- 56 nodes x 3 unknowns = 168 rows -- then
     // separate from the near band: fem3d stand-in, lattice teams of 2 x 2 lines x 2 panels need 5.7 union entries per row
     // against 6.95 for clusters, 0.913 -> 0.838 ms at n = 256), 64-row buckets beyond (one histogram per thread).
-    // CRPSPMM_LATTICE_SH = log2 of the bucket width.
-    static const int SH_env = getenv("CRPSPMM_LATTICE_SH") ? std::max(2, std::min(8, atoi(getenv("CRPSPMM_LATTICE_SH")))) : 0;
-    const int SH = SH_env ? SH_env : (nrow <= (1 << 21) ? 3 : 6);
+    const int SH = nrow <= (1 << 21) ? 3 : 6;                   // log2 of the bucket width
     const size_t nb = ((size_t) nrow >> SH) + 2;
     const int nt = host_threads();
     std::vector<std::vector<long long>> cnt_t((size_t) nt, std::vector<long long>(nb, 0)), sum_t(cnt_t);
@@ -366,7 +341,7 @@ bool detect_stride_lattice(int nrow, const int *rowptr, const int *colidx, int R
     }
     const double ratio = D2 / D1;
     const int M = (int) (ratio + 0.5);
-    static const double d1min = getenv("CRPSPMM_LATTICE_D1MIN") ? atof(getenv("CRPSPMM_LATTICE_D1MIN")) : 8.0;      // teeth of >= 8 panels
+    const double d1min = 8.0;                                   // teeth of >= 8 panels
     if (D1 < d1min * R || M < 2 || std::abs(ratio - M) > 0.02 * M || D2 * 2 > nrow) return false;
     *D1_ = D1;
     *D2_ = D2;
@@ -667,7 +642,7 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
     bool lattice = (np >= 64) && detect_stride_lattice(nrow, rowptr, colidx, R, &D1, &D2, &M);
     clk.lap("build_teams: lattice detection");
     // teams of eight (team2): shape of a team in tooth coordinates, si x sj teeth x st consecutive panels along
-    // the teeth (CRPSPMM_TEAM2_SHAPE=si,sj,st with si * sj * st = 8; "0" = eight consecutive panels even on a lattice)
+    // the teeth
     int si = TI, sj = 2, st = 1;
     if (T >= 8)
     {
@@ -675,12 +650,6 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
         // 4 x 2 x 1 and 5.4 for eight consecutive panels (0.351 / 0.418 / 0.424 ms with the first team2 kernel);
         // teams of sixteen: 2 x 2 x 4
         si = 2; sj = 2; st = T / 4;
-        if (const char *es = getenv("CRPSPMM_TEAM2_SHAPE"); es != NULL)
-        {
-            int a = 0, b = 0, c = 0;
-            if (sscanf(es, "%d,%d,%d", &a, &b, &c) == 3 && a > 0 && b > 0 && c > 0 && a * b * c == T) { si = a; sj = b; st = c; }
-            else if (atoi(es) == 0 && strchr(es, ',') == NULL) lattice = false;
-        }
     }
     out->st = st;
     out->lattice = lattice;
@@ -697,11 +666,8 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
     // Off a lattice, teams of eight are CLUSTERED: the eight panels of a team are picked for the columns they share
     // (greedy_cluster), not for being consecutive -- on a 3-D stencil in natural order eight consecutive panels are
     // a thin strip of one grid line (9.9 union entries per row on the 27-point fem3d stand-in), a cluster is a
-    // compact block (6.9); nlpkkt stand-in 7.1 (its lattice teams) -> 4.4.  CRPSPMM_TEAM2_CLUSTER=0 turns it off.
-    static const bool cluster_on = getenv("CRPSPMM_TEAM2_CLUSTER") == NULL || atoi(getenv("CRPSPMM_TEAM2_CLUSTER")) != 0;
-    static const bool cluster_lattice = getenv("CRPSPMM_TEAM2_CLUSTER") != NULL && atoi(getenv("CRPSPMM_TEAM2_CLUSTER")) == 2;
-    if (T >= 8 && cluster_lattice) lattice = out->lattice = false;
-    bool clustered = T >= 8 && cluster_on && np >= 2 * T;
+    // compact block (6.9); nlpkkt stand-in 7.1 (its lattice teams) -> 4.4.
+    bool clustered = T >= 8 && np >= 2 * T;
     std::vector<int> team_of, slot_of;
     if (clustered)
     {
@@ -712,7 +678,7 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
         // primal rows of the same nodes) fall into one range; for a mesh numbered along its own lines that is the row order.
         // Taken when the panels are of two kinds -- at least 15 % of them hold under half the mean number of entries --;
         // with panels of one size the rule changes nothing but the ties, and the row order is the better seed order
-        // (shell stand-in 0.264 -> 0.275 ms with it, nlpkkt stand-in 2.39 -> 2.12).  CRPSPMM_TEAM2_MIX=0|1 forces.
+        // (shell stand-in 0.264 -> 0.275 ms with it, nlpkkt stand-in 2.39 -> 2.12).
         bool mix = false;
         {
             long long tot = 0;
@@ -722,7 +688,6 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
             for (int q = 0; q < np; q++) small += (2LL * rc[(size_t) q] * np < tot);
             mix = small * 100 >= 15LL * np;
             if (mix_mode >= 0) mix = mix_mode != 0;
-            if (const char *em = getenv("CRPSPMM_TEAM2_MIX")) mix = atoi(em) != 0;
         }
         std::vector<int> pord((size_t) np);
         for (int q = 0; q < np; q++) pord[(size_t) q] = q;
@@ -1041,104 +1006,10 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
     // else the natural order
     out->torder.resize((size_t) nteam);
     for (int g = 0; g < nteam; g++) out->torder[(size_t) g] = g;
-    // Teams of eight and more (the LDS-sharing kernel): recursive bisection of the team graph (team_order.h) -- two teams
-    // are adjacent when one reads a B row whose row of A the other owns, weight = such rows.  The other orders (lattice:
-    // strips of team columns swept along the teeth; clusters: greedy super-teams in slab order) are below.
-    // Measured (MI355X, profiles/r03_schedule_matrix.txt): with the generation-wide absolute rounds and the kernel's generation
-    // barrier the bisection order cuts the bytes fetched beyond L2 as the L2 model predicts (nlpkkt stand-in 10.3 -> 7.9 GB,
-    // pwtk stand-in 0.99 -> 0.94 GB) but the slots that wait for their generation cost more time than the bytes save
-    // (+13 % / +33 %); without the barrier the slots' chains of teams drift apart within a few generations and the alignment
-    // the schedule needs is gone (bytes -6 % / +8 %, time -2 % / +4 %).  So the round-2 orders stay the default and
-    // CRPSPMM_T2_ORDER=bisect selects this one.
-    const bool legacy_order = getenv("CRPSPMM_T2_ORDER") == NULL || strcmp(getenv("CRPSPMM_T2_ORDER"), "bisect") != 0;
-    out->bisected = false;
-    if (T >= 8 && !legacy_order && nteam >= 2 * (T == 16 ? 32 : 64))
-    {
-        const int npanel_all = np;
-        std::vector<int> team_of_panel((size_t) npanel_all, -1);
-        for (int g = 0; g < nteam; g++)
-            for (int w = 0; w < T; w++)
-                if (out->tpanel[(size_t) g * T + w] >= 0) team_of_panel[(size_t) out->tpanel[(size_t) g * T + w]] = g;
-        // directed lists: team -> (owner team of a column it reads, rows)
-        std::vector<std::vector<std::pair<int, int>>> fwd((size_t) nteam);
-        parallel_chunks(nteam, 64, [&](long long b, long long e, int) {
-            std::vector<int> own;
-            for (long long g = b; g < e; g++)
-            {
-                own.clear();
-                for (int c : ucol[(size_t) g])
-                {
-                    if (c < 0) continue;                          // a row of the receive buffer: no row of A behind it
-                    const long long pos = colpos ? (c < nrow ? colpos[c] : -1) : c;
-                    if (pos < 0 || pos >= (long long) nrow) continue;
-                    const int h = team_of_panel[(size_t) (pos / R)];
-                    if (h >= 0 && h != (int) g) own.push_back(h);
-                }
-                std::sort(own.begin(), own.end());
-                std::vector<std::pair<int, int>> &f = fwd[(size_t) g];
-                for (size_t a = 0; a < own.size();)
-                {
-                    size_t z = a;
-                    while (z < own.size() && own[z] == own[a]) z++;
-                    f.push_back({own[a], (int) (z - a)});
-                    a = z;
-                }
-            }
-        });
-        // symmetric CSR: forward lists merged with their transpose (weights added)
-        std::vector<long long> tptr((size_t) nteam + 1, 0);
-        for (int g = 0; g < nteam; g++)
-            for (const auto &pr : fwd[(size_t) g]) tptr[(size_t) pr.first + 1]++;
-        for (int g = 0; g < nteam; g++) tptr[(size_t) g + 1] += tptr[(size_t) g];
-        std::vector<std::pair<int, int>> tr((size_t) tptr[(size_t) nteam]);
-        {
-            std::vector<long long> fillp(tptr.begin(), tptr.end() - 1);
-            for (int g = 0; g < nteam; g++)                      // (ascending g: every transposed list comes out sorted)
-                for (const auto &pr : fwd[(size_t) g]) tr[(size_t) fillp[(size_t) pr.first]++] = {g, pr.second};
-        }
-        std::vector<long long> gptr((size_t) nteam + 1, 0);
-        std::vector<std::vector<std::pair<int, int>>> sym((size_t) nteam);
-        parallel_chunks(nteam, 256, [&](long long b, long long e, int) {
-            for (long long g = b; g < e; g++)
-            {
-                const std::vector<std::pair<int, int>> &f = fwd[(size_t) g];
-                std::vector<std::pair<int, int>> &o = sym[(size_t) g];
-                size_t a = 0;
-                long long z = tptr[(size_t) g];
-                const long long ze = tptr[(size_t) g + 1];
-                while (a < f.size() || z < ze)
-                {
-                    if (z >= ze || (a < f.size() && f[a].first < tr[(size_t) z].first)) o.push_back(f[a++]);
-                    else if (a >= f.size() || tr[(size_t) z].first < f[a].first) o.push_back(tr[(size_t) z++]);
-                    else { o.push_back({f[a].first, f[a].second + tr[(size_t) z].second}); a++; z++; }
-                }
-                gptr[(size_t) g + 1] = (long long) o.size();
-            }
-        });
-        for (int g = 0; g < nteam; g++) gptr[(size_t) g + 1] += gptr[(size_t) g];
-        std::vector<int> gadj((size_t) gptr[(size_t) nteam]), gw((size_t) gptr[(size_t) nteam]), work((size_t) nteam);
-        parallel_chunks(nteam, 256, [&](long long b, long long e, int) {
-            for (long long g = b; g < e; g++)
-            {
-                long long q = gptr[(size_t) g];
-                for (const auto &pr : sym[(size_t) g]) { gadj[(size_t) q] = pr.first; gw[(size_t) q] = pr.second; q++; }
-                work[(size_t) g] = ((int) ucol[(size_t) g].size() + T - 1) / T + 4;
-            }
-        });
-        clk.lap("build_teams: team graph");
-        bisection_order(nteam, gptr, gadj, gw, work, T == 16 ? 32 : 64, &out->torder);
-        out->bisected = true;
-        clk.lap("build_teams: processing order (recursive bisection)");
-        parallel_chunks(nteam, 1024, [&](long long b, long long e, int) {
-            for (long long g = b; g < e; g++)
-            {
-                std::vector<int>().swap(ucol[(size_t) g]);
-                std::vector<uint32_t>().swap(umask[(size_t) g]);
-                std::vector<int>().swap(usrc[(size_t) g]);
-            }
-        });
-        return;
-    }
+    // (A recursive bisection of the team graph with generation-wide absolute rounds and a generation start barrier in the kernel
+    //  was built and measured in round 3 -- profiles/r03_schedule_matrix.txt: the bytes fetched beyond L2 fall as the L2 model
+    //  predicts, nlpkkt stand-in 10.3 -> 7.9 GB, but the slots that wait for their generation cost more time than the bytes
+    //  save, +13 % / +33 %; without the barrier the alignment is gone within a few generations -- and removed in round 4.)
     if (clustered && nteam >= 128)
     {
         // Clustered teams: the workgroups resident on an XCD at one time (64: 32 CUs x 2) start together and walk
@@ -1211,8 +1082,7 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
             for (size_t e = 0; e < edges.size(); e++) { gp[(size_t) edges[e].first + 1]++; ga[e] = edges[e].second; }
             for (int q = 0; q < ns; q++) gp[(size_t) q + 1] += gp[(size_t) q];
             std::vector<int> so;
-            static const int sorder = getenv("CRPSPMM_T2_SORDER") ? atoi(getenv("CRPSPMM_T2_SORDER")) : 1;
-            if (sorder == 0 || ns < 16 || !graph_slab_order(ns, gp, ga, weight, 8, &so))
+            if (ns < 16 || !graph_slab_order(ns, gp, ga, weight, 8, &so))
             {
                 so.resize((size_t) ns);
                 for (int q = 0; q < ns; q++) so[(size_t) q] = q;
@@ -1253,28 +1123,19 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
 }
 
 // ---- team2 streams (panel_format.h) ------------------------------------------------------------------
-static bool phase_env() { return getenv("CRPSPMM_TEAM2_PHASE") == NULL || atoi(getenv("CRPSPMM_TEAM2_PHASE")) != 0; }
-
 void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *colidx, Team2Host *out, const int *colpos)
 {
-    constexpr int D = TEAM2_D, CAP = TEAM2_CAP, TMAX = 16;
-    const int T = out->T == 16 ? 16 : TEAM2_T;                              // panels of a team
-    const int P = (out->P == 2 && T == 16) ? 2 : 1;                         // panels of a wave
-    const int W = T / P;                                                    // waves of a team = slots of a round
-    out->P = P;
-    const bool compact = out->compact || T != TEAM2_T || P != 1;            // (only the default geometry has a full-group instance)
-    out->compact = compact;
-    const int sbits = W == 16 ? 4 : 3, fbase = W == 16 ? 20 : 16;          // slot bits and first flag bit of record word 0
+    constexpr int D = TEAM2_D, CAP = TEAM2_CAP, T = TEAM2_T, W = TEAM2_T;   // panels of a team = waves = slots of a round
+    const bool compact = out->compact;
+    constexpr int sbits = 3, fbase = 16;                                    // slot bits and first flag bit of record word 0
     const size_t blkw = (size_t) 32 * W;                                    // words of a record block (8 rounds x W waves x 4)
     PhaseClock clk;
     released_async<TeamHost> th_owner;                                      // (freed by a background thread)
     TeamHost &th = *th_owner;
     // The balanced passes of build_teams break the ties of the phase key (a lattice team has twenty nodes per key value): in
     // plain column order the nodes of one wave come in runs, the rounds then hold four parts of one wave and none of another,
-    // and a round lasts as long as its busiest wave -- pwtk stand-in 0.304 -> 0.315 ms at n = 256, 0.199 -> 0.210 at n = 128
-    // (CRPSPMM_T2_BALANCED=0; it saves 1.5 s of a 17-s build at nlpkkt240 size).
-    const bool balanced_env = getenv("CRPSPMM_T2_BALANCED") == NULL || atoi(getenv("CRPSPMM_T2_BALANCED")) != 0;
-    build_teams(p, nrow, rowptr, colidx, &th, T, colpos, !phase_env() || balanced_env);
+    // and a round lasts as long as its busiest wave -- pwtk stand-in 0.304 -> 0.315 ms at n = 256, 0.199 -> 0.210 at n = 128.
+    build_teams(p, nrow, rowptr, colidx, &th, T, colpos, true);
     clk.lap("build_team2: build_teams total");
     // Phase key of a union entry: (position of its B row in the processing order) mod S, S = rows a team advances
     // along its sweep (8 x the consecutive panels of a lattice team, 64 for eight consecutive panels).  Teams are
@@ -1282,9 +1143,7 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
     // neighbouring teams sits S positions further in the next one.  Walking every team's union by this key makes
     // all its readers ask for it at the same point of their lives, i.e. within the few microseconds a line
     // survives in the XCD's L2 -- instead of at unrelated moments of 35-microsecond lives.
-    // CRPSPMM_TEAM2_PHASE=0 keeps the balanced order of build_teams().
     const int S = th.lattice ? 8 * th.st : 8 * T;
-    const bool phase = phase_env();
     const int nteam = th.nteam;
     out->nteam = nteam;
     out->lattice = th.lattice;
@@ -1292,7 +1151,7 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
     out->torder = th.torder;
     auto mask_of = [&](size_t q) { return (p.pmask4[q >> 2] >> (8 * (q & 3))) & 0xFFu; };
 
-    struct Part { int slot, first, len, src, bank; };       // bank = which of the wave's P panels
+    struct Part { int slot, first, len, src; };
     struct TeamOut
     {
         int nr = 0, filled = 0, nparts = 0;
@@ -1302,9 +1161,6 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
         // (round, wave) was 126 M heap allocations on the nlpkkt240-size matrix)
         std::vector<Part> ownp;
         std::vector<unsigned char> ownc;
-        // chains only: per round, 1 = the last round of a team of the chain (FLUSH); the team every round belongs to
-        std::vector<unsigned char> rfl;
-        std::vector<int> rmem;
     };
     std::vector<TeamOut> res((size_t) nteam);
     // real union entries of team g
@@ -1337,17 +1193,12 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
         }
         return n;
     };
-    // List scheduler of one team: `nodes` in the order they are to be met; target (optional) = the earliest round of
-    // every node (absolute schedule: a round takes only nodes whose target has come, and stays partly or wholly empty
-    // otherwise); <= T slots per round, <= CAP parts per wave and round, look-ahead 4 T nodes.
-    // Empty slots are marked TEAM2_NOCOL here and written to the records as a row of the team (a fetch nobody reads).
-    // CRPSPMM_T2_AHEAD: rounds a team may take a node before its target (fills the slots its own share of a round leaves
-    // empty; a line survives about four rounds in L2, so one round of slack costs no hit)
-    const int ahead = getenv("CRPSPMM_T2_AHEAD") ? atoi(getenv("CRPSPMM_T2_AHEAD")) : 1;
-    const bool swap_on = (getenv("CRPSPMM_T2_SWAP") == NULL || atoi(getenv("CRPSPMM_T2_SWAP")) != 0) && nteam <= 120000;   // (2 s per 100 k teams on 16 CPUs)
-    const int loadcap = getenv("CRPSPMM_T2_LOADCAP") ? atoi(getenv("CRPSPMM_T2_LOADCAP")) : 0;
-    const bool load_aware = getenv("CRPSPMM_T2_SCHED") != NULL && strcmp(getenv("CRPSPMM_T2_SCHED"), "load") == 0;
-    auto schedule_team = [&](int g, const std::vector<int> &nodes, const int *target) {
+    // List scheduler of one team: `nodes` in the order they are to be met; <= W slots per round, <= CAP parts per wave and
+    // round, look-ahead 4 W nodes.  Empty slots are marked TEAM2_NOCOL here and written to the records as a row of the team
+    // (a fetch nobody reads).  (Measured and removed: a scheduler that picks by the busiest wave's load, a cap on a wave's
+    // load per round -- round 3)
+    const bool swap_on = nteam <= 120000;                                   // (the balance pass costs 2 s per 100 k teams on 16 CPUs)
+    auto schedule_team = [&](int g, const std::vector<int> &nodes) {
         TeamOut &to = res[(size_t) g];
         to.anycol = nodes.empty() ? 0 : th.tcol[(size_t) nodes[0]];
         // the row ranges of every (node, wave), once: byte = first << 4 | len, up to 4 per wave (the look-ahead visits a
@@ -1367,7 +1218,7 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
         std::vector<char> taken(nn, 0);
         size_t head = 0, left = nn;
         {
-            // (one allocation each instead of one per round: the allocator was what the 64 builder threads were waiting for)
+            // (one allocation each instead of one per round: the allocator was what the builder threads were waiting for)
             const size_t est = nn / (size_t) W + nn / (size_t) (4 * W) + 8;
             to.col.reserve(est * (size_t) W);
             to.ownp.reserve(est * (size_t) W * CAP);
@@ -1375,8 +1226,8 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
         }
         while (left > 0)
         {
-            int cnt[TMAX], wload[TMAX];
-            for (int w = 0; w < TMAX; w++) cnt[w] = wload[w] = 0;
+            int cnt[W];
+            for (int w = 0; w < W; w++) cnt[w] = 0;
             int nslot = 0;
             const size_t base_col = to.col.size();
             to.col.resize(base_col + (size_t) W, TEAM2_NOCOL);
@@ -1384,141 +1235,38 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
             to.ownc.resize(to.ownc.size() + (size_t) W, 0);
             while (head < nn && taken[head]) head++;
             int seen = 0;
-            if (load_aware)
-            {
-                // CRPSPMM_T2_SCHED=load: of the open nodes in the look-ahead window the one that leaves the busiest wave of the
-                // round least busy (a part costs about 3 row-FMAs of overhead plus its rows); ties: the earliest
-                int load[TMAX];
-                for (int w = 0; w < TMAX; w++) load[w] = 0;
-                while (nslot < W)
-                {
-                    long best = -1;
-                    int best_max = 1 << 30, best_sum = 1 << 30, look = 0;
-                    for (size_t t = head; t < nn && look < 4 * W; t++)
-                    {
-                        if (taken[t]) continue;
-                        if (target != nullptr && target[t] > to.nr + ahead) break;
-                        look++;
-                        const unsigned char *kk = &rk[t * (size_t) T];
-                        bool fits = true;
-                        int mx = 0, sum = 0;
-                        for (int w = 0; w < W; w++)
-                        {
-                            int need = 0, work = 0;
-                            for (int j = 0; j < P; j++)
-                            {
-                                need += kk[w * P + j];
-                                for (int i = 0; i < kk[w * P + j]; i++) work += 3 + (rr[(t * (size_t) T + (size_t) (w * P + j)) * 4 + (size_t) i] & 15);
-                            }
-                            if (cnt[w] + need > CAP) fits = false;
-                            mx = std::max(mx, load[w] + work);
-                            sum += work;
-                        }
-                        if (!fits) continue;
-                        if (mx < best_max || (mx == best_max && sum > best_sum && false)) { best = (long) t; best_max = mx; best_sum = sum; }
-                    }
-                    if (best < 0) break;
-                    const size_t t = (size_t) best;
-                    const unsigned char *kk = &rk[t * (size_t) T];
-                    const int q = nodes[t];
-                    for (int x = 0; x < T; x++)
-                        for (int i = 0; i < kk[x]; i++)
-                        {
-                            const int w = x / P;
-                            const unsigned char b = rr[(t * (size_t) T + (size_t) x) * 4 + (size_t) i];
-                            Part pt;
-                            pt.first = b >> 4;
-                            pt.len = b & 15;
-                            pt.slot = nslot;
-                            pt.src = th.tsrc[(size_t) q * T + (size_t) x];
-                            pt.bank = x % P;
-                            to.ownp[((size_t) to.nr * W + (size_t) w) * CAP + (size_t) cnt[w]] = pt;
-                            to.ownc[(size_t) to.nr * W + (size_t) w]++;
-                            cnt[w]++;
-                            load[w] += 3 + pt.len;
-                            to.nparts++;
-                        }
-                    to.col[base_col + (size_t) nslot] = th.tcol[(size_t) q];
-                    nslot++;
-                    taken[t] = 1;
-                    left--;
-                    while (head < nn && taken[head]) head++;
-                }
-                if (nslot > 0 || P != 2)
-                {
-                    if (nslot == 0 && (target == nullptr || head >= nn || target[head] <= to.nr + ahead)) { fprintf(stderr, "[FATAL] team2 scheduler: a round placed nothing\n"); abort(); }
-                    to.filled += nslot;
-                    to.nr++;
-                    continue;
-                }
-                // (P = 2 and nothing fits an empty round: the splitting path below)
-            }
             for (size_t t = head; t < nn && nslot < W && seen < 4 * W; t++)
             {
                 if (taken[t]) continue;
-                if (target != nullptr && target[t] > to.nr + ahead) break;         // (targets ascend with t)
                 seen++;
-                unsigned char *kk = &rk[t * (size_t) T];                  // parts of every PANEL; wave of panel x = x / P
+                const unsigned char *kk = &rk[t * (size_t) T];
                 bool fits = true;
                 for (int w = 0; w < W; w++)
-                {
-                    int need = 0, work = 0;
-                    for (int j = 0; j < P; j++)
-                    {
-                        need += kk[w * P + j];
-                        if (loadcap > 0)
-                            for (int i = 0; i < kk[w * P + j]; i++) work += 3 + (rr[(t * (size_t) T + (size_t) (w * P + j)) * 4 + (size_t) i] & 15);
-                    }
-                    if (cnt[w] + need > CAP) fits = false;
-                    // CRPSPMM_T2_LOADCAP: a wave takes no more work in a round than this (a part = 3 + its rows), unless the round is empty
-                    if (loadcap > 0 && nslot > 0 && wload[w] + work > loadcap && work > 0) fits = false;
-                }
-                // With two panels per wave a column that both panels of a wave use in many separate ranges can need more
-                // than CAP parts of that wave: it can never fit.  Met in an EMPTY round it is split: the round takes the
-                // parts of the waves' first panels only, the node stays in the list with the rest and is fetched again.
-                bool split = false;
-                if (!fits && nslot == 0 && P == 2)
-                {
-                    bool alone_fits = true;
-                    for (int w = 0; w < W; w++)
-                        if (kk[w * P] + kk[w * P + 1] > CAP) alone_fits = false;
-                    split = !alone_fits;
-                }
-                if (!fits && !split) continue;
+                    if (cnt[w] + kk[w] > CAP) fits = false;
+                if (!fits) continue;
                 const int q = nodes[t];
-                for (int x = 0; x < T; x++)
-                {
-                    if (split && (x % P) != 0) continue;
-                    for (int i = 0; i < kk[x]; i++)
+                for (int w = 0; w < W; w++)
+                    for (int i = 0; i < kk[w]; i++)
                     {
-                        const int w = x / P;
-                        const unsigned char b = rr[(t * (size_t) T + (size_t) x) * 4 + (size_t) i];
+                        const unsigned char b = rr[(t * (size_t) T + (size_t) w) * 4 + (size_t) i];
                         Part pt;
                         pt.first = b >> 4;
                         pt.len = b & 15;
                         pt.slot = nslot;
-                        pt.src = th.tsrc[(size_t) q * T + (size_t) x];
-                        pt.bank = x % P;
+                        pt.src = th.tsrc[(size_t) q * T + (size_t) w];
                         to.ownp[((size_t) to.nr * W + (size_t) w) * CAP + (size_t) cnt[w]] = pt;
                         to.ownc[(size_t) to.nr * W + (size_t) w]++;
                         cnt[w]++;
-                        wload[w] += 3 + pt.len;
                         to.nparts++;
                     }
-                }
                 to.col[base_col + (size_t) nslot] = th.tcol[(size_t) q];
                 nslot++;
-                if (split)
-                {
-                    for (int x = 0; x < T; x += P) rk[t * (size_t) T + (size_t) x] = 0;      // (done; the second panels' parts remain)
-                    continue;
-                }
                 taken[t] = 1;
                 left--;
             }
-            if (nslot == 0 && (target == nullptr || head >= nn || target[head] <= to.nr + ahead))
+            if (nslot == 0)
             {
-                // (cannot happen: the first open node of an empty round always fits or is split)
+                // (cannot happen: the first open node of an empty round always fits -- a panel has at most 4 row ranges)
                 fprintf(stderr, "[FATAL] team2 scheduler: a round placed nothing\n");
                 abort();
             }
@@ -1529,7 +1277,7 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
     // Balance pass over a team's finished rounds: a round lasts as long as its busiest wave (one barrier per round), so for
     // every pair of consecutive rounds the exchange of one slot of each that lowers (busiest wave of r) + (busiest wave of
     // r + 1) most is made -- rounds stay full (an empty slot is a fetch), a node moves by one round at most per pass (the phase
-    // order it was placed by has that much slack).  Work of a part = 3 + its rows.  CRPSPMM_T2_SWAP=0 skips it.
+    // order it was placed by has that much slack).  Work of a part = 3 + its rows.
     auto balance_rounds = [&](TeamOut &to) {
         const int nr = to.nr;
         if (nr < 2) return;
@@ -1601,14 +1349,10 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
                 }
             }
     };
-    // ---- the launch grid: the order cut into 8 contiguous pieces of equal work (union entries / T + a fixed cost per
+    // ---- the launch grid: the order cut into 8 contiguous pieces of equal work (union entries / W + a fixed cost per
     // team), one per XCD -- pieces of equal team COUNT leave XCDs idle when the teams differ (KKT systems: 27-point primal
-    // rows, short dual rows).  Under the bisection order the cuts fall on multiples of a generation.
-    const int WGS = W == 16 ? 32 : 64;                                  // workgroups resident on an XCD = a generation
-    const bool abs_env = getenv("CRPSPMM_T2_ABS") == NULL || atoi(getenv("CRPSPMM_T2_ABS")) != 0;
-    const bool absolute = th.bisected && abs_env && phase;
-    out->absolute = absolute;
-    out->wgs = WGS;
+    // rows, short dual rows).
+    constexpr int WGS = 64;                                             // workgroups resident on an XCD = a generation
     std::vector<int> cut(9, nteam);
     std::vector<int> nn((size_t) nteam, 0);
     parallel_chunks(nteam, 256, [&](long long b, long long e, int) {
@@ -1627,86 +1371,22 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
             acc += (nn[(size_t) out->torder[(size_t) i]] + W - 1) / W + 4;
             while (x < 8 && acc * 8 >= total * x) cut[(size_t) x++] = i + 1;
         }
-        if (th.bisected)
-            for (int q = 1; q < 8; q++)
-            {
-                const int c = (cut[(size_t) q] + WGS / 2) / WGS * WGS;
-                cut[(size_t) q] = std::max(cut[(size_t) q - 1], std::min(nteam, c));
-            }
     };
     compute_cut();
-    if (!absolute)
-        parallel_chunks(nteam, 32, [&](long long b, long long e, int) {
-            std::vector<int> nodes;
-            for (long long g = b; g < e; g++)
-            {
-                team_nodes((int) g, nodes);
-                if (phase) std::stable_sort(nodes.begin(), nodes.end(), [&](int x, int y) { return key(x) < key(y); });
-                schedule_team((int) g, nodes, nullptr);
-                if (swap_on) balance_rounds(res[(size_t) g]);
-            }
-        });
-    else
-    {
-        // Absolute schedule.  A generation = WGS consecutive teams of an XCD's piece: they become resident together and
-        // must meet a B row they share within the few rounds a line survives in L2.  All of them therefore walk ONE
-        // list: the generation's distinct rows in key order, dealt evenly over R rounds (R = what the team with the
-        // largest union needs); a team fetches its rows in the rounds the list gives them and idles in between, so
-        // teams of different length (27-point primal rows next to 7-point dual rows) stay aligned to the last round.
-        struct Gen { int first, count; };
-        std::vector<Gen> gens;
-        for (int q = 0; q < 8; q++)
-            for (int i = cut[(size_t) q]; i < cut[(size_t) q + 1]; i += WGS) gens.push_back({i, std::min(WGS, cut[(size_t) q + 1] - i)});
-        parallel_chunks((long long) gens.size(), 1, [&](long long b, long long e, int) {
-            std::vector<std::vector<int>> nodes;
-            std::vector<std::pair<uint64_t, int>> all;             // (key << 32 | column key, slot in `where`)
-            std::vector<int> target;
-            for (long long gi = b; gi < e; gi++)
-            {
-                const Gen &G = gens[(size_t) gi];
-                nodes.assign((size_t) G.count, std::vector<int>());
-                all.clear();
-                int R = 1;
-                long long rsum = 0;
-                for (int i = 0; i < G.count; i++)
-                {
-                    const int g = out->torder[(size_t) (G.first + i)];
-                    team_nodes(g, nodes[(size_t) i]);
-                    rsum += ((long long) nodes[(size_t) i].size() + W - 1) / W;
-                    R = std::max(R, ((int) nodes[(size_t) i].size() + W - 1) / W);
-                    for (int q : nodes[(size_t) i]) all.push_back({((uint64_t) (uint32_t) key(q) << 32) | (uint64_t) col_key(th.tcol[(size_t) q]), 0});
-                }
-                std::sort(all.begin(), all.end());
-                all.erase(std::unique(all.begin(), all.end()), all.end());
-                const size_t U = all.size();
-                // rounds of the generation: what its mean team needs plus a margin, not what its largest needs -- a few
-                // large teams would make every other team idle; they run past R instead, late only in their own tail
-                const int rgen_pct = getenv("CRPSPMM_T2_RGEN") ? atoi(getenv("CRPSPMM_T2_RGEN")) : 8;
-                if (rgen_pct > 0) R = std::max(1, std::min(R, (int) ((rsum * (100 + rgen_pct) + 100LL * G.count - 1) / (100LL * G.count))));
-                for (int i = 0; i < G.count; i++)
-                {
-                    const int g = out->torder[(size_t) (G.first + i)];
-                    std::vector<int> &nd = nodes[(size_t) i];
-                    std::vector<std::pair<int, int>> tn(nd.size());       // (target round, union entry)
-                    for (size_t t = 0; t < nd.size(); t++)
-                    {
-                        const uint64_t k = ((uint64_t) (uint32_t) key(nd[t]) << 32) | (uint64_t) col_key(th.tcol[(size_t) nd[t]]);
-                        const size_t rank = (size_t) (std::lower_bound(all.begin(), all.end(), std::make_pair(k, 0)) - all.begin());
-                        tn[t] = {(int) (rank * (size_t) R / U), nd[t]};
-                    }
-                    std::stable_sort(tn.begin(), tn.end(), [](const std::pair<int, int> &x, const std::pair<int, int> &y) { return x.first < y.first; });
-                    target.resize(nd.size());
-                    for (size_t t = 0; t < nd.size(); t++) { target[t] = tn[t].first; nd[t] = tn[t].second; }
-                    schedule_team(g, nd, target.data());
-                }
-            }
-        });
-    }
-
+    parallel_chunks(nteam, 32, [&](long long b, long long e, int) {
+        std::vector<int> nodes;
+        for (long long g = b; g < e; g++)
+        {
+            team_nodes((int) g, nodes);
+            std::stable_sort(nodes.begin(), nodes.end(), [&](int x, int y) { return key(x) < key(y); });
+            schedule_team((int) g, nodes);
+            if (swap_on) balance_rounds(res[(size_t) g]);
+        }
+    });
     clk.lap("build_team2: rounds (phase sort, list scheduler)");
     // ---- lattice teams: the processing order by search over block orders against an L2 model (team_order.h).  CRPSPMM_T2_LATORDER=0
     // keeps the round-2 order (strips of team columns swept along the teeth).
-    if (th.lattice && !absolute && th.lat_key.size() == (size_t) nteam * 3 && knobs().t2_latorder)
+    if (th.lattice && th.lat_key.size() == (size_t) nteam * 3 && knobs().t2_latorder)
     {
         std::vector<const int *> cols((size_t) nteam);
         std::vector<int> nrs((size_t) nteam);
@@ -1720,82 +1400,8 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
         if (changed) compute_cut();
         clk.lap("build_team2: lattice order search");
     }
-    // ---- chains (panel_format.h): the teams of every XCD's run are dealt to chains of at most CH teams.  A run is cut into
-    // super-generations of about WGS * CH teams; inside one, chain j takes teams j, j + nch, j + 2 nch ... -- so the nch <= WGS
-    // workgroups that work through a super-generation are on neighbouring teams of the order at any time, as consecutive
-    // workgroups of a one-team-per-workgroup launch are.  From here on a UNIT is a chain (or a team, without chains).
-    const int CH = (out->chain > 0 && P == 1) ? out->chain : 0;
-    out->chain = CH;
-    out->cptr.clear();
-    out->cteam.clear();
-    std::vector<TeamOut> cres;
-    std::vector<int> ccut(9, 0);                                        // chains of run q: [ccut[q], ccut[q + 1])
-    if (CH > 0)
-    {
-        out->cptr.push_back(0);
-        for (int q = 0; q < 8; q++)
-        {
-            const int t0 = cut[(size_t) q], tx = cut[(size_t) q + 1] - cut[(size_t) q];
-            const int nsg = (int) (((long long) tx + (long long) WGS * CH - 1) / ((long long) WGS * CH));
-            for (int sg = 0; sg < nsg; sg++)
-            {
-                // (cuts on multiples of a generation: under the bisection order a generation is a leaf of the team graph)
-                auto sgcut = [&](int k) { return k >= nsg ? tx : (int) std::min<long long>(tx, ((long long) tx * k / nsg + WGS / 2) / WGS * WGS); };
-                const int b = sgcut(sg), e = sgcut(sg + 1);
-                if (e <= b) continue;
-                const int nch = std::min(WGS, e - b);
-                for (int j = 0; j < nch; j++)
-                {
-                    for (int i = b + j; i < e; i += nch) out->cteam.push_back(out->torder[(size_t) (t0 + i)]);
-                    out->cptr.push_back((int) out->cteam.size());
-                }
-            }
-            ccut[(size_t) q + 1] = (int) out->cptr.size() - 1;
-        }
-        // a column every empty slot of an empty team may fetch (a valid row: the matrix has nonzeros when this format is used)
-        int global_any = 0;
-        for (int g = 0; g < nteam; g++)
-            if (res[(size_t) g].filled > 0) { global_any = res[(size_t) g].anycol; break; }
-        const int nchain = (int) out->cptr.size() - 1;
-        cres.resize((size_t) nchain);
-        parallel_chunks(nchain, 16, [&](long long b, long long e, int) {
-            for (long long c = b; c < e; c++)
-            {
-                TeamOut &co = cres[(size_t) c];
-                co.anycol = global_any;
-                bool have_any = false;
-                for (int k = out->cptr[(size_t) c]; k < out->cptr[(size_t) c + 1]; k++)
-                {
-                    const int g = out->cteam[(size_t) k];
-                    TeamOut &to = res[(size_t) g];
-                    if (to.nr == 0)
-                    {
-                        // (no entries: one round of empty slots, so that the rows of C are cleared at its FLUSH)
-                        to.col.assign((size_t) W, TEAM2_NOCOL);
-                        to.ownp.assign((size_t) W * CAP, Part());
-                        to.ownc.assign((size_t) W, 0);
-                        to.nr = 1;
-                    }
-                    if (!have_any && to.filled > 0) { co.anycol = to.anycol; have_any = true; }
-                    co.col.insert(co.col.end(), to.col.begin(), to.col.begin() + (size_t) to.nr * W);
-                    co.ownp.insert(co.ownp.end(), to.ownp.begin(), to.ownp.begin() + (size_t) to.nr * W * CAP);
-                    co.ownc.insert(co.ownc.end(), to.ownc.begin(), to.ownc.begin() + (size_t) to.nr * W);
-                    co.nr += to.nr;
-                    co.filled += to.filled;
-                    co.nparts += to.nparts;
-                    co.rfl.resize((size_t) co.nr, 0);
-                    co.rfl[(size_t) co.nr - 1] = 1;
-                    co.rmem.resize((size_t) co.nr, g);
-                    std::vector<int>().swap(to.col);
-                    std::vector<Part>().swap(to.ownp);
-                    std::vector<unsigned char>().swap(to.ownc);
-                }
-            }
-        });
-        clk.lap("build_team2: chains");
-    }
-    const int nunit = CH > 0 ? (int) cres.size() : nteam;
-    std::vector<TeamOut> &ures = CH > 0 ? cres : res;
+    const int nunit = nteam;
+    std::vector<TeamOut> &ures = res;
     // ---- layout: record blocks, value streams
     out->tinfo.assign((size_t) nunit * 4, 0);
     out->tpro.assign((size_t) nunit * D * W * 2, 0);
@@ -1845,16 +1451,6 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
     out->tvoff[(size_t) nunit * W] = run;
     out->nvalues = run * TEAM2_VUNIT;
     // launch grid: run x of tgrid = what XCD x processes, in order (the cuts computed above)
-    if (CH > 0)
-    {
-        // (chains: run x = the chains of XCD x, super-generation after super-generation)
-        int cpx = 1;
-        for (int q = 0; q < 8; q++) cpx = std::max(cpx, ccut[(size_t) q + 1] - ccut[(size_t) q]);
-        out->tgrid.assign((size_t) cpx * 8, -1);
-        for (int q = 0; q < 8; q++)
-            for (int i = ccut[(size_t) q]; i < ccut[(size_t) q + 1]; i++) out->tgrid[(size_t) q * cpx + (size_t) (i - ccut[(size_t) q])] = i;
-    }
-    else
     {
         int cpx = 1;
         for (int q = 0; q < 8; q++) cpx = std::max(cpx, cut[(size_t) q + 1] - cut[(size_t) q]);
@@ -1902,7 +1498,6 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
                         // values start at 8 i, row r at 8 i + r, i.e. "prefix" = 8 i + first
                         if (!compact) prefix = 8 * (int) i + pt.first;
                         const uint32_t pos = (uint32_t) (prefix + 7 - pt.first);
-                        x |= (uint32_t) pt.bank << (fbase + 11 + (int) i);       // which of the wave's panels (P = 2)
                         if (i == 0) x |= pos << (fbase + 5);
                         else if (i == 1) y |= pos << 24;
                         else if (i == 2) z |= pos << 20;
@@ -1935,24 +1530,6 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
                     if (r + D - 1 >= to.nr) rec[0] |= 1u << (fbase + 1);                           // TAIL: fewer than D-1 younger rounds in flight
                     if (r == to.nr - 1) rec[0] |= 1u << (fbase + 2);                               // LAST
                     if (w == 0 && (r & 7) == 0 && (r >> 3) + 1 < (to.nr + 7) / 8) rec[0] |= 1u << (fbase + 3);   // RECS: fetch the next record block
-                    if (CH > 0)
-                    {
-                        if (to.rfl[(size_t) r]) rec[0] |= 1u << (fbase + 4);                     // FLUSH: the last round of a team of the chain
-                        // the rounds behind a FLUSH have the wave's C stores in their vmcnt queue: exactly 8 NV of them (+ the load of
-                        // the next panel's rows) when the panel had its 8 rows -- POSTFLUSH --, an unknown number otherwise, or when
-                        // two teams ended within D rounds: TAIL (wait for everything)
-                        int nfl = 0;
-                        bool exact = true;
-                        for (int f = std::max(0, r - D); f < r; f++)
-                            if (to.rfl[(size_t) f])
-                            {
-                                nfl++;
-                                const int pnl = out->tpanel[(size_t) to.rmem[(size_t) f] * W + (size_t) w];
-                                if (pnl < 0 || (long long) pnl * 8 + 8 > (long long) nrow) exact = false;
-                            }
-                        if (nfl == 1 && exact) rec[0] |= 1u << 31;
-                        else if (nfl > 0) rec[0] |= 1u << (fbase + 1);
-                    }
                 }
                 for (int d = 0; d < D; d++)
                 {
@@ -1978,230 +1555,9 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
             std::vector<int>().swap(to.col);
             std::vector<Part>().swap(to.ownp);
             std::vector<unsigned char>().swap(to.ownc);
-            std::vector<unsigned char>().swap(to.rfl);
-            std::vector<int>().swap(to.rmem);
         }
     });
     clk.lap("build_team2: release");
-}
-
-// ---- team2n streams (panel_format.h) ----------------------------------------------------------------------
-void build_team2n(const PanelHost &p, int nrow, const int *rowptr, const int *colidx, Team2NHost *out, const int *colpos)
-{
-    constexpr int W = 8, T = 8;
-    const int G = out->G == 2 ? 2 : 4;
-    out->G = G;
-    const int S = W * G, PMAX = 4 * G;                                       // slots of a round, parts of a wave and round
-    PhaseClock clk;
-    released_async<TeamHost> th_owner;
-    TeamHost &th = *th_owner;
-    build_teams(p, nrow, rowptr, colidx, &th, T, colpos, false);
-    clk.lap("build_team2n: build_teams total");
-    const int nteam = th.nteam;
-    out->nteam = nteam;
-    out->lattice = th.lattice;
-    out->tpanel = th.tpanel;
-    out->torder = th.torder;
-    const int Skey = th.lattice ? 8 * th.st : 8 * T;
-    auto mask_of = [&](size_t q) { return (p.pmask4[q >> 2] >> (8 * (q & 3))) & 0xFFu; };
-    auto key = [&](int q) {
-        const int c = th.tcol[(size_t) q];
-        const long long ps = c >= 0 ? (colpos ? colpos[c] : c) : (long long) (~c);
-        if (th.clustered && c >= 0 && ps / 8 < (long long) th.plocal.size()) return (int) (ps % 8) * 16 + th.plocal[(size_t) (ps / 8)];
-        return (int) (ps % Skey);
-    };
-    struct PartN { unsigned char slot, mask; int src; };
-    struct TeamOutN
-    {
-        int nr = 0, anycol = 0;
-        std::vector<int> col;                 // nr * S (TEAM2_NOCOL = empty)
-        std::vector<PartN> parts;             // (nr * W + w) * PMAX
-        std::vector<unsigned char> pc;        // nr * W: parts of wave w in round r
-    };
-    std::vector<TeamOutN> res((size_t) nteam);
-    parallel_chunks(nteam, 32, [&](long long b, long long e, int) {
-        std::vector<int> nodes;
-        for (long long g = b; g < e; g++)
-        {
-            TeamOutN &to = res[(size_t) g];
-            nodes.clear();
-            for (int q = th.tptr[(size_t) g]; q < th.tptr[(size_t) g + 1]; q++)
-            {
-                bool used = false;
-                for (int w = 0; w < T; w++) used = used || th.tsrc[(size_t) q * T + (size_t) w] >= 0;
-                if (used) nodes.push_back(q);
-            }
-            std::stable_sort(nodes.begin(), nodes.end(), [&](int x, int y) { return key(x) < key(y); });
-            to.anycol = nodes.empty() ? 0 : th.tcol[(size_t) nodes[0]];
-            const size_t nn = nodes.size();
-            std::vector<char> taken(nn, 0);
-            size_t head = 0, left = nn;
-            while (left > 0)
-            {
-                int cnt[W], vals[W];
-                for (int w = 0; w < W; w++) cnt[w] = vals[w] = 0;
-                int nslot = 0;
-                const size_t base_col = to.col.size();
-                to.col.resize(base_col + (size_t) S, TEAM2_NOCOL);
-                to.parts.resize(to.parts.size() + (size_t) W * PMAX);
-                to.pc.resize(to.pc.size() + (size_t) W, 0);
-                while (head < nn && taken[head]) head++;
-                int seen = 0;
-                for (size_t t = head; t < nn && nslot < S && seen < 4 * S; t++)
-                {
-                    if (taken[t]) continue;
-                    seen++;
-                    const int q = nodes[t];
-                    bool fits = true;
-                    for (int w = 0; w < W; w++)
-                    {
-                        const int src = th.tsrc[(size_t) q * T + (size_t) w];
-                        if (src < 0) continue;
-                        if (cnt[w] + 1 > PMAX || vals[w] + __builtin_popcount(mask_of((size_t) src)) > TEAM2N_MAXVAL) fits = false;
-                    }
-                    if (!fits) continue;
-                    for (int w = 0; w < W; w++)
-                    {
-                        const int src = th.tsrc[(size_t) q * T + (size_t) w];
-                        if (src < 0) continue;
-                        PartN pt;
-                        pt.slot = (unsigned char) nslot;
-                        pt.mask = (unsigned char) mask_of((size_t) src);
-                        pt.src = src;
-                        to.parts[((size_t) to.nr * W + (size_t) w) * PMAX + (size_t) cnt[w]] = pt;
-                        cnt[w]++;
-                        vals[w] += __builtin_popcount(pt.mask);
-                        to.pc[(size_t) to.nr * W + (size_t) w]++;
-                    }
-                    to.col[base_col + (size_t) nslot] = th.tcol[(size_t) q];
-                    nslot++;
-                    taken[t] = 1;
-                    left--;
-                }
-                if (nslot == 0) { fprintf(stderr, "[FATAL] team2n scheduler: a round placed nothing\n"); abort(); }
-                to.nr++;
-            }
-        }
-    });
-    clk.lap("build_team2n: rounds");
-    // ---- layout
-    out->tinfo.assign((size_t) nteam * 2, 0);
-    out->tvoff.assign((size_t) nteam * W + 1, 0);
-    long long rec0 = 0, run = 0;
-    out->rounds = out->parts = out->slots_filled = 0;
-    {
-        std::vector<long long> wunits((size_t) nteam * W, 0);
-        parallel_chunks(nteam, 256, [&](long long b, long long e, int) {
-            for (long long g = b; g < e; g++)
-            {
-                const TeamOutN &to = res[(size_t) g];
-                for (int w = 0; w < W; w++)
-                {
-                    long long u = 0;
-                    for (int r = 0; r < to.nr; r++)
-                    {
-                        int nv = 0;
-                        for (int i = 0; i < (int) to.pc[(size_t) r * W + (size_t) w]; i++) nv += __builtin_popcount(to.parts[((size_t) r * W + (size_t) w) * PMAX + (size_t) i].mask);
-                        u += (nv + TEAM2_VUNIT - 1) / TEAM2_VUNIT;
-                    }
-                    wunits[(size_t) g * W + (size_t) w] = u;
-                }
-            }
-        });
-        for (int g = 0; g < nteam; g++)
-        {
-            const TeamOutN &to = res[(size_t) g];
-            out->tinfo[(size_t) g * 2] = to.nr;
-            out->tinfo[(size_t) g * 2 + 1] = (int) rec0;
-            rec0 += to.nr;
-            out->rounds += to.nr;
-            for (int w = 0; w < W; w++)
-            {
-                out->tvoff[(size_t) g * W + (size_t) w] = run;
-                run += wunits[(size_t) g * W + (size_t) w];
-            }
-        }
-    }
-    out->tvoff[(size_t) nteam * W] = run;
-    out->nvalues = run * TEAM2_VUNIT;
-    if (rec0 >= (1LL << 31) / 128) { fprintf(stderr, "[FATAL] team2n format: too many rounds\n"); abort(); }
-    // launch grid: 8 runs of equal rounds
-    {
-        std::vector<int> cut(9, nteam);
-        long long total = 0;
-        for (int g = 0; g < nteam; g++) total += res[(size_t) g].nr + 2;
-        cut[0] = 0;
-        long long acc = 0;
-        int x = 1;
-        for (int i = 0; i < nteam && x < 8; i++)
-        {
-            acc += res[(size_t) out->torder[(size_t) i]].nr + 2;
-            while (x < 8 && acc * 8 >= total * x) cut[(size_t) x++] = i + 1;
-        }
-        int cpx = 1;
-        for (int q = 0; q < 8; q++) cpx = std::max(cpx, cut[(size_t) q + 1] - cut[(size_t) q]);
-        out->tgrid.assign((size_t) cpx * 8, -1);
-        for (int q = 0; q < 8; q++)
-            for (int i = cut[(size_t) q]; i < cut[(size_t) q + 1]; i++) out->tgrid[(size_t) q * cpx + (size_t) (i - cut[(size_t) q])] = out->torder[(size_t) i];
-    }
-    parallel_fill(out->trec, (size_t) (rec0 + 1) * 128, 0u);
-    parallel_fill(out->tval, (size_t) run * TEAM2_VUNIT + 256, 0.0);
-    big_vector<uint32_t> slot_of;
-    slot_of.resize(p.pcol.size() * 8);
-    parallel_chunks(nteam, 32, [&](long long b, long long e, int) {
-        for (long long g = b; g < e; g++)
-        {
-            const TeamOutN &to = res[(size_t) g];
-            for (int w = 0; w < W; w++)
-            {
-                long long voff = 0;                                           // units, inside the wave's stream
-                const long long e0 = out->tvoff[(size_t) g * W + (size_t) w] * TEAM2_VUNIT;
-                for (int r = 0; r < to.nr; r++)
-                {
-                    uint32_t *rec = &out->trec[((size_t) out->tinfo[(size_t) g * 2 + 1] + (size_t) r) * 128 + (size_t) w * 16];
-                    const PartN *pp = &to.parts[((size_t) r * W + (size_t) w) * PMAX];
-                    const int np_ = to.pc[(size_t) r * W + (size_t) w];
-                    long long at = e0 + voff * TEAM2_VUNIT;
-                    int nv = 0;
-                    for (int i = 0; i < np_; i++)
-                    {
-                        const int step = i / G, qq = i % G;
-                        rec[6 + 2 * step] |= (uint32_t) pp[i].mask << (8 * qq);
-                        rec[7 + 2 * step] |= (uint32_t) pp[i].slot << (5 * qq);
-                        for (int rr = 0; rr < 8; rr++)
-                            if ((pp[i].mask >> rr) & 1)
-                            {
-                                out->tval[(size_t) at] = p.pval[(size_t) pp[i].src * 8 + (size_t) rr];
-                                slot_of[(size_t) pp[i].src * 8 + (size_t) rr] = (uint32_t) at;
-                                at++;
-                                nv++;
-                            }
-                    }
-                    rec[0] = (uint32_t) np_ | ((uint32_t) nv << 8);
-                    rec[1] = (uint32_t) voff;
-                    for (int qq = 0; qq < G; qq++)
-                    {
-                        const int c = to.col[(size_t) r * S + (size_t) (w * G + qq)];
-                        rec[2 + qq] = (uint32_t) (c != TEAM2_NOCOL ? c : to.anycol);
-                    }
-                    voff += (nv + TEAM2_VUNIT - 1) / TEAM2_VUNIT;
-                }
-            }
-        }
-    });
-    for (int g = 0; g < nteam; g++)
-    {
-        const TeamOutN &to = res[(size_t) g];
-        for (int r = 0; r < to.nr; r++)
-            for (int sl = 0; sl < S; sl++) out->slots_filled += to.col[(size_t) r * S + (size_t) sl] != TEAM2_NOCOL;
-        for (unsigned char c : to.pc) out->parts += c;
-    }
-    clk.lap("build_team2n: records, value streams");
-    out->vmap.resize(p.pmap.size());
-    parallel_chunks((long long) p.pmap.size(), 1 << 18, [&](long long b, long long e, int) {
-        for (long long nz = b; nz < e; nz++) out->vmap[(size_t) nz] = slot_of[(size_t) p.pmap[(size_t) nz]];
-    });
-    clk.lap("build_team2n: value-update map");
 }
 
 // ---- team2r streams (panel_format.h) ----------------------------------------------------------------------
@@ -2210,8 +1566,7 @@ bool build_team2r(const PanelHost &p, int nrow, const int *rowptr, const int *co
     constexpr int W = 8, T = 8;
     const int G = out->G == 2 ? 2 : 4;
     out->G = G;
-    const int RD = out->rowdma == 1 ? 1 : 2;
-    out->rowdma = RD;
+    constexpr int RD = TEAM2R_ROWDMA;
     const int S = 8 * G * RD, SLOTB = 1024 / G, PERW = G * RD;              // slots of a round, bytes of a slot, slots a wave fetches
     const int ZERO = team2r_zero(RD);
     PhaseClock clk;
@@ -2228,23 +1583,16 @@ bool build_team2r(const PanelHost &p, int nrow, const int *rowptr, const int *co
     out->lattice = th.lattice;
     out->tpanel = th.tpanel;
     out->torder = th.torder;
-    const int Skey = th.lattice ? 8 * th.st : 8 * T;
     auto mask_of = [&](size_t q) { return (p.pmask4[q >> 2] >> (8 * (q & 3))) & 0xFFu; };
     // Order of a team's union entries over its rounds.  team2 sorts by a PHASE (position mod 8 first) so that its parts are
     // contiguous row ranges; here a round should give every row of a panel about the same number of nonzeros (a wave's steps are
     // the maximum over its 8 rows): the natural order of the columns does that -- a run of consecutive columns is one mesh line,
     // which the 8 consecutive rows of a panel touch alike -- where the phase order gives a round the columns that only one or two
-    // of the 8 rows have (nlpkkt stand-in: 2.7 padded steps per nonzero against 1.3 with this order).  CRPSPMM_T2R_KEY=phase: the
-    // team2 order.
-    const bool phase_key = getenv("CRPSPMM_T2R_KEY") != NULL && strcmp(getenv("CRPSPMM_T2R_KEY"), "phase") == 0;
+    // of the 8 rows have (nlpkkt stand-in: 2.7 padded steps per nonzero against 1.3 with this order).
     auto key = [&](int q) -> long long {
         const int c = th.tcol[(size_t) q];
-        const long long ps = c >= 0 ? (colpos ? colpos[c] : c) : (1LL << 40) + (long long) (~c);
-        if (!phase_key) return ps;
-        if (th.clustered && c >= 0 && ps / 8 < (long long) th.plocal.size()) return (ps % 8) * 16 + th.plocal[(size_t) (ps / 8)];
-        return ps % Skey;
+        return c >= 0 ? (long long) (colpos ? colpos[c] : c) : (1LL << 40) + (long long) (~c);
     };
-    const bool deal = getenv("CRPSPMM_T2R_DEAL") != NULL && atoi(getenv("CRPSPMM_T2R_DEAL")) != 0;
     struct ItemR { unsigned char slot; int src; };                            // a panel entry of a wave placed on a slot of the round
     struct TeamOutR
     {
@@ -2269,20 +1617,8 @@ bool build_team2r(const PanelHost &p, int nrow, const int *rowptr, const int *co
                 if (used) nodes.push_back(q);
             }
             std::stable_sort(nodes.begin(), nodes.end(), [&](int x, int y) { return key(x) < key(y); });
-            // CRPSPMM_T2R_DEAL=1: ... dealt out to the rounds like cards (round r takes the entries r, r + R, r + 2 R, ... of that
-            // order), so that every round is a uniform sample of the team's columns and every wave finds about 1 / R of its nonzeros
-            // in it -- a wave waits at the round's barrier for the wave with the most steps.  Mean / max steps of a round's waves
-            // 0.59 -> 0.86, and slower (nlpkkt stand-in n = 32 0.576 against 0.500 ms, nlpkkt240 size 8.15 against 7.83): consecutive
-            // columns in a round are consecutive B rows in time for every team of the XCD.  Off.
-            if (deal && nodes.size() > (size_t) S)
-            {
-                const size_t nn0 = nodes.size(), R = (nn0 + (size_t) S - 1) / (size_t) S;
-                std::vector<int> dealt;
-                dealt.reserve(nn0);
-                for (size_t r = 0; r < R; r++)
-                    for (size_t t = r; t < nn0; t += R) dealt.push_back(nodes[t]);
-                nodes.swap(dealt);
-            }
+            // (dealing the ordered entries out to the rounds like cards, so that the waves of a round have equal steps -- mean / max
+            //  0.59 -> 0.86 -- was 15 % slower: consecutive columns in a round are consecutive B rows in time for every team of the XCD)
             to.anycol = nodes.empty() ? 0 : th.tcol[(size_t) nodes[0]];
             to.iptr.push_back(0);
             const size_t nn = nodes.size();

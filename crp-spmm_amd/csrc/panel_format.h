@@ -19,13 +19,14 @@
 #include <time.h>
 #include <vector>
 #include "par.h"
+#include "knobs.h"
 
 namespace crp {
 
 // CRPSPMM_TIMING=1: phase times of the format builders on stderr
 struct PhaseClock
 {
-    bool on = getenv("CRPSPMM_TIMING") != NULL && atoi(getenv("CRPSPMM_TIMING")) != 0;
+    bool on = knobs().timing;
     double t0 = now();
     static double now() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double) ts.tv_sec + 1e-9 * (double) ts.tv_nsec; }
     void lap(const char *what)
@@ -119,7 +120,6 @@ struct TeamHost
     std::vector<long long> tq;     // per panel-format entry: its entry index in the value streams, or -1
     big_vector<int>       tsrc;    // T per union entry: the panel-format entry of wave w behind it, or -1
     long long real_entries = 0;    // union entries before padding
-    bool bisected = false;         // torder = recursive bisection of the team graph (team_order.h): a generation = 64 (T = 16: 32) consecutive teams
     std::vector<int>      lat_key; // lattice teams: 3 per team -- team column (a, b) and position t along the teeth (team_order.h, lattice_block_order)
 };
 // colpos (optional, matrices in a locality order): position of row c of A in the order the panels were built on.
@@ -135,29 +135,28 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
 void apply_team_schedule(PanelHost *p, const TeamHost &t);
 
 // ---- team2: the streams of the LDS-sharing kernel of csrc/team2_kernel.hip ---------------------------
-// A team is T panels on W = T / P waves of one workgroup (T = 8, P = 1: 512 threads; T = 16, P = 1: 1024 threads; T = 16,
-// P = 2: 512 threads, every wave owns two panels -- two banks of accumulators -- for operands of one 16-byte piece per
-// lane).  The union of their columns is walked in rounds of up to W union entries ("slots"); wave w fetches slot w of a
-// round (one B row slice) by LDS-DMA into a ring shared by the workgroup, TEAM2_D rounds ahead.  What a wave owns of a round
-// is a list of at most TEAM2_CAP PARTS: a part is one slot together with a CONTIGUOUS range of the rows of one of its panels
-// that have the column (an entry whose rows are not contiguous is split into several parts), so that the kernel can jump to
-// straight-line code for the range instead of testing a mask bit per row.  Per (round, wave) one 16-byte record
-// (W = 8; W = 16 in brackets):
-//   word 0 : bits 0-2 = number of parts c (0..4); bits 4+3i .. [4+4i ..] = ring slot of part i; flags from bit 16 [20]:
-//            ISSUE (r + D < rounds), TAIL (r + D - 1 >= rounds), LAST round, RECS (wave 0, r % 8 == 0 and a further record
-//            block exists: fetch it now), FLUSH (chains, below); bits 21-26 [25-30] = value position of part 0; bits 27 + i = bank
-//            (panel of the wave, P = 2) of part i; bit 31 = POSTFLUSH (chains)
+// A team is 8 panels on the 8 waves of one 512-thread workgroup.  (Teams of 16 panels on 16 waves, and on 8 waves with two
+// accumulator banks each, were built in rounds 2 - 3, measured 2 - 9 % slower / no faster, and removed in round 4.)  The union of
+// their columns is walked in rounds of up to 8 union entries ("slots"); wave w fetches slot w of a round (one B row slice) by
+// LDS-DMA into a ring shared by the workgroup, TEAM2_D rounds ahead.  What a wave owns of a round is a list of at most TEAM2_CAP
+// PARTS: a part is one slot together with a CONTIGUOUS range of the rows of its panel that have the column (an entry whose rows
+// are not contiguous is split into several parts), so that the kernel can jump to straight-line code for the range instead of
+// testing a mask bit per row.  Per (round, wave) one 16-byte record:
+//   word 0 : bits 0-2 = number of parts c (0..4); bits 4+3i .. = ring slot of part i; flags from bit 16: ISSUE (r + D < rounds),
+//            TAIL (r + D - 1 >= rounds), LAST round, RECS (wave 0, r % 8 == 0 and a further record block exists: fetch it now),
+//            one spare; bits 21-26 = value position of part 0
 //   word 1 : bits 6i .. 6i+5 = range of part i as first * 8 + len - 1; bits 24-29 = value position of part 1;
 //            bits 30-31 = size class q of the value block of round r + TEAM2_D (at most 8 (q + 1) values)
 //   word 2 : bits 0-19 = offset, inside the wave's value stream and in units of TEAM2_VUNIT values, of the block of
 //            round r + TEAM2_D; bits 20-25, 26-31 = value positions of parts 2 and 3
 //   word 3 : column (two-source encoding) of the union entry this wave fetches for round r + TEAM2_D (an empty slot: a row of
 //            the team, fetched and not read)
-// Records are stored in blocks of 8 rounds x W waves (one or two KiB); for the first TEAM2_D rounds the (column, value
-// offset) pairs come from tpro.  A wave's values are COMPACT: a part of len rows holds len values; the parts of a round form
-// one block of the wave's stream (padded to TEAM2_VUNIT values), in the order the wave meets them; part i's value position
-// = (values of the parts before it in the block) + 7 - first_i, what the kernel adds to a lane's row to find its value.
-// The stream of wave w of team g starts at value TEAM2_VUNIT * tvoff[W g + w].
+// Records are stored in blocks of 8 rounds x 8 waves (one KiB); for the first TEAM2_D rounds the (column, value offset) pairs come
+// from tpro.  A wave's values are COMPACT: a part of len rows holds len values; the parts of a round form one block of the wave's
+// stream (padded to TEAM2_VUNIT values), in the order the wave meets them; part i's value position = (values of the parts before
+// it in the block) + 7 - first_i, what the kernel adds to a lane's row to find its value -- or, for well-filled panels
+// (Team2Host::compact = false), 8 values per part: part i's row r at 8 i + r, no position to decode.
+// The stream of wave w of team g starts at value TEAM2_VUNIT * tvoff[8 g + w].
 constexpr int TEAM2_T = 8;
 constexpr int TEAM2_D = 3;
 constexpr int TEAM2_CAP = 4;
@@ -165,11 +164,8 @@ constexpr int TEAM2_VUNIT = 4;                    // value-stream offsets count 
 constexpr int TEAM2_NOCOL = (int) 0x80000000;   // builder-internal mark of an empty slot (the records name a row of the team instead)
 struct Team2Host
 {
-    int T = TEAM2_T;                 // panels per team: 8, or 16 (set before build_team2)
-    bool compact = true;             // value blocks hold only the values that exist; false (T = 8, P = 1 only): 8 values per part,
-                                     // part i's row r at 8 i + r of the round's block -- the kernel then decodes no value position
-    int P = 1;                       // panels per WAVE: 1, or 2 with T = 16 (teams of 16 panels on 8 waves: the narrow-operand
-                                     // instance of the kernel, two accumulator banks per wave); waves = slots of a round = T / P
+    bool compact = true;             // value blocks hold only the values that exist; false: 8 values per part, part i's row r at
+                                     // 8 i + r of the round's block -- the kernel then decodes no value position (set before build_team2)
     int nteam = 0;
     bool lattice = false;
     std::vector<int>       tpanel;   // 8 * nteam: panel of wave w, or -1
@@ -178,24 +174,11 @@ struct Team2Host
                                      // order (a contiguous piece of torder; -1 = no team); the pieces carry equal ROUNDS
     std::vector<int>       tinfo;    // 4 * nteam: rounds, first record block, parts of all waves, filled slots
     std::vector<int>       tpro;     // nteam * TEAM2_D * 8 * 2: {column, value offset} wave w fetches for round d < TEAM2_D
-    big_vector<uint32_t>   trec;     // record blocks: 32 T words each (8 rounds x T waves x 4)
-    std::vector<long long> tvoff;    // 8 * nteam + 1: first value group of wave w's stream
-    big_vector<double>     tval;     // value groups (8 doubles each)
+    big_vector<uint32_t>   trec;     // record blocks: 256 words each (8 rounds x 8 waves x 4)
+    std::vector<long long> tvoff;    // 8 * nteam + 1: first value unit of wave w's stream
+    big_vector<double>     tval;     // the value streams
     std::vector<uint32_t>  vmap;     // per CSR nonzero (panel format's own order of pmap): its slot in tval
-    bool absolute = false;           // rounds are generation-wide absolute rounds (build_team2): the kernel's generation barrier applies
-    int wgs = 64;                    // teams of a generation: the workgroups resident on an XCD (T = 16: 32)
-    long long nvalues = 0;           // values in tval (compact streams, blocks padded to TEAM2_VUNIT)
-    // CHAINS (chain > 0, set before build_team2; P = 1 only): what a PERSISTENT workgroup of csrc/team2p_kernel.hip works through.
-    // A chain is up to `chain` teams of one XCD's run (strided: the resident workgroups of the XCD are on neighbouring teams at
-    // any time); its rounds are the rounds of its teams one after the other in ONE pipeline -- the first rounds of the next team
-    // are in flight during the last rounds of this one.  The last round of every team of a chain carries the FLUSH flag (the wave
-    // stores its panel's C rows, clears its accumulators and turns to its panel of the next team); the three rounds after a
-    // FLUSH carry POSTFLUSH when the wave's panel had all of its 8 rows (the C stores then count exactly 8 NV in the wave's
-    // vmcnt queue) and TAIL otherwise.  A team without entries is given one empty round, so that its rows of C are written.
-    // With chains tinfo / tpro / tvoff / tgrid are PER CHAIN (cptr.size() - 1 of them), records and value streams are laid out
-    // chain by chain; tpanel / torder stay per team.
-    int chain = 0;
-    std::vector<int>       cptr, cteam;   // chain c = teams cteam[cptr[c] .. cptr[c + 1])
+    long long nvalues = 0;           // values in tval (blocks padded to TEAM2_VUNIT)
     long long real_entries = 0;      // union entries (filled slots)
     long long slots = 0;             // slots including the empty ones of partly filled rounds
     long long parts = 0;
@@ -206,46 +189,16 @@ struct Team2Host
 // rows of A, for the phase key of the union order (see build_team2); NULL = the column index itself.
 void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *colidx, Team2Host *out, const int *colpos = nullptr);
 
-// ---- team2n: the streams of the narrow-operand team kernel (csrc/team2n_kernel.hip) -----------------------------------
-// Operands of at most 64 fp64 columns: a B row slice fills a quarter (n <= 32) or half (n <= 64) of a wave, so the kernel takes
-// G = 4 or 2 union entries PER INSTRUCTION (lane group q holds entry q, rows an entry lacks are switched off through EXEC, as in
-// narrow_kernel.hip) -- from the LDS ring of a team, so that a B row slice is requested from L2 once per 64 rows (the row-panel
-// format requests it once per panel entry: 11 against 5 requests per B row on the pwtk stand-in, 10.9 against 4.4 on nlpkkt).
-// Same teams as team2 (8 panels on 8 waves).  A round has 8 G slots; wave w fetches slots w G .. w G + G - 1 with ONE LDS-DMA
-// instruction (lane group q fetches slot w G + q: 1024 / G bytes).  What a wave owns of a round is up to 4 G parts = (slot, row
-// mask) pairs -- no contiguous ranges: the mask does the work --, taken G at a time ("steps").  Its values are compact: one
-// block per round (the present rows of its parts, in part order, padded to TEAM2_VUNIT values).  Record of (round, wave), 16 words:
-//   [0] bits 0-4 parts, bits 8-16 values of the block;  [1] offset of the block in the wave's stream (units of TEAM2_VUNIT);
-//   [2 .. 5] columns (two-source encoding) of the G slots the wave fetches for THIS round (an empty slot: a row of the team);
-//   [6 + 2 s], [7 + 2 s] step s: masks (8 bits per part), slots (5 bits per part);  [14], [15] spare.
-// Records of a round are contiguous (8 waves x 16 words); team g's first round is record tinfo[2 g + 1], it has tinfo[2 g] rounds.
-constexpr int TEAM2N_MAXVAL = 128;             // values of one wave's block (1 KiB of LDS per ring set)
-struct Team2NHost
-{
-    int G = 4;                       // entries per instruction: 4 (n <= 32) or 2 (n <= 64); set before build_team2n
-    int nteam = 0;
-    bool lattice = false;
-    std::vector<int>       tpanel;   // 8 * nteam
-    std::vector<int>       torder;
-    std::vector<int>       tgrid;    // the launch grid, as Team2Host::tgrid
-    std::vector<int>       tinfo;    // 2 * nteam: rounds, first record (in rounds)
-    big_vector<uint32_t>   trec;     // 128 words per round
-    std::vector<long long> tvoff;    // 8 * nteam + 1: first value of wave w's stream (units of TEAM2_VUNIT)
-    big_vector<double>     tval;
-    std::vector<uint32_t>  vmap;     // per CSR nonzero: its index in tval
-    long long nvalues = 0, rounds = 0, parts = 0, slots_filled = 0;
-};
-void build_team2n(const PanelHost &p, int nrow, const int *rowptr, const int *colidx, Team2NHost *out, const int *colpos = nullptr);
-
 // ---- team2r: the streams of the row-owner team kernel (csrc/team2r_kernel.hip) -- narrow operands, panels that are mostly holes --
-// Same teams, same ring idea as team2n, but the lane groups OWN rows: with G = 4 (n <= 32) lane group q of a wave accumulates rows q
+// Operands of at most 64 fp64 columns: a B row slice fills a quarter (n <= 32) or half (n <= 64) of a wave.  Same teams as team2 (8 panels on
+// 8 waves), a ring of row slices shared by the workgroup, and the lane groups OWN rows: with G = 4 (n <= 32) lane group q of a wave accumulates rows q
 // and q + 4 of the wave's panel (G = 2, n <= 64: group q owns rows q, q + 2, q + 4, q + 6), and a STEP gives every row its next
 // nonzero of the round: an LDS byte offset of the B row slice inside the ring set + the value.  No row masks, no EXEC games: a row
 // that has run out of nonzeros in this round gets the value 0.0 and the offset of a slice of zeros (TEAM2R_ZERO) -- so an absent
 // (row, column) pair still is never multiplied with a B entry.  ~1.1 instructions per nonzero where the masked-row step of the
 // narrow kernels spends 57 per four panel entries = 7.7 per nonzero when an entry holds 1.84 of 8 rows (nlpkkt).
-// A round has 16 KiB of slices (rowdma = 2; 8 KiB with rowdma = 1): S = 8 G rowdma slots of 1024 / G bytes; wave w fetches slots
-// G rowdma w .. G rowdma (w + 1) - 1 with rowdma DMA instructions.  What a wave owns of a round: Lp steps (a multiple of 2, at most TEAM2R_LCAP: the scheduler closes a round before a
+// A round has 16 KiB of slices: S = 16 G slots of 1024 / G bytes; wave w fetches slots 2 G w .. 2 G (w + 1) - 1 with
+// TEAM2R_ROWDMA = 2 DMA instructions.  What a wave owns of a round: Lp steps (a multiple of 2, at most TEAM2R_LCAP: the scheduler closes a round before a
 // row would pass it), stored as a BLOCK of the wave's stream: [8 rows][Lp] values (doubles), [8 rows][Lp] offsets (uint16), and a
 // 64-byte HEADER = the wave's record of round r + 2 of the same team (zeros past the team's last round): the kernel issues the DMAs
 // of round r + 2 while it consumes round r, and finds what to fetch in the block that has just landed -- no load on its path.
@@ -256,15 +209,13 @@ void build_team2n(const PanelHost &p, int nrow, const int *rowptr, const int *co
 // tent[(e * 8 + w) * 32]: [0] rounds (0 = no team: the run ends), [1] panel, [2], [3] tvoff (low, high), [4 .. 14) record of round 0,
 // [14 .. 24) record of round 1 (its first 10 words), [24 .. 32) the C rows of the panel's 8 rows (filled on the device from the row map).
 constexpr int TEAM2R_LCAP = 12;
-// rowdma = 1: HALF rounds -- 8 G slots of 1024 / G bytes (8 KiB), one row DMA per wave and round: the ring of a workgroup is 26 KiB
-// instead of 50 and three workgroups fit a CU instead of two.  The zero slice sits behind the slots of a set: offset 8192 * rowdma.
-// (Measured: 0.634 / 1.322 ms against 0.475 / 0.969 at n = 32 / 64 on the nlpkkt stand-in, 9.72 / 21.7 against 7.7 / 17 at nlpkkt240
-//  size -- what a round costs beside its FMAs does not halve with its slots.  An option: CRPSPMM_T2R_ROWDMA=1.)
+// (Half rounds -- 8 KiB ring sets, one row DMA per wave and round, three workgroups per CU -- were measured 33 % slower in round 3
+//  and removed: what a round costs beside its FMAs does not halve with its slots.)  The zero slice sits behind the slots of a set.
+constexpr int TEAM2R_ROWDMA = 2;
 inline int team2r_zero(int rowdma) { return 8192 * rowdma; }
 struct Team2RHost
 {
     int G = 4;
-    int rowdma = 2;                  // row DMA instructions of a wave per round: 2 (16 G slots) or 1 (8 G slots); set before build_team2r
     int nteam = 0;
     bool lattice = false;
     std::vector<int>       tpanel, torder, tgrid, tinfo;

@@ -6,6 +6,7 @@
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
+#include "knobs.h"
 #ifdef __linux__
 #include <sched.h>
 #endif
@@ -48,9 +49,7 @@ inline int usable_cpus()
 
 inline int host_threads()
 {
-    const char *e = getenv("CRPSPMM_NUM_THREADS");
-    if (e == nullptr) e = getenv("OMP_NUM_THREADS");
-    int n = e ? atoi(e) : 0;
+    int n = knobs().num_threads;
     if (n <= 0)
     {
         static const int cpus = usable_cpus();
@@ -116,7 +115,7 @@ struct released_async
     {
         T *q = p;
         p = nullptr;
-        if (getenv("CRPSPMM_SYNC_RELEASE") != nullptr) { delete q; return; }      // (leak checkers: nothing may outlive main)
+        if (knobs().sync_release) { delete q; return; }      // (leak checkers: nothing may outlive main)
         try { std::thread([q] { delete q; }).detach(); }
         catch (...) { delete q; }
     }

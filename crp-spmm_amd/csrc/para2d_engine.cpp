@@ -16,6 +16,7 @@
 #include "crp_engine.h"
 #include "crpspmm_hip.h"
 #include "utils.h"
+#include "knobs.h"
 
 struct crp_para2d_spmm
 {
@@ -83,7 +84,7 @@ static void para2d_init_common(crp_comm_t *comm, int pm, int pn, const int *A0_r
         for (int j = 0; j < pn; j++) { cnt_i[j] = sizeof(int) * (size_t) nnzs[j]; dsp_i[j] = off; off += cnt_i[j]; }
         off = 0;
         for (int j = 0; j < pn; j++) { cnt_v[j] = sizeof(double) * (size_t) nnzs[j]; dsp_v[j] = off; off += cnt_v[j]; }
-        static const bool host_only = getenv("CRPSPMM_REPLICATE") != NULL && strcmp(getenv("CRPSPMM_REPLICATE"), "host") == 0;
+        const bool host_only = crp::knobs().replicate_host;
         if (comm_row->allgatherv_dev != NULL && !plan_only && !host_only && p_nnz > 0)
         {
             // Device replication (reference :81-83: two MPI_Iallgatherv on duplicate communicators): the own slices go

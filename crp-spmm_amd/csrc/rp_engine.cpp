@@ -218,8 +218,7 @@ static void build_plan(crp_rp_spmm *e, int A_nrow, const int *A_rowptr, const in
 static void build_device_matrices(crp_rp_spmm *e, const double *A_val_dev)
 {
     const int m = e->A_nrow;
-    int overlap = 1;
-    GET_ENV_INT_VAR(overlap, "CRPSPMM_OVERLAP", "overlap", 1, 0, 1, e->my_rank == 0);
+    const int overlap = crp::knobs().overlap;
     std::vector<int> rows_int, rows_bnd;
     if (overlap && e->nproc > 1 && e->n_recv_rows > 0)
     {

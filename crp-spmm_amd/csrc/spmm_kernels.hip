@@ -773,19 +773,7 @@ static hipError_t launch_panel_w(const PanelArgs &p, const SpmmArgs &a, hipStrea
     constexpr int TW = 64 * VW * NV;
     const int nwg = (p.norder + WPW - 1) / WPW;
     dim3 grid((nwg + 7) / 8 * 8, (a.n + TW - 1) / TW);      // multiple of 8 for the XCD remap
-    // value delivery: uniform-address LDS broadcast (default) or DPP row_newbcast (CRPSPMM_PANEL_DPP=1: hipcc
-    // needs 216 VGPRs for that body against 160, so it stays an experiment)
-    static const bool dpp = getenv("CRPSPMM_PANEL_DPP") ? atoi(getenv("CRPSPMM_PANEL_DPP")) != 0 : false;
-    if constexpr (DEPTH == 1 && WPW == 4)
-    {
-        if (dpp)
-        {
-            hipLaunchKernelGGL((spmm_panel_f64_kernel<R, NV, VW, DEPTH, ADDR64, HAS_B1, WPW, true>), grid, dim3(64 * WPW), 0, s, p.norder,
-                               a.nrow, a.n, p.porder, p.pptr, p.pcol, p.pmask4, p.pval, a.B0, a.ldB0, a.B1, a.ldB1, a.C, a.ldC, a.rowmap,
-                               p.psync);
-            return hipGetLastError();
-        }
-    }
+    // value delivery: uniform-address LDS broadcast (the DPP row_newbcast body needs 216 VGPRs against 160: not instantiated)
     hipLaunchKernelGGL((spmm_panel_f64_kernel<R, NV, VW, DEPTH, ADDR64, HAS_B1, WPW, false>), grid, dim3(64 * WPW), 0, s, p.norder, a.nrow,
                        a.n, p.porder, p.pptr, p.pcol, p.pmask4, p.pval, a.B0, a.ldB0, a.B1, a.ldB1, a.C, a.ldC, a.rowmap, p.psync);
     return hipGetLastError();
@@ -794,9 +782,7 @@ static hipError_t launch_panel_w(const PanelArgs &p, const SpmmArgs &a, hipStrea
 template <int R, int NV, int VW, int DEPTH, bool ADDR64, bool HAS_B1>
 static hipError_t launch_panel(const PanelArgs &p, const SpmmArgs &a, hipStream_t s)
 {
-    if constexpr (R == 8 && DEPTH == 1)
-        if (p.team_waves == 6) return launch_panel_w<R, NV, VW, DEPTH, ADDR64, HAS_B1, 6>(p, a, s);
-    if (p.team_waves != 4) return hipErrorInvalidValue;      // an order laid out for six-wave teams needs the six-wave body
+    if (p.team_waves != 4) return hipErrorInvalidValue;      // (the order is laid out for four-wave workgroups)
     return launch_panel_w<R, NV, VW, DEPTH, ADDR64, HAS_B1, 4>(p, a, s);
 }
 
@@ -807,19 +793,7 @@ static hipError_t launch_panel_addr(const PanelArgs &p, const SpmmArgs &a, hipSt
     const bool has_b1 = (a.B1 != nullptr) && (p.b1_rows > 0);
     const bool small = ((uint64_t) p.b0_rows * (uint64_t) a.ldB0 * 8ull < (1ull << 32)) &&
                        (!has_b1 || (uint64_t) p.b1_rows * (uint64_t) a.ldB1 * 8ull < (1ull << 32));
-    // ring depth: one set of 8 slots by default.  Two sets (15 entries in flight, CRPSPMM_PANEL_DEPTH=2,
-    // R = 8 wide tiles only) are kept as a measurement knob: hipcc needs 326 VGPRs for that body (one
-    // wave per SIMD) and it runs 40 % slower than the one-set body at three waves per SIMD.
-    static const int env_depth = getenv("CRPSPMM_PANEL_DEPTH") ? atoi(getenv("CRPSPMM_PANEL_DEPTH")) : 0;
-    const bool deep = (env_depth == 2) && p.team_waves == 4;
-    if (deep && R == 8 && NV == 2 && VW == 2)
-    {
-        PanelArgs q = p;
-        q.psync = nullptr;          // the two-set body has no team barriers
-        if (small)
-            return has_b1 ? launch_panel<R, NV, VW, 2, false, true>(q, a, s) : launch_panel<R, NV, VW, 2, false, false>(q, a, s);
-        return has_b1 ? launch_panel<R, NV, VW, 2, true, true>(q, a, s) : launch_panel<R, NV, VW, 2, true, false>(q, a, s);
-    }
+    // ring depth: one set of 8 slots (two sets, 15 entries in flight, need 326 VGPRs and ran 40 % slower: not instantiated)
     if (small)
         return has_b1 ? launch_panel<R, NV, VW, 1, false, true>(p, a, s) : launch_panel<R, NV, VW, 1, false, false>(p, a, s);
     return has_b1 ? launch_panel<R, NV, VW, 1, true, true>(p, a, s) : launch_panel<R, NV, VW, 1, true, false>(p, a, s);
@@ -850,191 +824,6 @@ hipError_t spmm_rm_f64_panel(const PanelArgs &p_, const SpmmArgs &a, hipStream_t
     if (p.R == 4) return launch_panel_shape<4>(p, a, s);
     if (p.R == 8) return launch_panel_shape<8>(p, a, s);
     return hipErrorInvalidValue;
-}
-
-// ---------------------------------------------------------------------------
-// Team kernel: one workgroup = four waves = four panels that share B rows (panel_format.h, TeamHost).
-// The union of the four panels' columns is walked in rounds of 8 entries; the B row slice of every
-// union entry is fetched ONCE, by LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B, no VGPR
-// destination), into a ring of TEAM_NSET sets x 8 slots x 2 KiB shared by the waves, TEAM_D rounds
-// ahead of the round being consumed; wave w loads entries 2w and 2w+1 of a round.  One barrier per
-// round: before it every wave has waited for its own DMAs of that round (counted vmcnt: the DMAs
-// of the following TEAM_D - 1 rounds stay in flight), after it the set is readable by all and the
-// set consumed in the previous round is free for the round issued next.  A wave then takes the
-// entries whose mask byte names it: slice from the ring (2 x ds_read_b128), its 8 values from its
-// own LDS value buffer (the wave's value stream arrives by LDS-DMA too, 16 entries = 1 KiB per
-// chunk, double buffered: scalar loads one entry ahead were tried and stall for the full memory
-// latency under load), masked FMAs as in the row-panel kernel.  The union is walked in a balanced schedule,
-// not in column order, so a row's products are summed in the order the team meets them.
-// Columns: 256-wide tile (16 B per lane x 2), n in (128, 256], operands 16-byte aligned.
-// ---------------------------------------------------------------------------
-constexpr int TEAM_D = 3;
-constexpr int TEAM_NSET = TEAM_D + 1;
-constexpr int TEAM_RING_BYTES = TEAM_NSET * 8 * 2048;
-constexpr int TEAM_LDS_BYTES = TEAM_RING_BYTES + 4 * 2 * 1024;      // + two 1 KiB value buffers per wave
-
-#define CRP_GPTR(p) ((const __attribute__((address_space(1))) void *) (p))
-#define CRP_LPTR(p) ((__attribute__((address_space(3))) void *) (p))
-
-__global__ __launch_bounds__(256) void spmm_team_f64_kernel(
-    const int nteam, const int nrow, const int n, const int *__restrict__ torder, const int *__restrict__ tpanel,
-    const int *__restrict__ tptr, const int *__restrict__ tcol, const uint32_t *__restrict__ tmask,
-    const long long *__restrict__ tvoff, const double *__restrict__ tval,
-    const double *__restrict__ B0, const int64_t ldB0, double *__restrict__ C, const int64_t ldC,
-    const int *__restrict__ rowmap)
-{
-    constexpr int R = 8;
-    extern __shared__ __attribute__((aligned(16))) char team_lds[];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
-    const int cpx  = (int) (gridDim.x >> 3);                  // grid is a multiple of 8 (XCD remap as above)
-    const int wg   = (int) (blockIdx.x & 7) * cpx + (int) (blockIdx.x >> 3);
-    if (wg >= nteam) return;                                  // whole workgroup leaves: no barrier is skipped
-    const int team  = torder[wg];
-    const int panel = __builtin_amdgcn_readfirstlane(tpanel[team * 4 + wave]);
-    const int q0 = tptr[team];
-    const int nr = (tptr[team + 1] - q0) >> 3;                // rounds: the same for the four waves
-
-    // this lane's two 16-byte pieces of a row; lanes past n read the row's first bytes (never used)
-    const bool ok0 = (lane * 2 + 1) < n, ok1 = (128 + lane * 2 + 1) < n;
-    const int off0 = ok0 ? lane * 16 : 0, off1 = ok1 ? 1024 + lane * 16 : 0;
-    const char *Bb = reinterpret_cast<const char *>(B0);
-    const int64_t ldbytes = ldB0 * 8;
-    char *ring = team_lds;
-    // this wave's value stream: 16 entries (1 KiB) per LDS-DMA chunk, two buffers
-    char *vbuf = team_lds + TEAM_RING_BYTES + wave * 2048;
-    const char *vsrc = reinterpret_cast<const char *>(tval + tvoff[team * 4 + wave] * R) + lane * 16;
-    auto issue_vals = [&](const int chunk) {
-        __builtin_amdgcn_global_load_lds(CRP_GPTR(vsrc + (int64_t) chunk * 1024), CRP_LPTR(vbuf + ((chunk & 1) << 10)), 16, 0, 0);
-    };
-
-    auto issue_round = [&](const int r) {
-#if defined(CRP_TEAM_ABL) && CRP_TEAM_ABL == 2   // timing experiment: no B row is loaded
-        return;
-#endif
-        const int qa = q0 + r * 8 + 2 * wave;
-        const int c0 = tcol[qa], c1 = tcol[qa + 1];
-        char *dst = ring + (((r % TEAM_NSET) * 8 + 2 * wave) << 11);
-        const char *r0 = Bb + (int64_t) c0 * ldbytes, *r1 = Bb + (int64_t) c1 * ldbytes;
-        __builtin_amdgcn_global_load_lds(CRP_GPTR(r0 + off0), CRP_LPTR(dst), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(CRP_GPTR(r0 + off1), CRP_LPTR(dst + 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(CRP_GPTR(r1 + off0), CRP_LPTR(dst + 2048), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(CRP_GPTR(r1 + off1), CRP_LPTR(dst + 3072), 16, 0, 0);
-    };
-
-    double acc[R][2][2];
-#pragma unroll
-    for (int r = 0; r < R; r++)
-#pragma unroll
-        for (int v = 0; v < 2; v++) { acc[r][v][0] = 0.0; acc[r][v][1] = 0.0; }
-
-    // prologue: value chunks 0 and 1 (the streams are padded: reading past a wave's last entry is
-    // harmless), then the first TEAM_D rounds of B rows
-    issue_vals(0);
-    issue_vals(1);
-    int iss0 = -100, iss1 = -100;                             // round in which the chunk in buffer 0 / 1 was issued
-#pragma unroll
-    for (int d = 0; d < TEAM_D; d++)
-        if (d < nr) issue_round(d);
-    int k = 0;                                                // own entries consumed so far
-    for (int r = 0; r < nr; r++)
-    {
-        // own DMAs of round r have landed (4 per round issued by this wave; TEAM_D - 1 younger rounds may fly)
-        if (r + TEAM_D - 1 < nr) wait_vmcnt<4 * (TEAM_D - 1)>();
-        else wait_vmcnt<0>();
-        asm volatile("s_barrier" ::: "memory");
-        if (r + TEAM_D < nr) issue_round(r + TEAM_D);         // into the set consumed in round r - 1
-        // the round's 8 mask words in two aligned 16-byte scalar loads (tptr is a multiple of 8)
-        const uint4 mka = *reinterpret_cast<const uint4 *>(tmask + q0 + r * 8);
-        const uint4 mkb = *reinterpret_cast<const uint4 *>(tmask + q0 + r * 8 + 4);
-        const uint32_t mk[8] = {mka.x, mka.y, mka.z, mka.w, mkb.x, mkb.y, mkb.z, mkb.w};
-        const char *setb = ring + ((r % TEAM_NSET) << 14) + lane * 16;
-#pragma unroll
-        for (int e = 0; e < 8; e++)
-        {
-            const uint32_t m = (uint32_t) __builtin_amdgcn_readfirstlane((int) ((mk[e] >> (8 * wave)) & 0xFFu));
-#if defined(CRP_TEAM_ABL) && CRP_TEAM_ABL == 1   // timing experiment: nothing is consumed
-            if (false)
-#else
-            if (m != 0)
-#endif
-            {
-                const int kk = k & 15;
-                if (kk == 0 && k > 0)
-                {
-                    // entering chunk c = k / 16: it was issued when chunk c - 1 was entered; the buffer of
-                    // chunk c - 1 is free for chunk c + 1
-                    const int c = k >> 4;
-                    const int issued = (c & 1) ? iss1 : iss0;
-                    if (r - issued < 3) wait_vmcnt<0>();      // (rare) not yet covered by three round waits
-                    issue_vals(c + 1);
-                    if ((c + 1) & 1) iss1 = r; else iss0 = r;
-                }
-                d2 sl[2], va[4];
-                const uint32_t saddr = (uint32_t) (uintptr_t) (setb + (e << 11));
-                const uint32_t vaddr = (uint32_t) (uintptr_t) (vbuf + (((k >> 4) & 1) << 10) + kk * 64);
-                asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:1024\n\t"
-                             "ds_read_b128 %2, %7\n\tds_read_b128 %3, %7 offset:16\n\t"
-                             "ds_read_b128 %4, %7 offset:32\n\tds_read_b128 %5, %7 offset:48\n\t"
-                             "s_waitcnt lgkmcnt(0)"
-                             : "=&v"(sl[0]), "=&v"(sl[1]), "=&v"(va[0]), "=&v"(va[1]), "=&v"(va[2]), "=&v"(va[3])
-                             : "v"(saddr), "v"(vaddr)
-                             : "memory");
-                const double a[R] = {va[0].x, va[0].y, va[1].x, va[1].y, va[2].x, va[2].y, va[3].x, va[3].y};
-                fmac_rows<R, 2, 2>(acc, a, sl, m);
-                k++;
-            }
-        }
-    }
-
-    if (panel >= 0)
-    {
-#pragma unroll
-        for (int r = 0; r < R; r++)
-        {
-            const int row = panel * R + r;
-            if (row < nrow)
-            {
-                double *crow = C + (int64_t) (rowmap ? rowmap[row] : row) * ldC;
-                if (ok0)
-                {
-                    d2 t;
-                    t.x = acc[r][0][0];
-                    t.y = acc[r][0][1];
-                    __builtin_nontemporal_store(t, reinterpret_cast<d2 *>(crow + lane * 2));
-                }
-                if (ok1)
-                {
-                    d2 t;
-                    t.x = acc[r][1][0];
-                    t.y = acc[r][1][1];
-                    __builtin_nontemporal_store(t, reinterpret_cast<d2 *>(crow + 128 + lane * 2));
-                }
-            }
-        }
-    }
-}
-
-bool spmm_team_applicable(const SpmmArgs &a)
-{
-    return a.n > 128 && a.n <= 256 && (a.n % 2 == 0) && (a.ldB0 % 2 == 0) && (a.ldC % 2 == 0) && a.B1 == nullptr &&
-           (((uintptr_t) a.B0 | (uintptr_t) a.C) % 16 == 0);
-}
-
-hipError_t spmm_rm_f64_team(const TeamArgs &t, const SpmmArgs &a, hipStream_t s)
-{
-    static bool attr_set = false;
-    if (!attr_set)
-    {
-        hipError_t e = hipFuncSetAttribute((const void *) spmm_team_f64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           TEAM_LDS_BYTES);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    dim3 grid((t.nteam + 7) / 8 * 8);
-    hipLaunchKernelGGL(spmm_team_f64_kernel, grid, dim3(256), TEAM_LDS_BYTES, s, t.nteam, a.nrow, a.n, t.torder, t.tpanel,
-                       t.tptr, t.tcol, t.tmask, t.tvoff, t.tval, a.B0, a.ldB0, a.C, a.ldC, a.rowmap);
-    return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------

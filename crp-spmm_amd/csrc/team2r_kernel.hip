@@ -425,53 +425,24 @@ hipError_t spmm_rm_f64_team2r(const Team2NArgs &t, const SpmmArgs &a, hipStream_
     // seven teams (and never fewer than are resident): the resident workgroups then work on neighbouring teams -- chains that run
     // for the whole launch drift apart, and with them the B rows their teams share (nlpkkt240 size, n = 32: 7.64 ms with 512
     // workgroups, 7.36 with 2048, 6.90 with 16384, 6.63 with 65536 = chains of 6.7 teams, 7.06 with one team per workgroup).
-    // Eight XCD runs; CRPSPMM_T2R_WGS overrides.
-    static int ncu = 0;
-    if (ncu == 0)
+    // Eight XCD runs.  (Per launch: the device behind the stream may differ from call to call.)
+    int ncu = 256;
     {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipGetLastError();
-        ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ncu = v;
     }
-    const int wgs_env = getenv("CRPSPMM_T2R_WGS") ? atoi(getenv("CRPSPMM_T2R_WGS")) : 0;
     const int run = t.ngrid / 8;                                            // entries of an XCD's run
-    const int per_xcd = std::max(1, std::min(run, wgs_env > 0 ? wgs_env / 8 : std::max(2 * ncu / 8, (run + 6) / 7)));
+    const int per_xcd = std::max(1, std::min(run, std::max(2 * ncu / 8, (run + 6) / 7)));
     dim3 grid(per_xcd * 8);
-    // CRPSPMM_T2R_BLOCKED=1 (experiment): a workgroup's chain = consecutive entries of the run instead of every per_xcd-th
-    const int chain_k = (getenv("CRPSPMM_T2R_BLOCKED") && atoi(getenv("CRPSPMM_T2R_BLOCKED"))) ? (run + per_xcd - 1) / per_xcd : 0;
+    // a workgroup's chain = every per_xcd-th entry of the run (consecutive entries instead: no better, 6.59 against 6.48 ms)
+    const int chain_k = 0;
     unsigned long long *dbg = nullptr;
-    const int stagger = getenv("CRPSPMM_T2R_STAGGER") ? atoi(getenv("CRPSPMM_T2R_STAGGER")) : 1;
-#ifdef T2R_DBG
-    // (build with EXTRA=-DT2R_DBG: s_memtime stamps around the phases of a round, summed over all waves; printed by the next launch)
-    static unsigned long long *dbg_buf = nullptr;
-    if (dbg_buf == nullptr)
-    {
-        if (hipMalloc((void **) &dbg_buf, 64) != hipSuccess) return hipGetLastError();
-        (void) hipMemset(dbg_buf, 0, 64);
-    }
-    else if (getenv("CRPSPMM_T2R_DBG_PRINT"))
-    {
-        unsigned long long h[8];
-        (void) hipDeviceSynchronize();
-        (void) hipMemcpy(h, dbg_buf, 64, hipMemcpyDeviceToHost);
-        (void) hipMemset(dbg_buf, 0, 64);
-        if (h[5] > 0)
-            fprintf(stderr, "[t2r dbg] wave-rounds %llu: per round  wait %.0f  barrier %.0f  issue %.0f (record %.0f, DMAs %.0f)  flush %.0f  consume %.0f (s_memtime ticks)\n", h[5],
-                    (double) h[0] / h[5], (double) h[1] / h[5], (double) h[2] / h[5], (double) h[6] / h[5], (double) h[7] / h[5], (double) h[3] / h[5], (double) h[4] / h[5]);
-    }
-    dbg = dbg_buf;
-#endif
+    const int stagger = 1;
 #define CRP_T2R_GO(G_, HB1_, RD_)                                                                                                                   \
     do                                                                                                                                              \
     {                                                                                                                                               \
-        static bool once = false;                                                                                                                   \
-        if (!once)                                                                                                                                  \
-        {                                                                                                                                           \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&spmm_team2r_kernel<G_, HB1_, RD_>), hipFuncAttributeMaxDynamicSharedMemorySize, t2r_lds(RD_)); \
-            if (e != hipSuccess) return e;                                                                                                          \
-            once = true;                                                                                                                            \
-        }                                                                                                                                           \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&spmm_team2r_kernel<G_, HB1_, RD_>), hipFuncAttributeMaxDynamicSharedMemorySize, t2r_lds(RD_)); \
+        if (e != hipSuccess) return e;                                                                                                              \
         hipLaunchKernelGGL((spmm_team2r_kernel<G_, HB1_, RD_>), grid, dim3(512), t2r_lds(RD_), s, t.ngrid, t.tent, t.tval, a.n, a.B0, a.ldB0, a.B1, a.ldB1, a.C, a.ldC, stagger, chain_k, dbg); \
     } while (0)
 #define CRP_T2R_PICK(RD_)                                                                                       \
@@ -480,8 +451,7 @@ hipError_t spmm_rm_f64_team2r(const Team2NArgs &t, const SpmmArgs &a, hipStream_
         if (t.G == 4) { if (has_b1) CRP_T2R_GO(4, true, RD_); else CRP_T2R_GO(4, false, RD_); }                  \
         else { if (has_b1) CRP_T2R_GO(2, true, RD_); else CRP_T2R_GO(2, false, RD_); }                           \
     } while (0)
-    if (t.rowdma == 1) CRP_T2R_PICK(1);
-    else CRP_T2R_PICK(2);
+    CRP_T2R_PICK(TEAM2R_ROWDMA);
 #undef CRP_T2R_PICK
 #undef CRP_T2R_GO
     return hipGetLastError();

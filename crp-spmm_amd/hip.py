@@ -138,10 +138,8 @@ def team_format_host(rowptr, colidx, val):
 
 
 def team2_format_host(rowptr, colidx, val):
-    """crp_team2_format_host -> dict(nteam, waves W (8 or 16), panels_per_wave P (1; 2 with CRPSPMM_TEAM2_FORMAT_PW=2: wave w owns
-    panels tpanel[g, 2w] and tpanel[g, 2w + 1]), lattice, tpanel[nteam, W * P], tinfo[nteam, 4], tpro[nteam, 3, W, 2],
-    trec (uint32 words), tvoff (units of 4 values), tval (compact value streams), torder, vmap, tgrid[8, entries per XCD]).
-    With chains (nchain > 0; cptr, cteam) tinfo / tpro / tvoff / tgrid are per chain."""
+    """crp_team2_format_host -> dict(nteam, waves W = 8, lattice, tpanel[nteam, 8], tinfo[nteam, 4], tpro[nteam, 3, 8, 2],
+    trec (uint32 words), tvoff (units of 4 values), tval (the value streams), torder, vmap, tgrid[8, entries per XCD])."""
     lib = L.load()
     rp = np.ascontiguousarray(rowptr, dtype=np.int32)
     ci = np.ascontiguousarray(colidx, dtype=np.int32)
@@ -160,62 +158,23 @@ def team2_format_host(rowptr, colidx, val):
                                       C.byref(tpr), C.byref(tr), C.byref(nrw), C.byref(tv), C.byref(tval), C.byref(nve),
                                       C.byref(to), C.byref(vm)), "crp_team2_format_host")
     nt = nteam.value
-    P = int(lib.crp_team2_panels_per_wave())
-    W = 8 if P == 2 else int(lib.crp_team2_waves())
+    P, W = 1, 8
     tg, ng = L.c_int_p(), C.c_int()
     L.check(lib.crp_team2_format_host_grid(C.byref(tg), C.byref(ng)), "crp_team2_format_host_grid")
-    cp, ct, nch, nmem = L.c_int_p(), L.c_int_p(), C.c_int(), C.c_int()
-    L.check(lib.crp_team2_format_host_chains(C.byref(cp), C.byref(nch), C.byref(ct), C.byref(nmem)), "crp_team2_format_host_chains")
 
     def take(ptr, cnt, dt):
         out = np.ctypeslib.as_array(ptr, (max(cnt, 1),))[:cnt].astype(dt).copy()
         L.c_free(C.cast(ptr, C.c_void_p))
         return out
-    nu = nch.value if nch.value > 0 else nt                     # units the per-unit arrays describe: chains, or teams
-    return dict(nteam=nt, nchain=nch.value, cptr=take(cp, nch.value + 1 if nch.value > 0 else 0, np.int32), cteam=take(ct, nmem.value, np.int32),
-                waves=W, panels_per_wave=P, compact=bool(lib.crp_team2_format_host_compact()), lattice=bool(lat.value), tpanel=take(tp, W * P * nt, np.int32).reshape(nt, W * P),
-                tinfo=take(ti, 4 * nu, np.int32).reshape(nu, 4), tpro=take(tpr, 6 * W * nu, np.int32).reshape(nu, 3, W, 2),
-                trec=take(tr, nrw.value, np.uint32), tvoff=take(tv, W * nu + 1, np.int64),
+    return dict(nteam=nt, waves=W, panels_per_wave=P, compact=bool(lib.crp_team2_format_host_compact()), lattice=bool(lat.value), tpanel=take(tp, W * P * nt, np.int32).reshape(nt, W * P),
+                tinfo=take(ti, 4 * nt, np.int32).reshape(nt, 4), tpro=take(tpr, 6 * W * nt, np.int32).reshape(nt, 3, W, 2),
+                trec=take(tr, nrw.value, np.uint32), tvoff=take(tv, W * nt + 1, np.int64),
                 tval=take(tval, nve.value, np.float64), torder=take(to, nt, np.int32),
                 vmap=take(vm, nnz, np.uint32), tgrid=take(tg, ng.value, np.int32).reshape(8, -1))
 
 
-def team2n_format_host(rowptr, colidx, val, G=4):
-    """crp_team2n_format_host -> dict(G, nteam, lattice, tpanel[nteam, 8], tinfo[nteam, 2], trec[rounds, 8, 16] (uint32), tvoff
-    (units of 4 values), tval, tgrid[8, entries per XCD], vmap, rounds, parts, slots_filled)."""
-    lib = L.load()
-    rp = np.ascontiguousarray(rowptr, dtype=np.int32)
-    ci = np.ascontiguousarray(colidx, dtype=np.int32)
-    va = np.ascontiguousarray(val, dtype=np.float64)
-    nnz = int(rp[-1])
-    if ci.size == 0:
-        ci, va = np.zeros(1, np.int32), np.zeros(1)
-    nteam, lat, ng = C.c_int(), C.c_int(), C.c_int()
-    tp, ti, tg = L.c_int_p(), L.c_int_p(), L.c_int_p()
-    tr, vm = C.POINTER(C.c_uint)(), C.POINTER(C.c_uint)()
-    tv = C.POINTER(C.c_longlong)()
-    tval = L.c_dbl_p()
-    nrw, nve = C.c_longlong(), C.c_longlong()
-    stats = (C.c_longlong * 3)()
-    L.check(lib.crp_team2n_format_host(rp.size - 1, rp.ctypes.data_as(L.c_int_p), ci.ctypes.data_as(L.c_int_p), va.ctypes.data_as(L.c_dbl_p),
-                                       int(G), C.byref(nteam), C.byref(lat), C.byref(tp), C.byref(ti), C.byref(tr), C.byref(nrw), C.byref(tv),
-                                       C.byref(tval), C.byref(nve), C.byref(tg), C.byref(ng), C.byref(vm), stats), "crp_team2n_format_host")
-    nt = nteam.value
-
-    def take(ptr, cnt, dt):
-        out = np.ctypeslib.as_array(ptr, (max(cnt, 1),))[:cnt].astype(dt).copy()
-        L.c_free(C.cast(ptr, C.c_void_p))
-        return out
-    return dict(G=int(G), nteam=nt, lattice=bool(lat.value), tpanel=take(tp, 8 * nt, np.int32).reshape(nt, 8),
-                tinfo=take(ti, 2 * nt, np.int32).reshape(nt, 2), trec=take(tr, nrw.value, np.uint32).reshape(-1, 8, 16),
-                tvoff=take(tv, 8 * nt + 1, np.int64), tval=take(tval, nve.value, np.float64),
-                tgrid=take(tg, ng.value, np.int32).reshape(8, -1), vmap=take(vm, nnz, np.uint32),
-                rounds=int(stats[0]), parts=int(stats[1]), slots_filled=int(stats[2]))
-
-
-def team2r_format_host(rowptr, colidx, val, G=4, rowdma=2):
-    """rowdma = 1: half rounds (8 G slots per round, crp_team2r_format_host with G + 256).
-    crp_team2r_format_host -> dict(G, nteam, lattice, tpanel[nteam, 8], tinfo[nteam, 2], trec[rounds, 8, 16] (uint32), tvoff (units
+def team2r_format_host(rowptr, colidx, val, G=4):
+    """crp_team2r_format_host -> dict(G, nteam, lattice, tpanel[nteam, 8], tinfo[nteam, 2], trec[rounds, 8, 16] (uint32), tvoff (units
     of 16 bytes), tval (the streams as float64 words; view as uint16 for the offsets), tgrid[8, -1], vmap, rounds, steps, slots_filled, nnz)."""
     lib = L.load()
     rp = np.ascontiguousarray(rowptr, dtype=np.int32)
@@ -232,7 +191,7 @@ def team2r_format_host(rowptr, colidx, val, G=4, rowdma=2):
     nrw, nwd = C.c_longlong(), C.c_longlong()
     stats = (C.c_longlong * 4)()
     L.check(lib.crp_team2r_format_host(rp.size - 1, rp.ctypes.data_as(L.c_int_p), ci.ctypes.data_as(L.c_int_p), va.ctypes.data_as(L.c_dbl_p),
-                                       int(G) + (256 if int(rowdma) == 1 else 0), C.byref(nteam), C.byref(lat), C.byref(tp), C.byref(ti), C.byref(tr), C.byref(nrw), C.byref(tv),
+                                       int(G), C.byref(nteam), C.byref(lat), C.byref(tp), C.byref(ti), C.byref(tr), C.byref(nrw), C.byref(tv),
                                        C.byref(tval), C.byref(nwd), C.byref(tg), C.byref(ng), C.byref(vm), stats, C.byref(te)), "crp_team2r_format_host")
     nt = nteam.value
 
@@ -240,7 +199,7 @@ def team2r_format_host(rowptr, colidx, val, G=4, rowdma=2):
         out = np.ctypeslib.as_array(ptr, (max(cnt, 1),))[:cnt].astype(dt).copy()
         L.c_free(C.cast(ptr, C.c_void_p))
         return out
-    return dict(G=int(G), rowdma=2 if int(rowdma) != 1 else 1, nteam=nt, lattice=bool(lat.value), tpanel=take(tp, 8 * nt, np.int32).reshape(nt, 8),
+    return dict(G=int(G), rowdma=2, nteam=nt, lattice=bool(lat.value), tpanel=take(tp, 8 * nt, np.int32).reshape(nt, 8),
                 tinfo=take(ti, 2 * nt, np.int32).reshape(nt, 2), trec=take(tr, nrw.value, np.uint32).reshape(-1, 8, 16),
                 tvoff=take(tv, 8 * nt + 1, np.int64), tval=take(tval, nwd.value, np.float64),
                 tgrid=take(tg, ng.value, np.int32).reshape(8, -1), vmap=take(vm, nnz, np.uint32),

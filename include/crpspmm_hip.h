@@ -124,8 +124,8 @@ int crp_csr_dev_reordered(crp_csr_dev_p A);
  * ldB, ldC: the create-time choice (crp_csr_dev_auto_variant), replaced by 5 (team2-R8) from 112 columns on (from 80 when
  * fewer than 35 % of the (row, entry) pairs of the R = 8 panels exist) where 64 consecutive rows share columns, and by 1
  * below 24 columns.  Operands that are not aligned like that fall back (5 -> 3 -> 1): what a product actually launched is
- * crp_csr_dev_last_variant().  Variant 6 (team2n-R8: the team kernel for 24 <= n <= 64, csrc/team2n_kernel.hip) is never
- * chosen by auto unless CRPSPMM_TEAM2N=1: measured slower than the row-panel kernels at every width it covers;
+ * crp_csr_dev_last_variant().  Variants 4 and 6 (the round-1 LDS team kernel, the narrow team kernel of round 3) were
+ * measured slower than what auto picks at every width and removed in round 4: asking for them returns -1;
  * variant 7 (team2r-R8: lane groups own rows, csrc/team2r_kernel.hip) replaces the create-time choice at 24 <= n <= 64 when fewer
  * than 35 % of the (row, entry) pairs of the R = 8 panels exist and 64 consecutive rows share columns (CRPSPMM_TEAM2R=0|1 forces). */
 int crp_csr_dev_resolved_variant(crp_csr_dev_p A, int n);
@@ -176,48 +176,21 @@ int crp_team_format_host(int nrow, const int *rowptr, const int *colidx, const d
  * a part of len rows holds len values; a round's parts form one block (padded to 4 values) of the wave's stream, which
  * starts at tval[4 * tvoff[8g + w]]; part i's first value sits (position_i - 7 + first_i) values into the block.
  * vmap[nz] = index in tval of CSR nonzero nz.  *nvalent = values in tval.  malloc'd copies (caller frees).  Used by the
- * CPU tests, which replay the streams in numpy.
- * With W = crp_team2_waves() = 16 (CRPSPMM_TEAM2_WAVES=16: teams of 16 panels, one 1024-thread workgroup per CU)
- * every "8 waves / 8 slots" above reads 16: tpanel[16g + w], tpro[((3g + d)*16 + w)*2], tvoff[16g + w], record
- * blocks of 8 rounds x 16 waves x 4 words, ring slots 4 bits each from bit 4 of word 0, flags from bit 20, part 0's
- * value position from bit 25 (W = 8: slots 3 bits each, flags from bit 16, position from bit 21). */
-int crp_team2_waves(void);
-/* panels per wave of the streams crp_team2_format_host() builds: 1, or 2 (CRPSPMM_TEAM2_FORMAT_PW=2: teams of 16 panels on 8
- * waves -- tpanel[(8g + w) * 2 + j], j = bank; word 0 bit 27 + i (W = 8) = bank of part i; the instance the library uses for
- * operands of one 16-byte piece per lane, fp64 n <= 128) */
-int crp_team2_panels_per_wave(void);
+ * CPU tests, which replay the streams in numpy. */
 int crp_team2_format_host(int nrow, const int *rowptr, const int *colidx, const double *val, int *nteam, int *lattice,
                           int **tpanel, int **tinfo, int **tpro, unsigned **trec, long long *nrecwords,
                           long long **tvoff, double **tval, long long *nvalent, int **torder, unsigned **vmap);
 /* The launch grid of the streams crp_team2_format_host() built last (process-wide, planning / test helper only): 8 runs
- * of *ngrid / 8 entries, run x = the teams XCD x processes, in order (-1 = none); a generation = 64 (W = 16: 32)
- * consecutive entries of a run.  Slots of a round that hold no B row name a row of the team (fetched, not read). */
+ * of *ngrid / 8 entries, run x = the teams XCD x processes, in order (-1 = none); a generation = 64 consecutive
+ * entries of a run.  Slots of a round that hold no B row name a row of the team (fetched, not read). */
 int crp_team2_format_host_grid(int **tgrid, int *ngrid);
-/* The chains of those streams (CRPSPMM_T2_CHAIN > 0, the default; csrc/team2p_kernel.hip): chain c = teams
- * cteam[cptr[c] .. cptr[c + 1]).  With chains tinfo / tpro / tvoff and the launch grid are per CHAIN (*nchain of them) and a
- * chain's rounds are its teams' rounds one after the other (record flag FLUSH = a team's last round).  *nchain = 0: none. */
-int crp_team2_format_host_chains(int **cptr, int *nchain, int **cteam, int *nmember);
 /* 1 when the value blocks of those streams are compact (a part of len rows holds len values), 0 when every part holds 8
  * values, row r of part i at 8 i + r of the round's block (panels filled to 40 % and more; CRPSPMM_TEAM2_COMPACT=0|1 forces) */
 int crp_team2_format_host_compact(void);
 
-/* Host-only: the streams variant 6 ("team2n-R8", csrc/team2n_kernel.hip: operands of 24 .. 64 fp64 columns) consumes.  Same
- * teams as variant 5 (8 panels of 8 rows on 8 waves); G = 4 (n <= 32) or 2 (n <= 64) union entries are taken per instruction.
- * A round has 8 G ring slots; wave w fetches slots w G .. w G + G - 1.  Team g has tinfo[2g] rounds, its first is round
- * tinfo[2g + 1] of trec, where round r, wave w owns the 16 words at trec[(r * 8 + w) * 16]: [0] parts (bits 0-4) | values of
- * the wave's block (bits 8-16); [1] offset of the block (units of 4 values) in the wave's stream, which starts at
- * tval[4 * tvoff[8g + w]]; [2 .. 2 + G) the columns of the slots the wave fetches for this round (two-source encoding, an empty
- * slot names a row of the team); [6 + 2 s], [7 + 2 s] step s = parts s G .. s G + G - 1: row masks (8 bits each), ring slots
- * (5 bits each).  A block holds the present rows' values of the wave's parts, in part order, rows ascending.  tgrid: the launch
- * grid (8 runs, -1 = none).  vmap[nz] = index in tval of CSR nonzero nz.  stats (3, may be NULL): rounds, parts, filled slots.
- * malloc'd copies (caller frees).  Used by the CPU tests, which replay the streams in numpy. */
-int crp_team2n_format_host(int nrow, const int *rowptr, const int *colidx, const double *val, int G, int *nteam, int *lattice, int **tpanel,
-                           int **tinfo, unsigned **trec, long long *nrecwords, long long **tvoff, double **tval, long long *nvalent,
-                           int **tgrid, int *ngrid, unsigned **vmap, long long *stats);
-
 /* Host-only: the streams variant 7 ("team2r-R8", csrc/team2r_kernel.hip: the row-owner team kernel for operands of 24 .. 64 fp64
  * columns) consumes.  Teams as variant 5.  A round has 8 G d ring slots of 1024 / G bytes (G = 4: n <= 32, 2: n <= 64; d = 2 row DMA
- * instructions per wave and round, or -- G + 256 passed as G -- d = 1: half rounds); wave w fetches slots G d w .. G d (w + 1) - 1.  Round r (from tinfo[2g + 1] on, tinfo[2g] rounds), wave w owns trec[(r * 8 + w) * 16 ..]: [0] Lp =
+ * instructions per wave and round); wave w fetches slots G d w .. G d (w + 1) - 1.  Round r (from tinfo[2g + 1] on, tinfo[2g] rounds), wave w owns trec[(r * 8 + w) * 16 ..]: [0] Lp =
  * steps (multiple of 2, <= 12); [1] first 16-byte unit of its block inside the wave's stream, which starts at byte 16 * tvoff[8g + w]
  * of tval; [2 .. 2 + G d) the columns of the slots the wave fetches for this round.  A block = [8 rows][Lp] doubles, then
  * [8 rows][Lp] uint16, then a 64-byte header = the record of round r + 2 of the same team and wave (zeros past the last round):

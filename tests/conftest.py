@@ -4,6 +4,9 @@ import sys
 import numpy as np
 import pytest
 
+# the library reads its CRPSPMM_* knobs once (csrc/knobs.cpp); the tests change some between calls of one process
+os.environ.setdefault("CRPSPMM_KNOBS_LIVE", "1")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

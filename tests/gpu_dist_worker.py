@@ -112,7 +112,7 @@ def main():
         Cd = torch.full((e - s, n), float("nan"), dtype=torch.float64, device=dev)
         for timing in (True, False):
             eng.set_timing(timing)
-            for variant in (0, 3, 4, 5, 1):
+            for variant in (0, 3, 5, 1):
                 eng.set_variant(variant)
                 Cd.fill_(float("nan"))
                 eng.exec(0, Bd, Cd)

@@ -158,16 +158,9 @@ int main()
             if (t.vmap.size() != a.ci.size()) { printf("FAIL team2 vmap\n"); return 1; }
             for (size_t p2 = 0; p2 < t.vmap.size(); p2++)
                 if (t.vmap[p2] >= t.tval.size() || t.tval[t.vmap[p2]] != a.va[p2]) { printf("FAIL team2 vmap entry %zu\n", p2); return 1; }
-            // the streams of the narrow team kernels (variants 6 and 7), both lane groupings
+            // the streams of the row-owner team kernel (variant 7), both lane groupings
             for (int G : {4, 2})
             {
-                crp::Team2NHost tn;
-                tn.G = G;
-                crp::build_team2n(h8, a.m, a.rp.data(), a.ci.data(), &tn, pos.empty() ? nullptr : pos.data());
-                if (tn.tgrid.size() % 8 || tn.trec.size() < (size_t) tn.rounds * 128 || (long long) tn.tval.size() < tn.nvalues)
-                { printf("FAIL team2n sizes\n"); return 1; }
-                for (size_t p2 = 0; p2 < tn.vmap.size(); p2++)
-                    if (tn.vmap[p2] >= tn.tval.size() || tn.tval[tn.vmap[p2]] != a.va[p2]) { printf("FAIL team2n vmap entry %zu\n", p2); return 1; }
                 crp::Team2RHost tr;
                 tr.G = G;
                 if (!crp::build_team2r(h8, a.m, a.rp.data(), a.ci.data(), &tr, pos.empty() ? nullptr : pos.data())) { printf("FAIL team2r refused\n"); return 1; }

@@ -56,7 +56,7 @@ def test_random_products(crp, orc, gpu, seed, monkeypatch):
         if split:
             B1 = torch.zeros((k - k0, n + pad), dtype=torch.float64, device=gpu)
             B1[:, :n] = torch.from_numpy(B[k0:]).to(gpu)
-        for variant in (0, 1, 2, 3, 4):
+        for variant in (0, 1, 2, 3, 5):
             Cd = torch.full((m, n + pad), float("nan"), dtype=torch.float64, device=gpu)
             hip.spmm_csr(A, B0[:, :n] if pad else B0, Cd[:, :n] if pad else Cd, n=n, B1=(B1[:, :n] if pad else B1) if split else None,
                          variant=variant)

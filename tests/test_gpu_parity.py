@@ -56,7 +56,7 @@ def test_kernel_vs_oracle_all_widths(crp, orc, gpu, n):
     rp, ci, va = gen.random_csr(m, k, 70, seed=n, empty_every=13)
     B = np.random.default_rng(n).uniform(-2, 2, size=(k, n))
     ref = orc.spmm_csr(rp, ci, va, B)
-    for variant in (0, 1, 2, 3, 4):                    # auto, csr-rowgroup, rowpanel-R4, rowpanel-R8, team-R8
+    for variant in (0, 1, 2, 3, 5):                    # auto, csr-rowgroup, rowpanel-R4, rowpanel-R8, team2-R8
         for ldpad in (0, 1, 2):
             got = _spmm(crp, gpu, rp, ci, va, k, B, n, ldpad=ldpad, variant=variant)
             assert orc.rel_fro_err(ref, got) <= FP64_TOL, (n, ldpad, variant)
@@ -304,21 +304,15 @@ def test_b_block_beyond_4gib(crp, orc, gpu):
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("order", ["default", "0", "1", "2", "3", "3-free", "3-six"])
+@pytest.mark.parametrize("order", ["default", "0", "1", "2", "3"])
 def test_lattice_matrix_team_paths(crp, orc, gpu, monkeypatch, order):
     """A stride-lattice matrix (two nested far strides) through every processing order of the
-    row-panel kernels -- default = team schedule with the per-round workgroup barrier, "3-free" = the
-    same schedule free-running -- and through the LDS-sharing team kernel (variant 4), at widths on
-    both sides of its 256-column tile; then new values on the same pattern (both formats refresh)."""
+    row-panel kernels (default = team schedule with the per-round workgroup barrier) and through the LDS-sharing
+    team kernel (variant 5), at widths on both sides of its 256-column tile; then new values on the same pattern
+    (both formats refresh)."""
     import torch
     from crp_spmm_amd import comm, engine, gen
-    if order == "3-free":
-        monkeypatch.setenv("CRPSPMM_PANEL_ORDER", "3")
-        monkeypatch.setenv("CRPSPMM_TEAM_SYNC", "0")
-    elif order == "3-six":                                 # six-wave workgroups (3 x 2 teeth)
-        monkeypatch.setenv("CRPSPMM_PANEL_ORDER", "3")
-        monkeypatch.setenv("CRPSPMM_TEAM_WAVES", "6")
-    elif order != "default":
+    if order != "default":
         monkeypatch.setenv("CRPSPMM_PANEL_ORDER", order)
     nx, ny, nz = 300, 7, 5
     m = nx * ny * nz + 13                                      # ragged last tooth / partial teams
@@ -333,7 +327,7 @@ def test_lattice_matrix_team_paths(crp, orc, gpu, monkeypatch, order):
         ref = orc.spmm_csr(rp, ci, va, B, fast=True)
         e = engine.RpSpmm(0, m, rp, ci, va, [0, m], n, sc)
         Bd, Cd = _t(B, gpu), torch.empty((m, n), dtype=torch.float64, device=gpu)
-        for variant in (3, 4, 2):
+        for variant in (3, 5, 2):
             e.set_variant(variant)
             Cd.fill_(float("nan"))
             e.exec(0, Bd, Cd)
@@ -344,7 +338,7 @@ def test_lattice_matrix_team_paths(crp, orc, gpu, monkeypatch, order):
             torch.cuda.synchronize()
             assert torch.equal(first, Cd), (order, n, variant, "not reproducible")
         e.update_values(va * 3.0)
-        for variant in (3, 4):
+        for variant in (3, 5):
             e.set_variant(variant)
             e.exec(0, Bd, Cd)
             torch.cuda.synchronize()
@@ -371,7 +365,7 @@ def test_row_subset_matrices(crp, orc, gpu):
     sel[2000::3] = True
     parts = [np.nonzero(sel)[0].astype(np.int32), np.nonzero(~sel)[0].astype(np.int32)]
     Bd = _t(B, gpu)
-    for variant in (1, 2, 3, 4):
+    for variant in (1, 2, 3, 5):
         Cd = torch.full((m, n), -3.0, dtype=torch.float64, device=gpu)
         for pi, rows in enumerate(parts):
             cnt = (rp[rows + 1] - rp[rows]).astype(np.int64)
@@ -404,7 +398,7 @@ def test_row_subset_matrices(crp, orc, gpu):
     sub_rp[1:] = np.cumsum(cnt)
     idx = np.concatenate([np.arange(rp[r], rp[r + 1]) for r in rows])
     sub_ci, sub_va = np.ascontiguousarray(ci[idx]), np.ascontiguousarray(va[idx])
-    for variant in (6, 7):
+    for variant in (7,):
         h = C.c_void_p()
         assert lib.crp_csr_dev_create(rows.size, k, sub_rp.ctypes.data_as(_IP), sub_ci.ctypes.data_as(_IP), sub_va.ctypes.data_as(_DP), C.byref(h)) == 0
         Cd = torch.full((m, n2), -3.0, dtype=torch.float64, device=gpu)
@@ -533,11 +527,6 @@ def test_team2_kernel_vs_oracle(crp, orc, gpu, monkeypatch, n, values):
     B = np.random.default_rng(n + 1).uniform(-2, 2, size=(mm, n))
     got = _spmm(crp, gpu, rp, ci, va, mm, B, n, variant=5)
     assert orc.rel_fro_err(orc.spmm_csr(rp, ci, va, B), got) <= FP64_TOL, ("lattice", n)
-    if n > 256:
-        # more than one column tile: the option that puts a team's tiles on consecutive workgroups (a 1-D launch grid)
-        monkeypatch.setenv("CRPSPMM_T2_TILEMAJOR", "0")
-        got = _spmm(crp, gpu, rp, ci, va, mm, B, n, variant=5)
-        assert orc.rel_fro_err(orc.spmm_csr(rp, ci, va, B), got) <= FP64_TOL, ("lattice, tiles interleaved", n)
 
 
 @pytest.mark.parametrize("values", ["compact", "full"])
@@ -609,7 +598,7 @@ def test_locality_order_all_variants(crp, orc, gpu, monkeypatch):
     A = hip.CsrDev(m, m, rp, ci, va)
     assert lib.crp_csr_dev_reordered(A.handle) == 1
     Bd = _t(B, gpu)
-    for variant in (0, 1, 2, 3, 4, 5):
+    for variant in (0, 1, 2, 3, 5):
         Cd = torch.full((m, n), float("nan"), dtype=torch.float64, device=gpu)
         hip.spmm_csr(A, Bd, Cd, n=n, variant=variant)
         torch.cuda.synchronize()
@@ -658,7 +647,7 @@ def test_locality_order_narrow_fallback_keeps_row_order(crp, orc, gpu, monkeypat
     A = hip.CsrDev(m, m, rp, ci, va)
     assert lib.crp_csr_dev_reordered(A.handle) == 1
     Bd = _t(B, gpu)
-    for variant in (0, 2, 3, 4, 5, 1):
+    for variant in (0, 2, 3, 5, 1):
         Cd = torch.full((m, n), float("nan"), dtype=torch.float64, device=gpu)
         hip.spmm_csr(A, Bd, Cd, n=n, variant=variant)
         torch.cuda.synchronize()
@@ -692,7 +681,7 @@ def test_update_values_device_pointer_before_first_product(crp, orc, gpu, monkey
     ref1 = orc.spmm_csr(rp, ci, va, B)
     Bd = _t(B, gpu)
     v2d = _t(v2, gpu)
-    for variant in (0, 3, 5, 2, 4, 1):
+    for variant in (0, 3, 5, 2, 1):
         A = hip.CsrDev(m, m, rp, ci, va)
         assert lib.crp_csr_dev_update_values(A.handle, v2d.data_ptr(), None) == 0
         Cd = torch.full((m, n), float("nan"), dtype=torch.float64, device=gpu)
@@ -756,94 +745,6 @@ def test_grid_2x4_rankwise(crp, orc, gpu, n):
         A.free()
 
 
-@pytest.mark.parametrize("gsync", ["0", "1"])
-def test_team2_bisection_order_absolute_rounds(crp, orc, gpu, monkeypatch, gsync):
-    """CRPSPMM_T2_ORDER=bisect: recursive-bisection team order, generation-wide absolute rounds (rounds with empty
-    slots: row DMAs with EXEC = 0, NOVAL records), with and without the kernel's generation start barrier
-    (CRPSPMM_T2_GSYNC=1; bounded wait) -- on the nlpkkt stand-in (mixed primal / dual teams), a stride-lattice matrix
-    and with a second B source.  Same product as every other variant."""
-    import torch
-    from crp_spmm_amd import gen, hip
-    monkeypatch.setenv("CRPSPMM_T2_ORDER", "bisect")
-    monkeypatch.setenv("CRPSPMM_T2_GSYNC", gsync)
-    offs = tuple(range(1, 15)) + tuple(range(304, 310)) + tuple(range(3040, 3046))
-    for name, (rp, ci, va) in (("kkt", gen.kkt3d(24)), ("lattice", gen.banded_fem(9120 * 2, offsets=offs, seed=3))):
-        m = len(rp) - 1
-        for n in (256, 136):
-            B = np.random.default_rng(3).normal(size=(m, n))
-            ref = orc.spmm_csr(rp, ci, va, B)
-            A = hip.CsrDev(m, m, rp, ci, va)
-            Bd = _t(B, gpu)
-            for rep in range(3):                      # (the barrier's counters carry over from launch to launch)
-                Cd = torch.full((m, n), float("nan"), dtype=torch.float64, device=gpu)
-                hip.spmm_csr(A, Bd, Cd, n=n, variant=5)
-                torch.cuda.synchronize()
-                assert orc.rel_fro_err(ref, Cd.cpu().numpy()) <= FP64_TOL, (name, n, rep)
-            Cf = torch.empty((m, n), dtype=torch.float32, device=gpu)
-            hip.spmm_csr_f32(A, Bd.to(torch.float32), Cf, n=n, variant=5)
-            torch.cuda.synchronize()
-            assert orc.rel_fro_err(ref, Cf.cpu().numpy().astype(np.float64)) <= 1e-5, (name, n)
-            A.free()
-    # two-source index: the upper half of the columns comes from a receive buffer
-    rp, ci, va = gen.kkt3d(24)
-    m = len(rp) - 1
-    half = m // 2
-    two = np.where(ci < half, ci, ~(ci - half)).astype(np.int32)
-    B = np.random.default_rng(4).normal(size=(m, 256))
-    ref = orc.spmm_csr(rp, ci, va, B)
-    A = hip.CsrDev(m, half, rp, two, va)
-    Cd = torch.full((m, 256), float("nan"), dtype=torch.float64, device=gpu)
-    hip.spmm_csr(A, _t(B[:half], gpu), Cd, n=256, B1=_t(B[half:], gpu), variant=5)
-    torch.cuda.synchronize()
-    assert orc.rel_fro_err(ref, Cd.cpu().numpy()) <= FP64_TOL
-    A.free()
-
-
-@pytest.mark.parametrize("n", [24, 64, 100, 128])
-def test_team2_two_panels_per_wave(crp, orc, gpu, monkeypatch, n):
-    """CRPSPMM_TEAM2_PW=2: variant 5 for operands of one 16-byte piece per lane on teams of 16 panels, two panels (two
-    accumulator banks) per wave: lattice, clustered (mixed KKT teams) and random matrices -- the last with columns that need
-    more than four parts of a wave and are split over two rounds --, a second B source, value updates, fp32."""
-    import torch
-    from crp_spmm_amd import gen, hip
-    lib = crp.load()
-    monkeypatch.setenv("CRPSPMM_TEAM2_PW", "2")
-    offs = tuple(range(1, 15)) + tuple(range(304, 310)) + tuple(range(3040, 3046))
-    for name, (rp, ci, va), k in (("lattice", gen.banded_fem(9120, offsets=offs, seed=3), 9120), ("kkt", gen.kkt3d(16), 8192),
-                                   ("random", gen.random_csr(777, 1234, 40, seed=3), 1234)):
-        m = len(rp) - 1
-        B = np.random.default_rng(6).normal(size=(k, n))
-        ref = orc.spmm_csr(rp, ci, va, B)
-        A = hip.CsrDev(m, k, rp, ci, va)
-        Bd = _t(B, gpu)
-        Cd = torch.full((m, n), float("nan"), dtype=torch.float64, device=gpu)
-        hip.spmm_csr(A, Bd, Cd, n=n, variant=5)
-        torch.cuda.synchronize()
-        assert orc.rel_fro_err(ref, Cd.cpu().numpy()) <= FP64_TOL, (name, n)
-        v2 = 0.25 * va - 1.0
-        assert lib.crp_csr_dev_update_values(A.handle, v2.ctypes.data, None) == 0
-        hip.spmm_csr(A, Bd, Cd, n=n, variant=5)
-        torch.cuda.synchronize()
-        assert orc.rel_fro_err(orc.spmm_csr(rp, ci, v2, B), Cd.cpu().numpy()) <= FP64_TOL, (name, n)
-        if n % 4 == 0:
-            Cf = torch.empty((m, n), dtype=torch.float32, device=gpu)
-            hip.spmm_csr_f32(A, Bd.to(torch.float32), Cf, n=n, variant=5)
-            torch.cuda.synchronize()
-            assert orc.rel_fro_err(orc.spmm_csr(rp, ci, v2, B), Cf.cpu().numpy().astype(np.float64)) <= 1e-5, (name, n)
-        A.free()
-    rp, ci, va = gen.kkt3d(16)
-    m = len(rp) - 1
-    half = m // 2
-    two = np.where(ci < half, ci, ~(ci - half)).astype(np.int32)
-    B = np.random.default_rng(7).normal(size=(m, n))
-    A = hip.CsrDev(m, half, rp, two, va)
-    Cd = torch.full((m, n), float("nan"), dtype=torch.float64, device=gpu)
-    hip.spmm_csr(A, _t(B[:half], gpu), Cd, n=n, B1=_t(B[half:], gpu), variant=5)
-    torch.cuda.synchronize()
-    assert orc.rel_fro_err(orc.spmm_csr(rp, ci, va, B), Cd.cpu().numpy()) <= FP64_TOL
-    A.free()
-
-
 FP32_TOL = 1e-5      # fp32 path vs the fp64 oracle: relative Frobenius error (there is no fp32 reference: src/rowpara_spmm.h:28)
 
 
@@ -900,9 +801,8 @@ def test_fp32_two_source_and_update(crp, orc, gpu):
     A.free()
 
 
-@pytest.mark.parametrize("compact", ["auto", "0", "1"])
 @pytest.mark.parametrize("n", [24, 26, 30, 32, 48, 64])
-def test_narrow_kernel(crp, orc, gpu, monkeypatch, n, compact):
+def test_narrow_kernel(crp, orc, gpu, monkeypatch, n):
     """The narrow-operand kernel (csrc/narrow_kernel.hip: row-panel format, four entries per instruction; variant 3 at
     24 <= n <= 32, even n, 16-byte aligned operands): random / banded / empty-row matrices with padded leading dimensions,
     the two-source column index (general addressing path), non-finite B rows next to absent pairs, value updates,
@@ -910,13 +810,9 @@ def test_narrow_kernel(crp, orc, gpu, monkeypatch, n, compact):
     import torch
     from crp_spmm_amd import gen, hip
     lib = crp.load()
-    # compact: the values of the panels without their holes (auto: when under half of the (row, entry) pairs exist; "1": always;
-    # "0": never); n = 48, 64: the two-piece instance, taken by itself only for panels that are mostly holes
-    if compact != "auto":
-        monkeypatch.setenv("CRPSPMM_NARROW_COMPACT", compact)
+    # (the values of the panels without their holes are taken when under 60 % of the (row, entry) pairs exist: the kkt case below;
+    #  n = 48, 64: the two-piece instance, taken by itself only for panels that are mostly holes, forced here)
     if n > 32:
-        if compact == "auto":
-            pytest.skip("two-piece instance: forced cases only")
         monkeypatch.setenv("CRPSPMM_NARROW_MAX", "64")
     cases = [gen.random_csr(777, 1234, 70, seed=n, empty_every=13), gen.banded_fem(5000, offsets=(1, 2, 3, 40, 41, 900), seed=n),
              gen.random_csr(13, 40, 5, seed=1), gen.kkt3d(10)]
@@ -986,29 +882,14 @@ def test_narrow_kernel(crp, orc, gpu, monkeypatch, n, compact):
         torch.cuda.empty_cache()
 
 
-def test_team2_sixteen_panel_teams_in_a_child_process(crp, orc, gpu):
-    """CRPSPMM_TEAM2_WAVES=16 (teams of 16 panels, 1024-thread workgroups; read once per process, hence the child):
-    the team2 and fp32 parity tests of this file again, in one pytest child process on the same GPU."""
-    import subprocess
-    import sys
-    env = dict(os.environ, CRPSPMM_TEAM2_WAVES="16")
-    here = os.path.dirname(os.path.abspath(__file__))
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_parity.py"), "-x", "-q", "-m", "gpu", "-k",
-                        "(team2 or fp32 or locality) and not child_process"], env=env, capture_output=True, text=True, timeout=900,
-                       cwd=os.path.dirname(here))
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert " passed" in r.stdout
-
-
-@pytest.mark.parametrize("variant", [6, 7])
+@pytest.mark.parametrize("variant", [7])
 @pytest.mark.parametrize("n", [24, 30, 32, 34, 48, 64])
-def test_team2n_kernel(crp, orc, gpu, n, variant):
-    """Variants 6 and 7, the team kernels for 24 <= n <= 64 columns (B rows shared through LDS).  6 = csrc/team2n_kernel.hip: four
-    (n <= 32) or two panel entries per instruction, masked rows, compact values; 7 = csrc/team2r_kernel.hip: lane groups own rows,
+def test_team2r_kernel(crp, orc, gpu, n, variant):
+    """Variant 7, the team kernel for 24 <= n <= 64 columns (B rows shared through LDS; csrc/team2r_kernel.hip): lane groups own rows,
     a step = every row's next nonzero, padding = 0.0 x a slice of zeros.  Random / banded / lattice / KKT / tiny matrices with
     padded leading dimensions, the two-source column index, non-finite B rows next to absent pairs, value updates (host and device
     pointers), row maps through the locality order, bit-identical repeats."""
-    vname = {6: b"team2n-R8", 7: b"team2r-R8"}[variant]
+    vname = {7: b"team2r-R8"}[variant]
     import torch
     from crp_spmm_amd import gen, hip
     lib = crp.load()
@@ -1092,32 +973,4 @@ def test_team2n_kernel(crp, orc, gpu, n, variant):
     m = len(rp) - 1
     B = np.random.default_rng(n + 2).normal(size=(m, n))
     got = _spmm(crp, gpu, rp, ci, va, m, B, n, variant=variant)
-    assert orc.rel_fro_err(orc.spmm_csr(rp, ci, va, B), got) <= FP64_TOL
-
-
-@pytest.mark.parametrize("n", [24, 32, 40, 64])
-def test_team2r_half_rounds(crp, orc, gpu, monkeypatch, n):
-    """Variant 7 on half rounds (CRPSPMM_T2R_ROWDMA=1: 8 KiB ring sets, one row DMA per wave and round, three workgroups per CU):
-    the kernel instance and the format of that layout against the oracle, two-source index included."""
-    from crp_spmm_amd import gen
-    monkeypatch.setenv("CRPSPMM_T2R_ROWDMA", "1")
-    cases = [gen.random_csr(777, 1234, 70, seed=n, empty_every=13), gen.kkt3d(12), gen.banded_fem(5000, offsets=(1, 2, 3, 40, 41, 900), seed=n),
-             gen.random_csr(13, 40, 5, seed=1)]
-    for rp, ci, va in cases:
-        m = len(rp) - 1
-        k = max(int(ci.max()) + 1, 1) if ci.size else 1
-        B = np.random.default_rng(n).uniform(-2, 2, size=(k, n))
-        ref = orc.spmm_csr(rp, ci, va, B)
-        for ldpad in (0, 2):
-            got = _spmm(crp, gpu, rp, ci, va, k, B, n, ldpad=ldpad, variant=7)
-            assert orc.rel_fro_err(ref, got) <= FP64_TOL, (m, ldpad)
-    m, k = 500, 900
-    rp, ci, va = gen.random_csr(m, k, 30, seed=2)
-    lo, hi = 300, 650
-    remote_rows = np.concatenate([np.arange(0, lo), np.arange(hi, k)])
-    pos = np.full(k, -1)
-    pos[remote_rows] = np.arange(remote_rows.size)
-    c2 = np.where((ci >= lo) & (ci < hi), ci - lo, ~pos[ci]).astype(np.int32)
-    B = np.random.default_rng(n + 1).normal(size=(k, n))
-    got = _spmm(crp, gpu, rp, c2, va, hi - lo, B[lo:hi], n, B1=B[remote_rows], variant=7)
     assert orc.rel_fro_err(orc.spmm_csr(rp, ci, va, B), got) <= FP64_TOL

@@ -295,11 +295,11 @@ def test_panel_locality_order(crp, monkeypatch):
     nx, ny, nz = 64, 8, 6
     m = nx * ny * nz
     rp, ci, va = gen.banded_fem(m, offsets=(1, 2, nx, nx * ny), seed=2)
-    monkeypatch.setenv("CRPSPMM_PANEL_GROUP", "2")
+    monkeypatch.setenv("CRPSPMM_PANEL_ORDER", "1")               # breadth-first groups of 16 consecutive panels
     f = hip.panel_format_host(rp, ci, va, 4)
     po = f["porder"]
     assert np.array_equal(np.sort(po), np.arange(f["npanel"]))
-    assert np.array_equal(po.reshape(-1, 2)[:, 1], po.reshape(-1, 2)[:, 0] + 1)      # groups stay whole
+    assert np.array_equal(po.reshape(-1, 16)[:, 1], po.reshape(-1, 16)[:, 0] + 1)    # groups stay whole
     pos = np.empty_like(po)
     pos[po] = np.arange(po.size)
     far = (nx * ny) // 4                                   # panels one z-plane apart
@@ -364,7 +364,7 @@ def test_team_schedule_and_team_format(crp, orc, monkeypatch):
     The processing order has 4 positions per team (-1 = none) and covers every panel once; a
     team's panels sit one stride apart; the re-ordered entries still expand to A * B; every wave
     meets a column it shares with a team-mate after (nearly) the same number of its own entries.
-    The team format (variant 4) lists every panel entry exactly once per wave, in that same order."""
+    The team format lists every panel entry exactly once per wave, in that same order."""
     from crp_spmm_amd import gen, hip
     nx, ny, nz = 600, 8, 4
     m = nx * ny * nz
@@ -372,16 +372,7 @@ def test_team_schedule_and_team_format(crp, orc, monkeypatch):
     R = 8
     npanel = (m + R - 1) // R
     monkeypatch.delenv("CRPSPMM_PANEL_ORDER", raising=False)
-    # optional layout for workgroups of six waves (3 x 2 teeth); the order covers every panel once
-    monkeypatch.setenv("CRPSPMM_TEAM_WAVES", "6")
-    po6 = hip.panel_format_host(rp, ci, va, R)["porder"]
-    assert po6.size % 6 == 0 and np.array_equal(np.sort(po6[po6 >= 0]), np.arange(npanel))
-    t6 = po6.reshape(-1, 6)
-    full6 = t6[(t6 >= 0).all(axis=1)]
-    assert full6.shape[0] > 0.6 * t6.shape[0]          # (8 teeth per block: two full 3 x 2 teams and one 2 x 2 remainder)
-    assert np.abs(np.median(full6[:, 1] - full6[:, 0]) - nx / R) <= 2 and np.abs(np.median(full6[:, 3] - full6[:, 0]) - nx * ny / R) <= 2
-    # the default: workgroups of four (2 x 2 teeth)
-    monkeypatch.delenv("CRPSPMM_TEAM_WAVES")
+    # workgroups of four (2 x 2 teeth)
     f = hip.panel_format_host(rp, ci, va, R)
     po = f["porder"]
     assert po.size % 4 == 0 and po.size >= npanel
@@ -611,71 +602,45 @@ def _range_of_code(code):
 
 
 def _replay_team2(t, m, B, va=None):
-    """Replays the team2 streams the way csrc/team2_kernel.hip / team2p_kernel.hip walk them: per unit (a team, or a CHAIN of
-    teams) and wave, round by round; the column behind ring slot e of round r is what wave e fetched for that round (tpro for
-    the first 3 rounds, the record of round r - 3 afterwards); the parts of round r take their values from the wave's stream
-    at the offset the record of round r - 3 (or tpro) announced.  W = 8 or 16 waves per team.  Chains: the rounds of the
-    chain's teams follow each other; a round with FLUSH is the last of a team -- the wave stores the rows of its panel of THAT
-    team and clears its accumulators; the three rounds behind a FLUSH carry POSTFLUSH (exactly 8 rows stored) or TAIL."""
+    """Replays the team2 streams the way csrc/team2_kernel.hip walks them: per team and wave, round by round;
+    the column behind ring slot e of round r is what wave e fetched for that round (tpro for the first 3
+    rounds, the record of round r - 3 afterwards); the parts of round r take their values from the wave's stream
+    at the offset the record of round r - 3 (or tpro) announced.  W = 8 or 16 waves per team."""
     W, P, compact = t["waves"], t.get("panels_per_wave", 1), t.get("compact", True)
     sbits, fbase = (3, 16) if W == 8 else (4, 20)
-    nchain = t.get("nchain", 0)
     C_out = np.zeros((m, B.shape[1]))
     written = np.zeros(m, dtype=bool)
     rec = t["trec"].reshape(-1, 8, W, 4)          # [block][round in block][wave][word]
-    units = [list(t["cteam"][t["cptr"][c]:t["cptr"][c + 1]]) for c in range(nchain)] if nchain else [[g] for g in range(t["nteam"])]
-    if nchain:
-        assert P == 1 and sorted(int(g) for u in units for g in u) == list(range(t["nteam"]))
-        # the launch grid names every chain once
-        tg = t["tgrid"].reshape(-1)
-        assert sorted(int(c) for c in tg[tg >= 0]) == list(range(nchain))
-    for u, members in enumerate(units):
-        nr, blk0 = int(t["tinfo"][u, 0]), int(t["tinfo"][u, 1])
-        if nchain:
-            assert nr >= len(members)
+    for g in range(t["nteam"]):
+        nr, blk0 = int(t["tinfo"][g, 0]), int(t["tinfo"][g, 1])
         cols = np.zeros((nr, W), dtype=np.int64)
         voffs = np.zeros((nr, W), dtype=np.int64)
         for r in range(nr):
             for w in range(W):
                 if r < 3:
-                    cols[r, w], voffs[r, w] = t["tpro"][u, r, w]
+                    cols[r, w], voffs[r, w] = t["tpro"][g, r, w]
                 else:
                     cols[r, w] = np.int32(rec[blk0 + ((r - 3) >> 3), (r - 3) & 7, w, 3])
                     voffs[r, w] = rec[blk0 + ((r - 3) >> 3), (r - 3) & 7, w, 2]
         parts_total = 0
-        flush_rounds = None
         for w in range(W):
-            k0 = int(t["tvoff"][W * u + w])
+            panels = [int(t["tpanel"][g, w * P + j]) for j in range(P)]
+            panel = max(panels)                                         # (-1 only when the wave owns nothing)
+            k0 = int(t["tvoff"][W * g + w])
             k = 0
             acc = np.zeros((P, 8, B.shape[1]))
-            member = 0
-            my_flush = []
             for r in range(nr):
-                g = int(members[member])
-                panels = [int(t["tpanel"][g, w * P + j]) for j in range(P)]
-                panel = max(panels)                                         # (-1 only when the wave owns nothing)
                 x, y = int(rec[blk0 + (r >> 3), r & 7, w, 0]), int(rec[blk0 + (r >> 3), r & 7, w, 1])
                 cnt = x & 7
                 assert cnt <= 4 and (x & 8) == 0
-                flush = bool(x >> (fbase + 4) & 1)
-                # flags: ISSUE while a round r + 3 exists, LAST on the last round
+                # flags: ISSUE while a round r + 3 exists, TAIL near the end, LAST on the last round
                 assert bool(x >> fbase & 1) == (r + 3 < nr) and bool(x >> (fbase + 2) & 1) == (r == nr - 1)
-                tail = bool(x >> (fbase + 1) & 1)
-                recent = [f for f in my_flush if r - 3 <= f[0] < r]
-                if not nchain:
-                    assert not flush and not (x >> 31) and tail == (r + 2 >= nr)
-                else:
-                    # behind ONE flush of a whole panel: POSTFLUSH; behind anything else (or near the chain's end): TAIL
-                    post = bool(x >> 31)
-                    want_post = len(recent) == 1 and recent[0][1]
-                    assert post == want_post, (u, w, r)
-                    assert tail == (r + 2 >= nr or (len(recent) > 0 and not want_post)), (u, w, r)
-                    assert flush or r < nr - 1
+                assert bool(x >> (fbase + 1) & 1) == (r + 2 >= nr)
                 if panel < 0:
                     assert cnt == 0
                 z = int(rec[blk0 + (r >> 3), r & 7, w, 2])
                 if cnt:
-                    assert (voffs[r, w] & 0xFFFFF) == k, (u, w, r)         # the announced offset (units of 4 values) is where the stream stands
+                    assert (voffs[r, w] & 0xFFFFF) == k, (g, w, r)         # the announced offset (units of 4 values) is where the stream stands
                 prefix = 0
                 for i in range(cnt):
                     slot = (x >> (4 + sbits * i)) & (W - 1)
@@ -684,7 +649,7 @@ def _replay_team2(t, m, B, va=None):
                     assert first + ln <= 8
                     pos = ((x >> (fbase + 5)) & 63, (y >> 24) & 63, (z >> 20) & 63, (z >> 26) & 63)[i]
                     # compact blocks: the part's values follow those of the parts before it; full groups: 8 per part
-                    assert pos == ((prefix + 7 - first) if compact else (8 * i + 7)), (u, w, r, i)
+                    assert pos == ((prefix + 7 - first) if compact else (8 * i + 7)), (g, w, r, i)
                     c = int(cols[r, slot])
                     assert 0 <= c < B.shape[0]
                     bank = (x >> (fbase + 11 + i)) & 1
@@ -696,59 +661,34 @@ def _replay_team2(t, m, B, va=None):
                 if r >= 3 and cnt:
                     # the size class announced three rounds earlier covers this round's values
                     y3 = int(rec[blk0 + ((r - 3) >> 3), (r - 3) & 7, w, 1])
-                    assert 8 * ((y3 >> 30) + 1) >= prefix > 8 * (y3 >> 30), (u, w, r)
+                    assert 8 * ((y3 >> 30) + 1) >= prefix > 8 * (y3 >> 30), (g, w, r)
                 k += (prefix + 3) // 4
                 parts_total += cnt
-                if flush or (not nchain and r == nr - 1):
-                    for j in range(P):
-                        if panels[j] < 0:
-                            continue
-                        lo, hi = panels[j] * 8, min(m, panels[j] * 8 + 8)
-                        C_out[lo:hi] = acc[j, :hi - lo]
-                        assert not written[lo:hi].any()
-                        written[lo:hi] = True
-                    whole = panel >= 0 and panel * 8 + 8 <= m
-                    my_flush.append((r, whole))
-                    acc[:] = 0.0
-                    member += 1
-            if nr == 0:                                                    # (a team without entries, one workgroup per team: rows of zeros)
-                g = int(members[0])
-                for j in range(P):
-                    pj = int(t["tpanel"][g, w * P + j])
-                    if pj >= 0:
-                        written[pj * 8:min(m, pj * 8 + 8)] = True
-                member = 1
-            assert member == len(members), (u, w)
-            if flush_rounds is None:
-                flush_rounds = [f[0] for f in my_flush]
-            assert flush_rounds == [f[0] for f in my_flush]                 # every wave ends its teams in the same rounds
-            if any(int(t["tpanel"][int(g), w * P + j]) >= 0 for g in members for j in range(P)):
-                assert k0 + k == int(t["tvoff"][W * u + w + 1]), (u, w)
-        assert parts_total == int(t["tinfo"][u, 2])
+            if panel >= 0:
+                assert k0 + k == int(t["tvoff"][W * g + w + 1]), (g, w)
+            for j in range(P):
+                if panels[j] < 0:
+                    continue
+                lo, hi = panels[j] * 8, min(m, panels[j] * 8 + 8)
+                C_out[lo:hi] = acc[j, :hi - lo]
+                assert not written[lo:hi].any()
+                written[lo:hi] = True
+        assert parts_total == int(t["tinfo"][g, 2])
     assert written.all()
     if va is not None:                             # the value-update map names every nonzero's slot
         assert np.array_equal(t["tval"].reshape(-1)[t["vmap"]], va)
     return C_out
 
 
-@pytest.mark.parametrize("order", ["default", "bisect", "two-panels", "compact", "full-groups", "chains", "chains-of-2"])
+@pytest.mark.parametrize("order", ["default", "compact", "full-groups"])
 def test_team2_streams_replay(crp, orc, monkeypatch, order):
     """The streams of the LDS-sharing kernel (variant 5), replayed in numpy: every row is produced once and
     equals the oracle's product -- for a stride-lattice matrix (teams of 4 x 2 teeth), a random matrix (8
     consecutive panels per team; duplicates, empty rows), and sizes that leave ragged last panels / teams."""
     from crp_spmm_amd import gen, hip
-    if order == "bisect":
-        # the recursive-bisection team order with generation-wide absolute rounds (rounds with empty slots, NOVAL records)
-        monkeypatch.setenv("CRPSPMM_T2_ORDER", "bisect")
     if order in ("compact", "full-groups"):
         # value blocks without the holes / with 8 values per part, whatever the fill (the default picks by fill)
         monkeypatch.setenv("CRPSPMM_TEAM2_COMPACT", "1" if order == "compact" else "0")
-    if order in ("chains", "chains-of-2"):
-        # persistent workgroups (team2p_kernel.hip) / short chains: teams end close to each other and to the chain's end
-        monkeypatch.setenv("CRPSPMM_T2_CHAIN", "8" if order == "chains" else "2")
-    if order == "two-panels":
-        # teams of 16 panels on 8 waves, two panels (accumulator banks) per wave: the narrow-operand instance
-        monkeypatch.setenv("CRPSPMM_TEAM2_FORMAT_PW", "2")
     rng = np.random.default_rng(2)
     cases = []
     # pwtk-like bands (a near band of 14, two far bands of 6): the tooth-shaped lattice teams are kept
@@ -785,95 +725,6 @@ def test_team2_streams_replay(crp, orc, monkeypatch, order):
         got = _replay_team2(t, m, B, va)
         ref = orc.spmm_csr(rp, ci, va, B)
         assert orc.rel_fro_err(ref, got) <= 1e-13, name
-
-
-def _replay_team2n(t, m, B, va):
-    """What csrc/team2n_kernel.hip does with the streams of crp_team2n_format_host, in numpy (B1-less)."""
-    G = t["G"]
-    out = np.zeros((m, B.shape[1]))
-    done = np.zeros(m, dtype=np.int64)
-    assert np.array_equal(t["tval"][t["vmap"]], va)
-    seen_teams = []
-    for g in t["tgrid"].ravel():
-        if g < 0:
-            continue
-        seen_teams.append(int(g))
-        nr, r0 = (int(x) for x in t["tinfo"][g])
-        acc = np.zeros((8, 8, B.shape[1]))
-        for r in range(nr):
-            recs = t["trec"][r0 + r]                                       # [8 waves, 16 words]
-            cols = np.array([[int(np.int32(recs[w, 2 + q])) for q in range(G)] for w in range(8)]).ravel()   # slot w G + q
-            assert np.all(cols >= 0) and np.all(cols < B.shape[0])        # empty slots name a real row: the DMA reads it
-            for w in range(8):
-                rec = [int(x) for x in recs[w]]
-                npart, nv = rec[0] & 31, (rec[0] >> 8) & 0x1FF
-                assert npart <= 4 * G and nv <= 128
-                first = 4 * (int(t["tvoff"][8 * g + w]) + rec[1])
-                assert first + nv <= 4 * int(t["tvoff"][8 * g + w + 1])   # the block lies inside the wave's stream
-                block = t["tval"][first:first + nv]
-                at = 0
-                for i in range(4 * G):
-                    step, qq = divmod(i, G)
-                    mask = (rec[6 + 2 * step] >> (8 * qq)) & 0xFF
-                    slot = (rec[7 + 2 * step] >> (5 * qq)) & 31
-                    if i >= npart:
-                        assert mask == 0                                   # the kernel takes whole steps: idle lane groups have no rows
-                        continue
-                    assert mask != 0 and slot < 8 * G
-                    for rr in range(8):
-                        if (mask >> rr) & 1:
-                            acc[w, rr] += block[at] * B[cols[slot]]
-                            at += 1
-                assert at == nv
-        for w in range(8):
-            p = int(t["tpanel"][g, w])
-            if p < 0:
-                assert not acc[w].any()
-                continue
-            for rr in range(8):
-                row = p * 8 + rr
-                if row < m:
-                    out[row] = acc[w, rr]
-                    done[row] += 1
-                else:
-                    assert not acc[w, rr].any()
-    assert sorted(seen_teams) == list(range(t["nteam"]))
-    assert np.all(done == 1)
-    return out
-
-
-@pytest.mark.parametrize("G", [4, 2])
-def test_team2n_streams_replay(crp, orc, G):
-    """The streams of the narrow-operand team kernel (variant 6), replayed in numpy: every row is produced once and equals
-    the oracle's product -- same matrices as the team2 replay (lattice / clustered teams, random, duplicates, ragged sizes)."""
-    from crp_spmm_amd import gen, hip
-    rng = np.random.default_rng(4)
-    cases = []
-    offs = tuple(range(1, 15)) + tuple(range(304, 310)) + tuple(range(3040, 3046))
-    cases.append(("lattice",) + gen.banded_fem(9120, offsets=offs, seed=3))
-    nx, ny, nz = 300, 5, 3
-    cases.append(("clustered",) + gen.banded_fem(nx * ny * nz, offsets=(1, 2, 3, nx, nx + 1, nx * ny, nx * ny + 1), seed=3))
-    cases.append(("random",) + gen.random_csr(611, 611, 14, seed=5, empty_every=9))
-    cases.append(("kkt",) + gen.kkt3d(16))
-    cases.append(("random40",) + gen.random_csr(777, 1234, 40, seed=3))     # waves with more than 4 G parts on a round's slots
-    cases.append(("dense64",) + gen.random_csr(64, 40, 36, seed=7))         # blocks that would pass 128 values
-    cases.append(("tiny",) + gen.random_csr(13, 40, 5, seed=1))
-    rp, ci, va = gen.random_csr(200, 64, 6, seed=8)
-    ci2 = ci.copy()
-    ci2[1::7] = ci2[0::7][:ci2[1::7].size]
-    cases.append(("dups", rp, ci2, va))
-    for name, rp, ci, va in cases:
-        m = len(rp) - 1
-        k = int(ci.max()) + 1 if ci.size else 1
-        t = hip.team2n_format_host(rp, ci, va, G=G)
-        assert np.array_equal(np.sort(t["tpanel"][t["tpanel"] >= 0]), np.arange((m + 7) // 8)), name
-        B = rng.uniform(-1, 1, size=(k, 3))
-        got = _replay_team2n(t, m, B, va)
-        ref = orc.spmm_csr(rp, ci, va, B)
-        assert orc.rel_fro_err(ref, got) <= 1e-13, name
-        if name == "lattice":
-            # the point of the format: a B row is fetched once per team, not once per panel entry
-            assert t["slots_filled"] < 0.6 * t["parts"], (t["slots_filled"], t["parts"])
 
 
 def _replay_team2r(t, m, B, va):
@@ -942,9 +793,8 @@ def _replay_team2r(t, m, B, va):
     return out
 
 
-@pytest.mark.parametrize("rowdma", [2, 1])
 @pytest.mark.parametrize("G", [4, 2])
-def test_team2r_streams_replay(crp, orc, G, rowdma):
+def test_team2r_streams_replay(crp, orc, G):
     """The streams of the row-owner team kernel (variant 7), replayed in numpy: every row is produced once and equals the oracle's
     product; padding steps carry the value 0.0 and the offset of the slice of zeros."""
     from crp_spmm_amd import gen, hip
@@ -966,7 +816,7 @@ def test_team2r_streams_replay(crp, orc, G, rowdma):
     for name, rp, ci, va in cases:
         m = len(rp) - 1
         k = int(ci.max()) + 1 if ci.size else 1
-        t = hip.team2r_format_host(rp, ci, va, G=G, rowdma=rowdma)
+        t = hip.team2r_format_host(rp, ci, va, G=G)
         assert np.array_equal(np.sort(t["tpanel"][t["tpanel"] >= 0]), np.arange((m + 7) // 8)), name
         B = rng.uniform(-1, 1, size=(k, 3))
         got = _replay_team2r(t, m, B, va)

@@ -14,7 +14,7 @@ def test_host_code_under_asan_ubsan(tmp_path):
     if gxx is None:
         pytest.skip("no g++")
     src = os.path.join(ROOT, "crp-spmm_amd", "csrc")
-    files = [os.path.join(src, f) for f in ("panel_format.cpp", "team_order.cpp", "locality.cpp", "spmat_part.cpp", "mmio_utils.cpp", "host_support.cpp")]
+    files = [os.path.join(src, f) for f in ("panel_format.cpp", "team_order.cpp", "locality.cpp", "spmat_part.cpp", "mmio_utils.cpp", "host_support.cpp", "knobs.cpp")]
     exe = str(tmp_path / "host_asan")
     cmd = [gxx, "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
            "-fno-omit-frame-pointer", "-pthread", "-I" + os.path.join(ROOT, "include"), "-I" + src,

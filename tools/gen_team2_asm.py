@@ -44,20 +44,7 @@ lane's 16-byte piece two at a time (accumulators are 64-bit pairs, as in fp64).
 T2_BPOL (environment, generation time) appends a cache policy to the B-row DMAs; measured on the pwtk stand-in:
 nt +35 % time, sc0 / sc1 / sc0 sc1 within +-2 %; the committed file uses none.
 
-PERSISTENT instances (gen(..., persist=True); csrc/team2p_kernel.hip, chains of teams: panel_format.h, Team2Host::chain):
-the statement is the whole life of a workgroup.  The accumulators are FIXED registers (v32 .. v95: pair a at v[32 + 2a],
-so the four registers of a 16-byte piece are adjacent and go out with one global_store_dwordx4), cleared at the start and
-after every FLUSH.  A round whose record carries FLUSH (the last round of a team of the chain) ends with a call of the
-flush routine: the 8 C rows of the wave's panel -- their numbers sit in lanes 0..7 of a fixed VGPR, loaded one team ahead
-from the chain's row table -- are stored (8 NV stores; a row number < 0 = no such row), the accumulators cleared, the row
-numbers of the next team requested.  The stores and that load enter the wave's vmcnt queue BEHIND the DMAs of the next D
-rounds, which are in flight already -- the pipeline does not drain at a team's end --, so the D rounds after a FLUSH
-wait with vmcnt((D-1) OPR + 8 NV + 1) (record flag POSTFLUSH, bit 31; set by the format only when the store count is
-exact, TAIL = vmcnt(0) otherwise; a column tile whose second piece lies wholly past n -- [ok1] = 0 -- takes POSTFLUSH
-as TAIL).
-
 usage: tools/gen_team2_asm.py > crp-spmm_amd/csrc/team2_consume.inc
-       tools/gen_team2_asm.py --persist > crp-spmm_amd/csrc/team2p_consume.inc
 """
 import os
 import sys
@@ -75,39 +62,23 @@ SBASE = 84           # fixed SGPRs: pc(2) ret(2) tblA(2) tblB(2) t cnt rowbase(2
 NCODE = 64          # sequences per staging buffer: index first * 8 + len - 1 (28 of them unused)
 NVREG = 28
 NSREG = 14
-# persistent instances: accumulators v32..v95, staging registers v96..v123, the panel's C rows v124; two more fixed SGPRs
-# (the chain's row-table pointer)
-P_ACC = 32
-P_VBASE = 96
-P_VROW = 124
-P_NSREG = 16
 
 
-def gen(nv, has_b1, f32=False, tw=8, pw=1, compact=True, persist=False):
+def gen(nv, has_b1, f32=False, compact=True):
     """nv = 16-byte pieces per lane and row; f32: 4 floats per piece (values 4 bytes, 8 per part = 32 bytes, value
     slot 128 bytes), else 2 doubles per piece (values 8 bytes, 64 bytes per part, value slot 256 bytes).
-    tw = waves (= slots of a round) per team: 8, or 16 (one 1024-thread workgroup per CU; slot numbers take 4
-    bits in w0, the flags move up to bits 20-23, a record block is 2 KiB).
     compact = False: the value blocks hold 8 values per part (part i's row r at 8 i + r): no value position to decode per part and
     a value DMA of fixed size -- two instructions per part and three per round fewer; the instance for panels that are well filled
-    (pwtk stand-in, fill 0.61: 3 % faster at n = 256 and 10 % at n = 128 than on compact values; nlpkkt stand-in, 0.23: 2-5 % slower).
-    pw = panels per wave: 1, or 2 (nv = 1 only: the narrow-operand instance -- a wave owns TWO panels, i.e. two banks of
-    accumulators, so that a team is 16 panels = 128 rows on 8 waves; every part names its bank in w0 bits fbase+11+i and
-    the call goes to that bank's copy of the sequences.  Half the rounds per row, and a B row is fetched once per 128 rows)."""
-    sbits = 3 if tw == 8 else 4                     # bits of a slot number in w0
-    fbase = 16 if tw == 8 else 20                   # first flag bit of w0: ISSUE, TAIL, LAST, RECS
+    (pwtk stand-in, fill 0.61: 3 % faster at n = 256 and 10 % at n = 128 than on compact values; nlpkkt stand-in, 0.23: 2-5 % slower)."""
+    tw = 8                                          # waves (= slots of a round) per team
+    sbits = 3                                       # bits of a slot number in w0
+    fbase = 16                                      # first flag bit of w0: ISSUE, TAIL, LAST, RECS
     recrow = 16 * tw                                # bytes of the records of one round
     recblk = 8 * recrow                             # ... of a record block
     vw = 4 if f32 else 2                            # elements per 16-byte piece
     vgrp = 32 if f32 else 64                        # bytes of one part's 8 values
     vslot = 4 * vgrp
-    b = P_VBASE if persist else VBASE
-    assert not persist or pw == 1
-    RT = SBASE + 14                                 # persistent: the row-table pointer of the wave (advanced per team)
-
-    def acc(i):
-        """accumulator pair i as an operand of the FMAs"""
-        return "v[%d:%d]" % (P_ACC + 2 * i, P_ACC + 2 * i + 1) if persist else "%%[a%d]" % i
+    b = VBASE
     A = {"s0": b, "s1": b + 4, "v": b + 8}
     B = {"s0": b + 10, "s1": b + 14, "v": b + 18}
     TA, TV, REC = b + 20, b + 21, b + 22
@@ -119,19 +90,14 @@ def gen(nv, has_b1, f32=False, tw=8, pw=1, compact=True, persist=False):
     # 2^x >= the longest sequence: fp64 8 rows x nv * 2 FMAs x 8 bytes + return; fp32 8 rows x (1 + nv * 2) x 8 bytes + return
     seq_align = {(1, False): 8, (2, False): 9, (1, True): 8, (2, True): 9}[(nv, f32)]
     opr = nv + 1                                    # DMAs a wave issues per round
-    assert pw == 1 or nv == 1
-    tag = "%s%s%d%d%s%s%s_%%=" % ("P" if persist else "", "s" if f32 else "d", nv, 1 if has_b1 else 0, "w" if tw == 16 else "", "p" if pw == 2 else "", "" if compact else "f")
-    nacc = 8 * nv * 2 * pw
-    nstore = 8 * nv + 1                             # persistent: what a FLUSH adds to the wave's vmcnt queue
+    tag = "%s%d%d%s_%%=" % ("s" if f32 else "d", nv, 1 if has_b1 else 0, "" if compact else "f")
     L = []
     emit = L.append
 
     def rd(k, i, X):
         emit("s_bfe_u32 s%d, %%[w0], 0x%x" % (T, (sbits << 16) | (4 + sbits * i)))
-        # (a DS offset has 16 bits: the upper two sets of the 128 KiB ring of tw = 16, nv = 2 go through a second base)
-        far = k * setb + 1024 * (nv - 1) > 65535
-        koff = (k - 2) * setb if far else k * setb
-        emit("v_lshl_add_u32 v%d, s%d, %d, %%[%s]" % (TA, T, slot_shift, "seta2" if far else "seta"))
+        koff = k * setb
+        emit("v_lshl_add_u32 v%d, s%d, %d, %%[seta]" % (TA, T, slot_shift))
         emit("ds_read_b128 v[%d:%d], v%d offset:%d" % (X["s0"], X["s0"] + 3, TA, koff))
         if nv == 2:
             emit("ds_read_b128 v[%d:%d], v%d offset:%d" % (X["s1"], X["s1"] + 3, TA, koff + 1024))
@@ -154,11 +120,6 @@ def gen(nv, has_b1, f32=False, tw=8, pw=1, compact=True, persist=False):
     def call(i, tb):
         emit("s_bfe_u32 s%d, %%[w1], 0x%x" % (T, (6 << 16) | (6 * i)))
         emit("s_lshl_b32 s%d, s%d, %d" % (T, T, seq_align))
-        if pw == 2:
-            # the part's bank: its sequences sit 2 * NCODE further (bank 0: tables A, B; bank 1: tables A, B)
-            emit("s_bitcmp1_b32 %%[w0], %d" % (fbase + 11 + i))
-            emit("s_cselect_b32 s%d, 0x%x, 0" % (CNT, (2 * NCODE) << seq_align))
-            emit("s_add_u32 s%d, s%d, s%d" % (T, T, CNT))
         emit("s_add_u32 s%d, s%d, s%d" % (PC, tb, T))
         emit("s_addc_u32 s%d, s%d, 0" % (PC + 1, tb + 1))
         emit("s_swappc_b64 s[%d:%d], s[%d:%d]" % (RET, RET + 1, PC, PC + 1))
@@ -172,38 +133,16 @@ def gen(nv, has_b1, f32=False, tw=8, pw=1, compact=True, persist=False):
     emit("s_addc_u32 s%d, s%d, 0" % (TBB + 1, TBA + 1))
     emit("s_mov_b32 s%d, %%[rslo]" % RS)
     emit("s_mov_b32 s%d, %%[rshi]" % (RS + 1))
-    if persist:
-        emit("s_mov_b32 s%d, %%[rtlo]" % RT)
-        emit("s_mov_b32 s%d, %%[rthi]" % (RT + 1))
-        emit("v_mov_b32 v%d, %%[rows0]" % P_VROW)
-        for i in range(nacc):
-            emit("v_mov_b64 v[%d:%d], 0" % (P_ACC + 2 * i, P_ACC + 2 * i + 1))
     emit("s_branch .Lt2body0%s" % tag)               # round 0: the compiler's code has waited, synchronised and read the record
 
     for k in range(NSET):
         kd = (k + D) % NSET                          # set of round r + D
         emit(".Lt2round%d%s:" % (k, tag))
-        if persist:
-            # TAIL or POSTFLUSH: the slow path sorts them out
-            emit("s_and_b32 s%d, %%[w0], 0x%x" % (T, (1 << 31) | (1 << (fbase + 1))))
-            emit("s_cbranch_scc1 .Lt2sl%d%s" % (k, tag))
-        else:
-            emit("s_bitcmp1_b32 %%[w0], %d" % (fbase + 1))
-            emit("s_cbranch_scc1 .Lt2tw%d%s" % (k, tag))
+        emit("s_bitcmp1_b32 %%[w0], %d" % (fbase + 1))
+        emit("s_cbranch_scc1 .Lt2tw%d%s" % (k, tag))
         emit("s_waitcnt vmcnt(%d)" % ((D - 1) * opr))
         emit("s_barrier")
         emit("s_branch .Lt2body%d%s" % (k, tag))
-        if persist:
-            emit(".Lt2sl%d%s:" % (k, tag))
-            emit("s_bitcmp1_b32 %%[w0], %d" % (fbase + 1))
-            emit("s_cbranch_scc1 .Lt2tw%d%s" % (k, tag))
-            if nv == 2:
-                # (a column tile whose second piece lies wholly past n stores nothing for it: the count is not exact)
-                emit("s_cmp_eq_u64 %[ok1], 0")
-                emit("s_cbranch_scc1 .Lt2tw%d%s" % (k, tag))
-            emit("s_waitcnt vmcnt(%d)" % ((D - 1) * opr + nstore))
-            emit("s_barrier")
-            emit("s_branch .Lt2body%d%s" % (k, tag))
         emit(".Lt2tw%d%s:" % (k, tag))
         emit("s_waitcnt vmcnt(0)")
         emit("s_barrier")
@@ -300,21 +239,8 @@ def gen(nv, has_b1, f32=False, tw=8, pw=1, compact=True, persist=False):
             if c != 1:
                 emit("s_branch .Lt2pe%d%s" % (k, tag))
         emit(".Lt2pe%d%s:" % (k, tag))
-        if persist:
-            # FLUSH (a team of the chain ends here; the chain's LAST round carries it too)
-            emit("s_bitcmp1_b32 %%[w0], %d" % (fbase + 4))
-            emit("s_cbranch_scc0 .Lt2nf%d%s" % (k, tag))
-            emit("s_getpc_b64 s[%d:%d]" % (PC, PC + 1))
-            emit(".Lt2fp%d%s:" % (k, tag))
-            emit("s_add_u32 s%d, s%d, .Lt2flush%s-.Lt2fp%d%s" % (PC, PC, tag, k, tag))
-            emit("s_addc_u32 s%d, s%d, 0" % (PC + 1, PC + 1))
-            emit("s_swappc_b64 s[%d:%d], s[%d:%d]" % (RET, RET + 1, PC, PC + 1))
-            emit("s_bitcmp1_b32 %%[w0], %d" % (fbase + 2))
-            emit("s_cbranch_scc1 .Lt2done%s" % tag)
-            emit(".Lt2nf%d%s:" % (k, tag))
-        else:
-            emit("s_bitcmp1_b32 %%[w0], %d" % (fbase + 2))
-            emit("s_cbranch_scc1 .Lt2done%s" % tag)
+        emit("s_bitcmp1_b32 %%[w0], %d" % (fbase + 2))
+        emit("s_cbranch_scc1 .Lt2done%s" % tag)
         emit("s_waitcnt lgkmcnt(0)")
         emit("v_readfirstlane_b32 %%[w0], v%d" % REC)
         emit("v_readfirstlane_b32 %%[w1], v%d" % (REC + 1))
@@ -323,7 +249,7 @@ def gen(nv, has_b1, f32=False, tw=8, pw=1, compact=True, persist=False):
         if k == NSET - 1:
             emit("s_branch .Lt2round0%s" % tag)
     # ---- the sequences
-    for bank, (name, X) in [(bk, nx) for bk in range(pw) for nx in (("A", A), ("B", B))]:
+    for bank, (name, X) in [(0, nx) for nx in (("A", A), ("B", B))]:
         code = 0
         for first in range(8):
             for ln in range(1, 9):
@@ -343,77 +269,31 @@ def gen(nv, has_b1, f32=False, tw=8, pw=1, compact=True, persist=False):
                         base = X["s0"] if v == 0 else X["s1"]
                         for w in range(2):
                             if f32:
-                                emit("v_pk_fma_f32 %s, v[%d:%d], v[%d:%d], %s op_sel_hi:[1,0,1]"
-                                     % (acc(((bank * 8 + r) * nv + v) * 2 + w), base + 2 * w, base + 2 * w + 1, TP, TP + 1, acc(((bank * 8 + r) * nv + v) * 2 + w)))
+                                emit("v_pk_fma_f32 %%[a%d], v[%d:%d], v[%d:%d], %%[a%d] op_sel_hi:[1,0,1]"
+                                     % (((bank * 8 + r) * nv + v) * 2 + w, base + 2 * w, base + 2 * w + 1, TP, TP + 1, ((bank * 8 + r) * nv + v) * 2 + w))
                             else:
-                                emit("v_fmac_f64_dpp %s, v[%d:%d], v[%d:%d] row_newbcast:%d row_mask:0xf bank_mask:0xf"
-                                     % (acc(((bank * 8 + r) * nv + v) * 2 + w), X["v"], X["v"] + 1, base + 2 * w, base + 2 * w + 1, r))
+                                emit("v_fmac_f64_dpp %%[a%d], v[%d:%d], v[%d:%d] row_newbcast:%d row_mask:0xf bank_mask:0xf"
+                                     % (((bank * 8 + r) * nv + v) * 2 + w, X["v"], X["v"] + 1, base + 2 * w, base + 2 * w + 1, r))
                 emit("s_setpc_b64 s[%d:%d]" % (RET, RET + 1))
         assert code == NCODE
-    if persist:
-        # ---- the flush routine: C rows of the wave's panel out, accumulators cleared, the next team's row numbers requested
-        emit(".Lt2flush%s:" % tag)
-        for r in range(8):
-            emit("v_readlane_b32 s%d, v%d, %d" % (T, P_VROW, r))
-            emit("s_cmp_lt_i32 s%d, 0" % T)
-            emit("s_cbranch_scc1 .Lt2fs%d%s" % (r, tag))
-            emit("s_mul_hi_u32 s%d, s%d, %%[ldc]" % (RB + 1, T))
-            emit("s_mul_i32 s%d, s%d, %%[ldc]" % (RB, T))
-            emit("s_add_u32 s%d, s%d, %%[clo]" % (RB, RB))
-            emit("s_addc_u32 s%d, s%d, %%[chi]" % (RB + 1, RB + 1))
-            for v in range(nv):
-                emit("s_mov_b64 exec, %%[ok%d]" % v)
-                a0 = P_ACC + 2 * ((r * nv + v) * 2)
-                emit("global_store_dwordx4 %%[coff], v[%d:%d], s[%d:%d]%s nt" % (a0, a0 + 3, RB, RB + 1, " offset:1024" if v == 1 else ""))
-            emit(".Lt2fs%d%s:" % (r, tag))
-        emit("s_mov_b64 exec, -1")
-        emit("s_nop 0")
-        for i in range(nacc):
-            emit("v_mov_b64 v[%d:%d], 0" % (P_ACC + 2 * i, P_ACC + 2 * i + 1))
-        emit("s_add_u32 s%d, s%d, %d" % (RT, RT, 32 * tw))
-        emit("s_addc_u32 s%d, s%d, 0" % (RT + 1, RT + 1))
-        emit("global_load_dword v%d, %%[rowoff], s[%d:%d]" % (P_VROW, RT, RT + 1))
-        emit("s_setpc_b64 s[%d:%d]" % (RET, RET + 1))
     emit(".Lt2done%s:" % tag)
     emit("s_waitcnt lgkmcnt(0)")                     # the record read of the round after the last one
     return L
 
 
-def main_persist():
-    out = sys.stdout
-    out.write("// GENERATED by tools/gen_team2_asm.py --persist -- do not edit; see that script for the design.\n")
-    out.write("// Fixed registers v%d..v%d and s%d..s%d (and m0) must be in the clobber list of the statement.\n"
-              % (P_ACC, P_VROW, SBASE, SBASE + P_NSREG - 1))
-    out.write("#define CRP_TEAM2P_CLOBBERS %s, %s\n" % (", ".join('"v%d"' % r for r in range(P_ACC, P_VROW + 1)),
-                                                       ", ".join('"s%d"' % r for r in range(SBASE, SBASE + P_NSREG))))
-    for tw, compact in ((8, True), (8, False), (16, True)):
-     for f32 in (False, True):
-      for nv in (1, 2):
-        for hb in (0, 1):
-            out.write("#define CRP_TEAM2P_LOOP_%s_NV%d_B%d%s \\\n" % ("F32" if f32 else "F64", nv, hb, "_W16" if tw == 16 else ("" if compact else "_F")))
-            lines = gen(nv, bool(hb), f32, tw, 1, compact, persist=True)
-            for k, l in enumerate(lines):
-                sep = "\\n\\t" if not l.endswith(":") else "\\n"
-                last = k == len(lines) - 1
-                out.write('    "%s%s"%s\n' % (l, "" if last else sep, "" if last else " \\"))
-            out.write("\n")
-
-
 def main():
-    if "--persist" in sys.argv[1:]:
-        return main_persist()
     out = sys.stdout
     out.write("// GENERATED by tools/gen_team2_asm.py -- do not edit; see that script for the design.\n")
     out.write("// Fixed registers v%d..v%d and s%d..s%d (and m0) must be in the clobber list of the statement.\n"
               % (VBASE, VBASE + NVREG - 1, SBASE, SBASE + NSREG - 1))
     out.write("#define CRP_TEAM2_CLOBBERS %s, %s\n" % (", ".join('"v%d"' % r for r in range(VBASE, VBASE + NVREG)),
                                                       ", ".join('"s%d"' % r for r in range(SBASE, SBASE + NSREG))))
-    for tw, pw, compact in ((8, 1, True), (8, 1, False), (16, 1, True), (8, 2, True)):
+    for compact in (True, False):
      for f32 in (False, True):
-      for nv in ((1, 2) if pw == 1 else (1,)):
+      for nv in (1, 2):
         for hb in (0, 1):
-            out.write("#define CRP_TEAM2_LOOP_%s_NV%d_B%d%s \\\n" % ("F32" if f32 else "F64", nv, hb, "_W16" if tw == 16 else ("_P2" if pw == 2 else ("" if compact else "_F"))))
-            lines = gen(nv, bool(hb), f32, tw, pw, compact)
+            out.write("#define CRP_TEAM2_LOOP_%s_NV%d_B%d%s \\\n" % ("F32" if f32 else "F64", nv, hb, "" if compact else "_F"))
+            lines = gen(nv, bool(hb), f32, compact)
             for k, l in enumerate(lines):
                 sep = "\\n\\t" if not l.endswith(":") else "\\n"
                 last = k == len(lines) - 1
