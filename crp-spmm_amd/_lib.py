@@ -132,6 +132,7 @@ SIGNATURES = {
     "crp_csr_dev_nrow": (_I, [_V]),
     "crp_csr_dev_nnz": (_LL, [_V]),
     "crp_csr_dev_bytes": (_LL, [_V]),
+    "crp_csr_dev_row_part_comm_size": (_I, [_V, _I, c_int_p, c_int_p, c_int_p, c_int_p]),
     "crp_csr_dev_auto_variant": (_I, [_V]),
     "crp_csr_dev_reordered": (_I, [_V]),
     "crp_csr_dev_resolved_variant": (_I, [_V, _I]),

@@ -121,6 +121,9 @@ hipError_t scatter_vals_f64(int64_t n, const uint32_t *map, const double *src, d
 hipError_t convert_f64_f32(int64_t n, const double *src, float *dst, hipStream_t s);
 hipError_t transpose_f64(int nrow, int ncol, const double *src, int64_t lds, double *dst, int64_t ldd,
                          hipStream_t s);
+// csr_mat_row_part_comm_size on a device-resident CSR (bits: nblk * ceil(ncol / 32) words, zeroed; comm_dev: nblk ints, zeroed)
+hipError_t row_part_comm_size(int nrow, int ncol, const int *rowptr, const int *colidx, int nblk, const int *rblk_dev, const int *xd_dev,
+                              unsigned *bits, int *comm_dev, int *bad_dev, hipStream_t s);
 hipError_t probe_copy(int64_t bytes, const void *src, void *dst, int blocks, unsigned long long *stamps, hipStream_t s);
 hipError_t probe_stamp(unsigned long long *out, hipStream_t s);
 

@@ -6,6 +6,7 @@
 // movement: 16-byte accesses per lane, consecutive lanes on consecutive
 // addresses, grid-stride so that a launch is capped at ~8 blocks per CU.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <stdint.h>
 #include "kernels.h"
 
@@ -191,6 +192,76 @@ hipError_t probe_copy(int64_t bytes, const void *src, void *dst, int blocks, uns
 hipError_t probe_stamp(unsigned long long *out, hipStream_t s)
 {
     hipLaunchKernelGGL(probe_stamp_kernel, dim3(1), dim3(1), 0, s, out);
+    return hipGetLastError();
+}
+
+// ---- csr_mat_row_part_comm_size on the device (planner, /root/reference/src/spmat_part.c:38-64) -------------------------
+// For a row partition rblk (nblk + 1) and a partition xd of the columns (nblk + 1): comm[b] = distinct columns the rows of
+// block b name that lie outside [xd[b], xd[b + 1]).  One bitmap of ncol bits per block: pass 1 sets the bit of every nonzero
+// (one wave per row; the row's block by binary search), pass 2 counts the set bits outside the block's own range.
+// Integer work: bit-exact against the reference.
+__global__ void comm_mark_kernel(const int nrow, const int *__restrict__ rowptr, const int *__restrict__ colidx, const int nblk,
+                                 const int *__restrict__ rblk, const long long words, unsigned *__restrict__ bits, int *__restrict__ bad)
+{
+    const int lane = threadIdx.x & 63;
+    const long long wave0 = ((long long) blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwave = ((long long) gridDim.x * blockDim.x) >> 6;
+    for (long long r = wave0; r < nrow; r += nwave)
+    {
+        int lo = 0, hi = nblk;                       // rblk[lo] <= r < rblk[hi]: the last block that starts at or before r
+        while (hi - lo > 1)
+        {
+            const int mid = (lo + hi) >> 1;
+            if (rblk[mid] <= (int) r) lo = mid; else hi = mid;
+        }
+        unsigned *my = bits + (long long) lo * words;
+        for (int p = rowptr[r] + lane; p < rowptr[r + 1]; p += 64)
+        {
+            const int c = colidx[p];
+            if (c < 0) { *bad = 1; continue; }       // (a two-source index: not a column of the global matrix)
+            atomicOr(my + (c >> 5), 1u << (c & 31));
+        }
+    }
+}
+
+__global__ void comm_count_kernel(const int ncol, const int nblk, const int *__restrict__ xd, const long long words,
+                                  const unsigned *__restrict__ bits, int *__restrict__ comm)
+{
+    const int b = blockIdx.y;
+    const int own0 = xd[b], own1 = xd[b + 1];
+    int cnt = 0;
+    for (long long w = (long long) blockIdx.x * blockDim.x + threadIdx.x; w < words; w += (long long) gridDim.x * blockDim.x)
+    {
+        unsigned v = bits[(long long) b * words + w];
+        if (v == 0) continue;
+        const long long c0 = w << 5;
+        // clear the bits of the block's own columns [own0, own1)
+        if (c0 + 32 > own0 && c0 < own1)
+        {
+            const int lo = (int) std::max<long long>(own0 - c0, 0), hi = (int) std::min<long long>(own1 - c0, 32);
+            const unsigned m = (hi - lo >= 32) ? 0xFFFFFFFFu : (((1u << (hi - lo)) - 1u) << lo);
+            v &= ~m;
+        }
+        cnt += __popc(v);
+    }
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(comm + b, cnt);
+    (void) ncol;
+}
+
+hipError_t row_part_comm_size(int nrow, int ncol, const int *rowptr, const int *colidx, int nblk, const int *rblk_dev, const int *xd_dev,
+                              unsigned *bits, int *comm_dev, int *bad_dev, hipStream_t s)
+{
+    const long long words = ((long long) ncol + 31) / 32;
+    if (nrow > 0)
+    {
+        const int blocks = (int) std::min<long long>(((long long) nrow + 3) / 4, 65536);
+        hipLaunchKernelGGL(comm_mark_kernel, dim3(blocks), dim3(256), 0, s, nrow, rowptr, colidx, nblk, rblk_dev, words, bits, bad_dev);
+    }
+    if (words > 0)
+    {
+        const int bx = (int) std::min<long long>((words + 255) / 256, 1024);
+        hipLaunchKernelGGL(comm_count_kernel, dim3(bx, nblk), dim3(256), 0, s, ncol, nblk, xd_dev, words, bits, comm_dev);
+    }
     return hipGetLastError();
 }
 

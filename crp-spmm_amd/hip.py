@@ -27,6 +27,17 @@ class CsrDev:
     def nnz(self):
         return int(self._lib.crp_csr_dev_nnz(self.handle))
 
+    def row_part_comm_size(self, rblk_ptr, x_displs):
+        """csr_mat_row_part_comm_size (src/spmat_part.c:38-64) evaluated on the device-resident CSR -> (sizes, total)."""
+        rb = np.ascontiguousarray(rblk_ptr, dtype=np.int32)
+        xd = np.ascontiguousarray(x_displs, dtype=np.int32)
+        nblk = rb.size - 1
+        sizes = np.zeros(nblk, dtype=np.int32)
+        tot = C.c_int()
+        L.check(self._lib.crp_csr_dev_row_part_comm_size(self.handle, nblk, rb.ctypes.data_as(L.c_int_p), xd.ctypes.data_as(L.c_int_p),
+                                                         sizes.ctypes.data_as(L.c_int_p), C.byref(tot)), "crp_csr_dev_row_part_comm_size")
+        return sizes, tot.value
+
     def free(self):
         if self.handle:
             self._lib.crp_csr_dev_destroy(C.byref(self.handle))

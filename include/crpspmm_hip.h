@@ -101,6 +101,13 @@ int crp_csr_dev_nrow(crp_csr_dev_p A);
 long long crp_csr_dev_nnz(crp_csr_dev_p A);
 /* bytes of HBM the kernel must touch for A itself: 12*nnz + 4*(nrow+1). */
 long long crp_csr_dev_bytes(crp_csr_dev_p A);
+/* csr_mat_row_part_comm_size (/root/reference/src/spmat_part.c:38-64; include/spmat_part.h) evaluated ON THE DEVICE for a
+ * matrix that is device-resident already -- re-planning a grid for other widths or rank counts without touching the host CSR:
+ * comm_sizes[b] = distinct columns the rows rblk_ptr[b] .. rblk_ptr[b + 1] name outside [x_displs[b], x_displs[b + 1]),
+ * *total_size their sum; bit-exact against the host function.  One bitmap of ncol bits per block in HBM (nblk * ncol / 8
+ * bytes, temporary).  Only for matrices with plain column indices (no two-source encoding): -2 otherwise. */
+int crp_csr_dev_row_part_comm_size(crp_csr_dev_p A, int nblk, const int *rblk_ptr, const int *x_displs, int *comm_sizes,
+                                   int *total_size);
 
 /* what variant 0 resolves to for this matrix: 1 csr-rowgroup, 2 rowpanel-R4, 3 rowpanel-R8
  * (chosen at create time from how many columns the rows of a panel share;

@@ -861,7 +861,7 @@ def test_narrow_kernel(crp, orc, gpu, monkeypatch, n):
     torch.cuda.synchronize()
     assert orc.rel_fro_err(orc.spmm_csr(rp, ci, v2, Bf), Cd.cpu().numpy()) <= FP64_TOL
     A.free()
-    if n == 32 and compact != "0":
+    if n == 32:
         # B rows addressed past 4 GiB: the 64-bit addressing path
         kb, ld = 1100, 1 << 19
         rpb, cib, vab = gen.random_csr(1500, kb, 40, seed=21)
@@ -974,3 +974,35 @@ def test_team2r_kernel(crp, orc, gpu, n, variant):
     B = np.random.default_rng(n + 2).normal(size=(m, n))
     got = _spmm(crp, gpu, rp, ci, va, m, B, n, variant=variant)
     assert orc.rel_fro_err(orc.spmm_csr(rp, ci, va, B), got) <= FP64_TOL
+
+
+@pytest.mark.parametrize("name", GOLDEN_NAMES)
+def test_comm_size_on_device_vs_host_planner(crp, orc, gpu, name):
+    """csr_mat_row_part_comm_size (src/spmat_part.c:38-64) on the device-resident CSR (crp_csr_dev_row_part_comm_size: one bitmap
+    per block) against the host function -- itself bit-exact against the reference build -- and the oracle, for the
+    planner's nnz-balanced row blocks and for ragged ones (empty blocks, x partition different from the row partition); integers:
+    exact."""
+    from crp_spmm_amd import gen, hip, planner
+    g = load_golden(name, "csr")
+    cases = [(int(g["m"]), int(g["k"]), g["rowptr"], g["colidx"], g["val"])]
+    rp, ci, va = gen.banded_fem(20011, offsets=(1, 2, 3, 40, 41, 900, 5000), seed=7)
+    cases.append((20011, 20011, rp, ci, va))
+    rp, ci, va = gen.random_csr(3000, 7001, 23, seed=11, empty_every=7)
+    cases.append((3000, 7001, rp, ci, va))
+    for m, k, rp, ci, va in cases:
+        A = hip.CsrDev(m, k, rp, ci, va)
+        for P in (1, 2, 3, 4, 6, 8, 13):
+            rb = planner.csr_mat_row_partition(rp, P)
+            xd = rb if m == k else planner.even_displs(k, P)
+            ref_sizes, ref_tot = planner.csr_mat_row_part_comm_size(k, rp, ci, rb, xd)
+            got_sizes, got_tot = A.row_part_comm_size(rb, xd)
+            assert np.array_equal(ref_sizes, got_sizes) and ref_tot == got_tot, (name, m, P)
+            o_sizes, o_tot = orc.csr_row_part_comm_size(k, rp, ci, rb, xd)
+            assert np.array_equal(np.asarray(o_sizes), got_sizes) and int(o_tot) == got_tot, (name, m, P, "oracle")
+        # ragged: empty blocks at both ends, an x partition unrelated to the rows
+        rb = np.array([0, 0, m // 3, m // 3, m, m], dtype=np.int32)
+        xd = np.array([0, k // 5, k // 5, k // 2, k - 1, k], dtype=np.int32)
+        ref_sizes, ref_tot = planner.csr_mat_row_part_comm_size(k, rp, ci, rb, xd)
+        got_sizes, got_tot = A.row_part_comm_size(rb, xd)
+        assert np.array_equal(ref_sizes, got_sizes) and ref_tot == got_tot, (name, m, "ragged")
+        A.free()
