@@ -33,7 +33,13 @@ struct PanelDev
     long long cvalues = 0;
 };
 
-constexpr int TEAM2_MIN_N = 112;      // fp64 columns from which auto picks variant 5
+// fp64 columns from which auto picks variant 5.  Round 4: the one-piece instances (n <= 128) run THREE workgroups per CU (80
+// VGPRs, 43 KiB of LDS) -- pwtk stand-in n = 128 0.181 -> 0.163 ms, nlpkkt stand-in n = 96 1.18 -> 0.98 -- and the crossover against
+// the row-panel kernel moved down (profiles/r04_team2_min_n.txt, variant 3 / 5: pwtk stand-in n = 80 0.138 / 0.146, n = 96 0.155 /
+// 0.151, n = 112 0.167 / 0.154; shell n = 64 0.120 / 0.119, n = 96 0.166 / 0.137; Queen stand-in n = 64 0.447 / 0.403, n = 96 0.531 / 0.444).
+constexpr int TEAM2_MIN_N = 96;
+// ... where the row-panel format asks for more than 12 B row slices per row of A (Queen / shell stand-ins: 17.8 / 13; pwtk: 10.5)
+constexpr int TEAM2_MIN_N_DENSE = 64;
 // ... when fewer than 35 % of the (row, entry) pairs of the R = 8 panels are present: the row-panel format then stores mostly
 // zeros (8 values per entry) while the team kernel's value streams are compact (nlpkkt stand-in, fill 0.23, n = 96: 1.26 ms
 // against 1.47; at n = 64 -- half of the kernel's 128-column tile idle -- 1.23 against 1.14, so not below 80)
@@ -669,6 +675,7 @@ static int csr_dev_create_impl(int nrow, int ncol, const int *rowptr, const int 
         // 0.73 / 1.34 / 1.95 through CSR and 1.00 / 1.10 / 1.45 on R = 4; the shell stand-in 0.106 / 0.129 against 0.135 / 0.144
         // on R = 4.  Erdos-Renyi (e8 = nnz) stays with CSR.
         if ((double) e8 <= 0.6 * (double) nnz) A->auto_variant = 3;
+        if ((double) e8 > 12.0 * (double) nrow) A->team2_min_n = TEAM2_MIN_N_DENSE;
         if ((double) nnz < 0.35 * 8.0 * (double) e8)
         {
             A->team2_min_n = TEAM2_MIN_N_SPARSE;

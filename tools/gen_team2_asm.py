@@ -58,6 +58,10 @@ D = 3
 NSET = 4
 VSLOT = 256
 VBASE = 100          # fixed VGPRs: A0(4) A1(4) AV(2) B0(4) B1(4) BV(2) TA TV REC(4) TP(2: fp32 broadcast pair)
+# ... of the one-piece instances (nv = 1: 16 accumulator pairs instead of 32): low enough that the kernel fits 80 VGPRs, i.e. six
+# waves per SIMD = THREE workgroups per CU (their LDS, 43 KiB each, allows it) -- below 256 columns the round is a chain of
+# latencies (DMA wait, barrier, LDS reads of at most four parts), not a queue of requests, and a third workgroup fills it
+VBASE1 = 52
 SBASE = 84           # fixed SGPRs: pc(2) ret(2) tblA(2) tblB(2) t cnt rowbase(2) recsrc(2)
 NCODE = 64          # sequences per staging buffer: index first * 8 + len - 1 (28 of them unused)
 NVREG = 28
@@ -78,7 +82,7 @@ def gen(nv, has_b1, f32=False, compact=True):
     vw = 4 if f32 else 2                            # elements per 16-byte piece
     vgrp = 32 if f32 else 64                        # bytes of one part's 8 values
     vslot = 4 * vgrp
-    b = VBASE
+    b = VBASE if nv == 2 else VBASE1
     A = {"s0": b, "s1": b + 4, "v": b + 8}
     B = {"s0": b + 10, "s1": b + 14, "v": b + 18}
     TA, TV, REC = b + 20, b + 21, b + 22
@@ -284,10 +288,11 @@ def gen(nv, has_b1, f32=False, compact=True):
 def main():
     out = sys.stdout
     out.write("// GENERATED by tools/gen_team2_asm.py -- do not edit; see that script for the design.\n")
-    out.write("// Fixed registers v%d..v%d and s%d..s%d (and m0) must be in the clobber list of the statement.\n"
-              % (VBASE, VBASE + NVREG - 1, SBASE, SBASE + NSREG - 1))
-    out.write("#define CRP_TEAM2_CLOBBERS %s, %s\n" % (", ".join('"v%d"' % r for r in range(VBASE, VBASE + NVREG)),
-                                                      ", ".join('"s%d"' % r for r in range(SBASE, SBASE + NSREG))))
+    out.write("// Fixed registers v%d..v%d (one-piece instances: v%d..v%d) and s%d..s%d (and m0) must be in the clobber list of the statement.\n"
+              % (VBASE, VBASE + NVREG - 1, VBASE1, VBASE1 + NVREG - 1, SBASE, SBASE + NSREG - 1))
+    for name, vb in (("CRP_TEAM2_CLOBBERS", VBASE), ("CRP_TEAM2_CLOBBERS_NV1", VBASE1)):
+        out.write("#define %s %s, %s\n" % (name, ", ".join('"v%d"' % r for r in range(vb, vb + NVREG)),
+                                           ", ".join('"s%d"' % r for r in range(SBASE, SBASE + NSREG))))
     for compact in (True, False):
      for f32 in (False, True):
       for nv in (1, 2):
