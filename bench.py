@@ -196,16 +196,16 @@ def cpu_baseline(rp, ci, va, k, n, budget_s=20.0):
 
 
 def measured_traffic(matrix, data, n, world, kernel_name, dtype="f64"):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r03_traffic.json: 2 x FETCH_SIZE +
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r04_traffic.json: 2 x FETCH_SIZE +
     WRITE_SIZE, gfx950 correction applied; tools/prof_pmc.sh) -- a pointer to that run, not a measurement of this one:
     returned only for the configuration, dtype and kernel it was taken on, with its source; (None, None) otherwise."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r03_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r04_traffic.json")) as f:
             t = json.load(f)
         for e in t["entries"]:
             if world == 1 and data == "synthetic" and e["matrix"] == matrix and e["n"] == n and e["kernel"] == kernel_name and \
                e.get("dtype", "f64") == dtype:
-                return float(e["traffic_bytes_per_launch"]), "profiles/r03_traffic.json: %s" % e["source"]
+                return float(e["traffic_bytes_per_launch"]), "profiles/r04_traffic.json: %s" % e["source"]
     except Exception:
         pass
     return None, None

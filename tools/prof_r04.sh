@@ -23,6 +23,7 @@ pmc)
     fem3d)     bash tools/prof_pmc.sh $OUT/pmc_fem3d --matrix fem3d --n 1024 --host-exec 0 > $OUT/pmc_fem3d.txt 2>&1 ;;
     fem3d_f32) bash tools/prof_pmc.sh $OUT/pmc_fem3d_f32 --matrix fem3d --n 1024 --dtype f32 > $OUT/pmc_fem3d_f32.txt 2>&1 ;;
     queen)
+      mkdir -p $OUT/pmc_queen_f32
       cd /tmp && export TMPDIR=/tmp
       i=0
       for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum"; do
