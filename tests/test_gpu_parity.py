@@ -1006,3 +1006,47 @@ def test_comm_size_on_device_vs_host_planner(crp, orc, gpu, name):
         got_sizes, got_tot = A.row_part_comm_size(rb, xd)
         assert np.array_equal(ref_sizes, got_sizes) and ref_tot == got_tot, (name, m, "ragged")
         A.free()
+
+
+def test_create_with_device_values(crp, orc, gpu):
+    """crp_csr_dev_create_dv: a matrix whose values are in device memory already (the panel a device all-gather replicated,
+    src/para2d_spmm.c:56-86): the whole matrix (values in order) and a row subset (src_start per row), through the CSR kernel, the
+    row-panel kernels and the team kernel (derived formats are built from the host values; both copies agree here by construction),
+    against the oracle."""
+    import ctypes as C
+    import torch
+    from crp_spmm_amd import gen
+    lib = crp.load()
+    _IP, _DP = C.POINTER(C.c_int), C.POINTER(C.c_double)
+    rp, ci, va = gen.banded_fem(6000, offsets=(1, 2, 3, 40, 41, 900), seed=9)
+    m = k = 6000
+    n = 128
+    B = np.random.default_rng(3).uniform(-1, 1, size=(k, n))
+    ref = orc.spmm_csr(rp, ci, va, B)
+    va_dev = torch.from_numpy(va).to(gpu)
+    Bd = _t(B, gpu)
+    h = C.c_void_p()
+    assert lib.crp_csr_dev_create_dv(m, k, rp.ctypes.data_as(_IP), ci.ctypes.data_as(_IP), va.ctypes.data_as(_DP), C.c_void_p(va_dev.data_ptr()), None,
+                                     C.byref(h)) == 0
+    for variant in (1, 3, 5):
+        Cd = torch.full((m, n), float("nan"), dtype=torch.float64, device=gpu)
+        assert lib.crp_spmm_csr_f64(h, 0, n, C.c_void_p(Bd.data_ptr()), n, None, 0, C.c_void_p(Cd.data_ptr()), n, variant, None) == 0
+        torch.cuda.synchronize()
+        assert orc.rel_fro_err(ref, Cd.cpu().numpy()) <= FP64_TOL, variant
+    lib.crp_csr_dev_destroy(C.byref(h))
+    # a row subset: every third row, values gathered on the device from the full matrix's values
+    rows = np.arange(0, m, 3, dtype=np.int32)
+    cnt = (rp[rows + 1] - rp[rows]).astype(np.int64)
+    sub_rp = np.zeros(rows.size + 1, dtype=np.int32)
+    sub_rp[1:] = np.cumsum(cnt)
+    idx = np.concatenate([np.arange(rp[r], rp[r + 1]) for r in rows])
+    sub_ci, sub_va = np.ascontiguousarray(ci[idx]), np.ascontiguousarray(va[idx])
+    start = np.ascontiguousarray(rp[rows], dtype=np.int32)
+    assert lib.crp_csr_dev_create_dv(rows.size, k, sub_rp.ctypes.data_as(_IP), sub_ci.ctypes.data_as(_IP), sub_va.ctypes.data_as(_DP),
+                                     C.c_void_p(va_dev.data_ptr()), start.ctypes.data_as(_IP), C.byref(h)) == 0
+    Cd = torch.full((rows.size, n), float("nan"), dtype=torch.float64, device=gpu)
+    assert lib.crp_spmm_csr_f64(h, 0, n, C.c_void_p(Bd.data_ptr()), n, None, 0, C.c_void_p(Cd.data_ptr()), n, 1, None) == 0
+    torch.cuda.synchronize()
+    assert orc.rel_fro_err(ref[rows], Cd.cpu().numpy()) <= FP64_TOL
+    assert lib.crp_csr_dev_create_dv(m, k, rp.ctypes.data_as(_IP), ci.ctypes.data_as(_IP), va.ctypes.data_as(_DP), None, None, C.byref(h)) == -1
+    lib.crp_csr_dev_destroy(C.byref(h))

@@ -822,3 +822,39 @@ def test_team2r_streams_replay(crp, orc, G):
         got = _replay_team2r(t, m, B, va)
         ref = orc.spmm_csr(rp, ci, va, B)
         assert orc.rel_fro_err(ref, got) <= 1e-13, name
+
+
+def test_lattice_team_order_search(crp, orc, monkeypatch):
+    """The processing order of lattice teams (csrc/team_order.cpp, lattice_block_order): for a 3-D stencil in natural order the order
+    found by the search against the L2 model fetches clearly fewer B rows than the strips along the teeth in tools/l2sim.py's replay
+    (the same model, restated in Python: dispatch in order, 64 resident teams per XCD, an LRU of 2048 row slices); both launch grids
+    name every team once; the streams' product does not depend on the order."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import l2sim
+    from crp_spmm_amd import gen, hip
+    rp, ci, va = gen.fem3d(32)
+    m = len(rp) - 1
+    res = {}
+    for lo in ("0", "1"):
+        monkeypatch.setenv("CRPSPMM_T2_LATORDER", lo)
+        t = hip.team2_format_host(rp, ci, va)
+        assert t["lattice"] and t["nteam"] >= 1024
+        tg = t["tgrid"].reshape(-1)
+        assert np.array_equal(np.sort(tg[tg >= 0]), np.arange(t["nteam"]))
+        req, miss = l2sim.simulate(l2sim.team_rounds(t), None, 2048, 64, grid=t["tgrid"])
+        res[lo] = (miss, req, t)
+    assert res["0"][1] == res["1"][1]                                   # the same rounds, another order
+    assert res["1"][0] < 0.85 * res["0"][0], (res["0"][0], res["1"][0])
+    B = np.random.default_rng(5).uniform(-1, 1, size=(m, 2))
+    got = _replay_team2(res["1"][2], m, B, va)
+    assert orc.rel_fro_err(orc.spmm_csr(rp, ci, va, B, fast=True), got) <= 1e-13
+    # a lattice with few team columns (the pwtk stand-in's shape, scaled down): whatever the search picks is no worse in the model
+    offs = tuple(range(1, 15)) + tuple(range(304, 310)) + tuple(range(3040, 3046))
+    rp, ci, va = gen.banded_fem(9120 * 8, offsets=offs, seed=3)
+    miss = []
+    for lo in ("0", "1"):
+        monkeypatch.setenv("CRPSPMM_T2_LATORDER", lo)
+        t = hip.team2_format_host(rp, ci, va)
+        miss.append(l2sim.simulate(l2sim.team_rounds(t), None, 2048, 64, grid=t["tgrid"])[1])
+    assert miss[1] <= 1.02 * miss[0], miss
