@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B helper for the GPU box: runs bench.py for every (matrix spec) x (environment setting) and prints one line each.
-#   tools/ab.sh OUTDIR "pwtk 256|fem3d 1024 f32|..." "CRPSPMM_T2_CHAIN=0|CRPSPMM_T2_CHAIN=8 CRPSPMM_T2_ORDER=bisect|..."
+#   tools/ab.sh OUTDIR "pwtk 256|fem3d 1024 f32|..." "CRPSPMM_T2_LATORDER=0|CRPSPMM_T2_LATORDER=1|CRPSPMM_LIB_PATH=other/libcrpspmm_hip.so|..."
 # Matrix spec: name, n, optional dtype.  Lines go to OUTDIR/ab.txt as well; bench JSON lines to OUTDIR/*.json.
 set -o pipefail
 OUT=$1; mkdir -p $OUT

@@ -1,15 +1,10 @@
 #!/bin/bash
 # A/B helper for the GPU box: bench.py per (matrix, n) with each kernel variant forced; one line each.
-#   tools/ab_variants.sh OUTDIR "pwtk 64|fem3d 96|..." "0 3 5"
+#   VARIANTS="3 5" tools/ab_variants.sh OUTDIR "pwtk 64|fem3d 96|..."        (default VARIANTS="0 3 5")
 set -o pipefail
 OUT=$1; mkdir -p $OUT
 IFS='|' read -ra MATS <<< "$2"
 STEPS=${STEPS:-100}
-for m in "${MATS[@]}"; do
-  set -- $m
-  name=$1; n=$2; dt=${3:-f64}
-  for v in $3; do :; done
-done
 for m in "${MATS[@]}"; do
   set -- $m
   name=$1; n=$2
