@@ -238,13 +238,13 @@ void crp_spmm_part2d_amortized(const int nproc, const int m, const int n, const 
 }
 
 // Fraction of the HBM roofline (algorithmic bytes) the local kernels reach at a given operand width, measured on
-// MI355X (profiles/r02_sweep_n32_256_1024.jsonl and DESIGN.md section 4): the width a grid leaves every GPU with is
+// MI355X (profiles/r04_sweep_n32_256_1024.jsonl, r04_bench_pwtk_n*.json and DESIGN.md section 4.00): the width a grid leaves every GPU with is
 // part of its price.
 static double kernel_fraction(const int n_local)
 {
-    if (n_local >= 256) return 0.45;
-    if (n_local >= 112) return 0.40;
-    if (n_local > 32) return 0.38;
+    if (n_local >= 256) return 0.44;
+    if (n_local >= 96) return 0.43;          // (round 4: the one-piece team instances run three workgroups per CU)
+    if (n_local > 32) return 0.40;
     if (n_local >= 24) return 0.50;
     return 0.13;
 }

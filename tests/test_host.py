@@ -504,7 +504,7 @@ def test_timed_planner_link_model(crp, orc):
     from crp_spmm_amd import gen, planner
 
     def frac(nl):
-        return 0.45 if nl >= 256 else 0.40 if nl >= 112 else 0.38 if nl > 32 else 0.50 if nl >= 24 else 0.13
+        return 0.44 if nl >= 256 else 0.43 if nl >= 96 else 0.40 if nl > 32 else 0.50 if nl >= 24 else 0.13
 
     def model(P, m, n, rp, ci, rb, rA, link=64e9, hbm=8000e9):
         out = {}
