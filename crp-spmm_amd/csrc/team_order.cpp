@@ -79,7 +79,7 @@ bool lattice_block_order(int nteam, const int *lat, int W, int slots, int lru_ro
         B = std::max(B, lat[(size_t) g * 3 + 1] + 1);
         Tn = std::max(Tn, lat[(size_t) g * 3 + 2] + 1);
     }
-    if (A < 1 || B < 1 || Tn < 1) return false;
+    if (A < 1 || B < 1 || Tn < 1 || A >= (1 << 21) || B >= (1 << 21) || Tn >= (1 << 21)) return false;
     int nb0 = 0, nb1 = 0;                               // row ids: B0 rows, then B1 rows
     for (int g = 0; g < nteam; g++)
         for (long long q = 0; q < (long long) nrounds[g] * W; q++)
@@ -113,19 +113,28 @@ bool lattice_block_order(int nteam, const int *lat, int W, int slots, int lru_ro
     auto make = [&](const Cand &c, std::vector<int> *o) {
         *o = given;
         if (c.pa == 0) return;
-        std::vector<uint64_t> key((size_t) nteam);
+        // sort key = (box, block, position inside the block); 21 bits per block coordinate
+        std::vector<uint64_t> kblk((size_t) nteam);
+        std::vector<uint32_t> kin((size_t) nteam);
         for (int g = 0; g < nteam; g++)
         {
             const int a = lat[(size_t) g * 3], b = lat[(size_t) g * 3 + 1], t = lat[(size_t) g * 3 + 2];
             const int ia = (int) ((long long) a * c.pa / A), ib = (int) ((long long) b * c.pb / B);
             const uint64_t box = (uint64_t) (ia * c.pb + ib);
             const uint64_t Bt = (uint64_t) (t / c.bt), Ba = (uint64_t) (a / c.ba), Bb = (uint64_t) (b / c.bb);
-            const uint64_t blk = (c.flags & 1) ? ((Bt << 24) | (Ba << 12) | Bb) : ((Ba << 24) | (Bb << 12) | Bt);
-            const uint64_t it = (uint64_t) (t % c.bt), ja = (uint64_t) (a % c.ba), jb = (uint64_t) (b % c.bb);
-            const uint64_t in = (c.flags & 2) ? ((it << 12) | (ja << 6) | jb) : ((ja << 12) | (jb << 6) | it);
-            key[(size_t) g] = (box << 56) | (blk << 18) | in;
+            const uint64_t blk = (c.flags & 1) ? ((Bt << 42) | (Ba << 21) | Bb) : ((Ba << 42) | (Bb << 21) | Bt);
+            const uint32_t it = (uint32_t) (t % c.bt), ja = (uint32_t) (a % c.ba), jb = (uint32_t) (b % c.bb);
+            kin[(size_t) g] = (c.flags & 2) ? ((it << 12) | (ja << 6) | jb) : ((ja << 12) | (jb << 6) | it);
+            kblk[(size_t) g] = blk;
+            kin[(size_t) g] |= (uint32_t) box << 18;                  // box in the bits above the in-block position ...
         }
-        std::stable_sort(o->begin(), o->end(), [&](int x, int y) { return key[(size_t) x] < key[(size_t) y]; });
+        // ... but compared FIRST: (box, block, in-block)
+        std::stable_sort(o->begin(), o->end(), [&](int x, int y) {
+            const uint32_t bx = kin[(size_t) x] >> 18, by = kin[(size_t) y] >> 18;
+            if (bx != by) return bx < by;
+            if (kblk[(size_t) x] != kblk[(size_t) y]) return kblk[(size_t) x] < kblk[(size_t) y];
+            return (kin[(size_t) x] & 0x3FFFFu) < (kin[(size_t) y] & 0x3FFFFu);
+        });
     };
     struct Scratch { std::vector<long long> last; std::vector<int> touched; std::vector<std::pair<int, long long>> events; };
     auto cost = [&](const std::vector<int> &o, int sample, std::initializer_list<int> runs, Scratch &sc) {
