@@ -38,8 +38,11 @@ struct PanelDev
 // the row-panel kernel moved down (profiles/r04_team2_min_n.txt, variant 3 / 5: pwtk stand-in n = 80 0.138 / 0.146, n = 96 0.155 /
 // 0.151, n = 112 0.167 / 0.154; shell n = 64 0.120 / 0.119, n = 96 0.166 / 0.137; Queen stand-in n = 64 0.447 / 0.403, n = 96 0.531 / 0.444).
 constexpr int TEAM2_MIN_N = 96;
-// ... where the row-panel format asks for more than 12 B row slices per row of A (Queen / shell stand-ins: 17.8 / 13; pwtk: 10.5)
-constexpr int TEAM2_MIN_N_DENSE = 64;
+// ... where the row-panel format asks for more than 12 B row slices per row of A (Queen / shell stand-ins: 17.8 / 13; pwtk: 10.5).
+// From 48 columns since the HALF-piece instances (operands of at most 64 fp64 / 128 fp32 columns: 8 bytes per lane, one FMA per row
+// and part, four workgroups per CU; profiles/r04_half_piece_instances.txt, variant 3 / 5: Queen stand-in n = 48 0.424 / 0.339 ms,
+// n = 64 0.451 / 0.361; shell n = 64 0.124 / 0.108; pwtk stand-in n = 64 0.119 / 0.126: stays with the row-panel kernel).
+constexpr int TEAM2_MIN_N_DENSE = 48;
 // ... when fewer than 35 % of the (row, entry) pairs of the R = 8 panels are present: the row-panel format then stores mostly
 // zeros (8 values per entry) while the team kernel's value streams are compact (nlpkkt stand-in, fill 0.23, n = 96: 1.26 ms
 // against 1.47; at n = 64 -- half of the kernel's 128-column tile idle -- 1.23 against 1.14, so not below 80)

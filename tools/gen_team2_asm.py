@@ -62,15 +62,22 @@ VBASE = 100          # fixed VGPRs: A0(4) A1(4) AV(2) B0(4) B1(4) BV(2) TA TV RE
 # waves per SIMD = THREE workgroups per CU (their LDS, 43 KiB each, allows it) -- below 256 columns the round is a chain of
 # latencies (DMA wait, barrier, LDS reads of at most four parts), not a queue of requests, and a third workgroup fills it
 VBASE1 = 52
+# ... of the HALF-piece instances (below): 8 accumulator pairs; 64 VGPRs = eight waves per SIMD = FOUR workgroups per CU (27 KiB of LDS each)
+VBASEH = 36
+SBASEH = 56          # ... and their fixed SGPRs: eight waves per SIMD leave a wave 80 SGPRs, the top eight of them reserved (VCC, FLAT_SCRATCH, XNACK_MASK)
 SBASE = 84           # fixed SGPRs: pc(2) ret(2) tblA(2) tblB(2) t cnt rowbase(2) recsrc(2)
 NCODE = 64          # sequences per staging buffer: index first * 8 + len - 1 (28 of them unused)
 NVREG = 28
 NSREG = 14
 
 
-def gen(nv, has_b1, f32=False, compact=True):
+def gen(nv, has_b1, f32=False, compact=True, half=False):
     """nv = 16-byte pieces per lane and row; f32: 4 floats per piece (values 4 bytes, 8 per part = 32 bytes, value
     slot 128 bytes), else 2 doubles per piece (values 8 bytes, 64 bytes per part, value slot 256 bytes).
+    half (nv = 1 only): the HALF-piece instance for operands of at most 64 fp64 / 128 fp32 columns -- a lane holds 8 bytes of a row
+    (one double / two floats), a ring slot is 512 bytes, fetched by the lower 32 lanes of the wave's 16-byte-per-lane DMA (EXEC masked),
+    read back with ds_read_b64; ONE FMA per row and part instead of two half-empty ones, 8 accumulator pairs, and a kernel small enough
+    for four workgroups per CU.
     compact = False: the value blocks hold 8 values per part (part i's row r at 8 i + r): no value position to decode per part and
     a value DMA of fixed size -- two instructions per part and three per round fewer; the instance for panels that are well filled
     (pwtk stand-in, fill 0.61: 3 % faster at n = 256 and 10 % at n = 128 than on compact values; nlpkkt stand-in, 0.23: 2-5 % slower)."""
@@ -82,19 +89,23 @@ def gen(nv, has_b1, f32=False, compact=True):
     vw = 4 if f32 else 2                            # elements per 16-byte piece
     vgrp = 32 if f32 else 64                        # bytes of one part's 8 values
     vslot = 4 * vgrp
-    b = VBASE if nv == 2 else VBASE1
+    assert not half or nv == 1
+    b = VBASE if nv == 2 else (VBASEH if half else VBASE1)
     A = {"s0": b, "s1": b + 4, "v": b + 8}
     B = {"s0": b + 10, "s1": b + 14, "v": b + 18}
     TA, TV, REC = b + 20, b + 21, b + 22
     TP = b + 26                                     # fp32: pair whose low register holds the row's broadcast value
-    PC, RET, TBA, TBB, T, CNT, RB, RS = SBASE, SBASE + 2, SBASE + 4, SBASE + 6, SBASE + 8, SBASE + 9, SBASE + 10, SBASE + 12
-    slotb = 1024 * nv
+    sb = SBASEH if half else SBASE
+    PC, RET, TBA, TBB, T, CNT, RB, RS = sb, sb + 2, sb + 4, sb + 6, sb + 8, sb + 9, sb + 10, sb + 12
+    slotb = 512 if half else 1024 * nv
     setb = tw * slotb
-    slot_shift = 11 if nv == 2 else 10
+    slot_shift = 11 if nv == 2 else (9 if half else 10)
     # 2^x >= the longest sequence: fp64 8 rows x nv * 2 FMAs x 8 bytes + return; fp32 8 rows x (1 + nv * 2) x 8 bytes + return
     seq_align = {(1, False): 8, (2, False): 9, (1, True): 8, (2, True): 9}[(nv, f32)]
+    if half:
+        seq_align = 8 if f32 else 7                  # fp64: 8 rows x 1 FMA x 8 bytes + return; fp32: 8 rows x (1 + 1) x 8 bytes + return
     opr = nv + 1                                    # DMAs a wave issues per round
-    tag = "%s%d%d%s_%%=" % ("s" if f32 else "d", nv, 1 if has_b1 else 0, "" if compact else "f")
+    tag = "%s%s%d%s_%%=" % ("s" if f32 else "d", "h" if half else str(nv), 1 if has_b1 else 0, "" if compact else "f")
     L = []
     emit = L.append
 
@@ -102,7 +113,10 @@ def gen(nv, has_b1, f32=False, compact=True):
         emit("s_bfe_u32 s%d, %%[w0], 0x%x" % (T, (sbits << 16) | (4 + sbits * i)))
         koff = k * setb
         emit("v_lshl_add_u32 v%d, s%d, %d, %%[seta]" % (TA, T, slot_shift))
-        emit("ds_read_b128 v[%d:%d], v%d offset:%d" % (X["s0"], X["s0"] + 3, TA, koff))
+        if half:
+            emit("ds_read_b64 v[%d:%d], v%d offset:%d" % (X["s0"], X["s0"] + 1, TA, koff))
+        else:
+            emit("ds_read_b128 v[%d:%d], v%d offset:%d" % (X["s0"], X["s0"] + 3, TA, koff))
         if nv == 2:
             emit("ds_read_b128 v[%d:%d], v%d offset:%d" % (X["s1"], X["s1"] + 3, TA, koff + 1024))
         if not compact:
@@ -175,7 +189,10 @@ def gen(nv, has_b1, f32=False, compact=True):
             emit("s_addc_u32 s%d, s%d, %%[b1hi]" % (RB + 1, RB + 1))
             emit(".Lt2bj%d%s:" % (k, tag))
         emit("s_add_u32 m0, %%[wslot], %d" % (kd * setb))
-        emit("s_nop 0")
+        if half:
+            emit("s_mov_b64 exec, 0xffffffff")       # 32 lanes x 16 bytes = the 512-byte slice (the value DMA below sets EXEC again)
+        else:
+            emit("s_nop 0")
         emit("global_load_lds_dwordx4 %%[voffa], s[%d:%d]%s" % (RB, RB + 1, BPOL))
         if nv == 2:
             emit("global_load_lds_dwordx4 %%[voffb], s[%d:%d] offset:1024%s" % (RB, RB + 1, BPOL))
@@ -253,6 +270,10 @@ def gen(nv, has_b1, f32=False, compact=True):
         if k == NSET - 1:
             emit("s_branch .Lt2round0%s" % tag)
     # ---- the sequences
+    def aidx(r, v, w):
+        """accumulator pair of row r, piece v, half w of the piece (the half-piece instance has one pair per row)"""
+        return r if half else (r * nv + v) * 2 + w
+
     for bank, (name, X) in [(0, nx) for nx in (("A", A), ("B", B))]:
         code = 0
         for first in range(8):
@@ -271,13 +292,13 @@ def gen(nv, has_b1, f32=False, compact=True):
                         emit("v_mov_b32_dpp v%d, v%d row_newbcast:%d row_mask:0xf bank_mask:0xf" % (TP, X["v"], r))
                     for v in range(nv):
                         base = X["s0"] if v == 0 else X["s1"]
-                        for w in range(2):
+                        for w in range(1 if half else 2):
                             if f32:
                                 emit("v_pk_fma_f32 %%[a%d], v[%d:%d], v[%d:%d], %%[a%d] op_sel_hi:[1,0,1]"
-                                     % (((bank * 8 + r) * nv + v) * 2 + w, base + 2 * w, base + 2 * w + 1, TP, TP + 1, ((bank * 8 + r) * nv + v) * 2 + w))
+                                     % (aidx(r, v, w), base + 2 * w, base + 2 * w + 1, TP, TP + 1, aidx(r, v, w)))
                             else:
                                 emit("v_fmac_f64_dpp %%[a%d], v[%d:%d], v[%d:%d] row_newbcast:%d row_mask:0xf bank_mask:0xf"
-                                     % (((bank * 8 + r) * nv + v) * 2 + w, X["v"], X["v"] + 1, base + 2 * w, base + 2 * w + 1, r))
+                                     % (aidx(r, v, w), X["v"], X["v"] + 1, base + 2 * w, base + 2 * w + 1, r))
                 emit("s_setpc_b64 s[%d:%d]" % (RET, RET + 1))
         assert code == NCODE
     emit(".Lt2done%s:" % tag)
@@ -290,15 +311,15 @@ def main():
     out.write("// GENERATED by tools/gen_team2_asm.py -- do not edit; see that script for the design.\n")
     out.write("// Fixed registers v%d..v%d (one-piece instances: v%d..v%d) and s%d..s%d (and m0) must be in the clobber list of the statement.\n"
               % (VBASE, VBASE + NVREG - 1, VBASE1, VBASE1 + NVREG - 1, SBASE, SBASE + NSREG - 1))
-    for name, vb in (("CRP_TEAM2_CLOBBERS", VBASE), ("CRP_TEAM2_CLOBBERS_NV1", VBASE1)):
+    for name, vb, sb in (("CRP_TEAM2_CLOBBERS", VBASE, SBASE), ("CRP_TEAM2_CLOBBERS_NV1", VBASE1, SBASE), ("CRP_TEAM2_CLOBBERS_H", VBASEH, SBASEH)):
         out.write("#define %s %s, %s\n" % (name, ", ".join('"v%d"' % r for r in range(vb, vb + NVREG)),
-                                           ", ".join('"s%d"' % r for r in range(SBASE, SBASE + NSREG))))
+                                           ", ".join('"s%d"' % r for r in range(sb, sb + NSREG))))
     for compact in (True, False):
      for f32 in (False, True):
-      for nv in (1, 2):
+      for nv in (0, 1, 2):                          # 0 = the half-piece instance
         for hb in (0, 1):
-            out.write("#define CRP_TEAM2_LOOP_%s_NV%d_B%d%s \\\n" % ("F32" if f32 else "F64", nv, hb, "" if compact else "_F"))
-            lines = gen(nv, bool(hb), f32, compact)
+            out.write("#define CRP_TEAM2_LOOP_%s_NV%s_B%d%s \\\n" % ("F32" if f32 else "F64", nv if nv else "H", hb, "" if compact else "_F"))
+            lines = gen(max(nv, 1), bool(hb), f32, compact, half=(nv == 0))
             for k, l in enumerate(lines):
                 sep = "\\n\\t" if not l.endswith(":") else "\\n"
                 last = k == len(lines) - 1
