@@ -157,12 +157,9 @@ def gen(nv, has_b1, f32=False, compact=True, half=False):
         kd = (k + D) % NSET                          # set of round r + D
         emit(".Lt2round%d%s:" % (k, tag))
         emit("s_bitcmp1_b32 %%[w0], %d" % (fbase + 1))
-        emit("s_cbranch_scc1 .Lt2tw%d%s" % (k, tag))
+        emit("s_cbranch_scc1 .Lt2tw%d%s" % (k, tag))     # TAIL: out of line (behind the loop), back at .Lt2bar
         emit("s_waitcnt vmcnt(%d)" % ((D - 1) * opr))
-        emit("s_barrier")
-        emit("s_branch .Lt2body%d%s" % (k, tag))
-        emit(".Lt2tw%d%s:" % (k, tag))
-        emit("s_waitcnt vmcnt(0)")
+        emit(".Lt2bar%d%s:" % (k, tag))
         emit("s_barrier")
         emit(".Lt2body%d%s:" % (k, tag))
         # -- issue for round r + D.  The B row first: every wave of the workgroup runs this block right behind the barrier, all
@@ -171,6 +168,8 @@ def gen(nv, has_b1, f32=False, compact=True, half=False):
         # them the pwtk stand-in ran 6 % slower).
         emit("s_bitcmp1_b32 %%[w0], %d" % fbase)
         emit("s_cbranch_scc0 .Lt2ni%d%s" % (k, tag))
+        # (M0 first: the scalar instructions of the address stand between its write and the DMA that reads it -- no s_nop)
+        emit("s_add_u32 m0, %%[wslot], %d" % (kd * setb))
         if has_b1:
             # c < 0: row ~c of B1
             emit("s_cmp_lt_i32 %[w3], 0")
@@ -188,16 +187,14 @@ def gen(nv, has_b1, f32=False, compact=True, half=False):
             emit("s_add_u32 s%d, s%d, %%[b1lo]" % (RB, RB))
             emit("s_addc_u32 s%d, s%d, %%[b1hi]" % (RB + 1, RB + 1))
             emit(".Lt2bj%d%s:" % (k, tag))
-        emit("s_add_u32 m0, %%[wslot], %d" % (kd * setb))
         if half:
             emit("s_mov_b64 exec, 0xffffffff")       # 32 lanes x 16 bytes = the 512-byte slice (the value DMA below sets EXEC again)
-        else:
-            emit("s_nop 0")
         emit("global_load_lds_dwordx4 %%[voffa], s[%d:%d]%s" % (RB, RB + 1, BPOL))
         if nv == 2:
             emit("global_load_lds_dwordx4 %%[voffb], s[%d:%d] offset:1024%s" % (RB, RB + 1, BPOL))
         # the wave's value block of round r + D: offset in units of 4 values, 4 (q + 1) lanes of 16 bytes (fp32: 2 (q + 1))
         emit("s_and_b32 s%d, %%[w2], 0xfffff" % T)
+        emit("s_add_u32 m0, %%[vringw], %d" % (kd * vslot))      # (early: no s_nop in front of the DMA that reads it)
         emit("v_lshl_add_u32 v%d, s%d, %d, %%[lane16]" % (TV, T, 4 if f32 else 5))
         if compact:
             emit("s_bfe_u32 s%d, %%[w1], 0x2001e" % T)
@@ -208,8 +205,6 @@ def gen(nv, has_b1, f32=False, compact=True, half=False):
             emit("s_bfm_b64 exec, s%d, 0" % T)
         else:
             emit("s_mov_b64 exec, 0x%x" % ((1 << (vslot // 16)) - 1))
-        emit("s_add_u32 m0, %%[vringw], %d" % (kd * vslot))
-        emit("s_nop 0")
         emit("global_load_lds_dwordx4 v%d, %%[vbase]%s" % (TV, APOL))
         emit("s_mov_b64 exec, -1")
         emit(".Lt2ni%d%s:" % (k, tag))
@@ -234,18 +229,21 @@ def gen(nv, has_b1, f32=False, compact=True, half=False):
             emit("v_add_u32 %[recaddr], %[recbase], %[recoff]")
             emit("ds_read_b128 v[%d:%d], %%[recaddr]" % (REC, REC + 3))
         # -- parts
+        # (two compares on the way to the common counts 3 and 4, three to the others)
         emit("s_and_b32 s%d, %%[w0], 7" % CNT)
-        emit("s_cmp_eq_u32 s%d, 0" % CNT)
-        emit("s_cbranch_scc1 .Lt2pe%d%s" % (k, tag))
-        emit("s_cmp_eq_u32 s%d, 1" % CNT)
-        emit("s_cbranch_scc1 .Lt2v%d_1%s" % (k, tag))
-        emit("s_cmp_eq_u32 s%d, 2" % CNT)
-        emit("s_cbranch_scc1 .Lt2v%d_2%s" % (k, tag))
+        emit("s_cmp_lt_u32 s%d, 3" % CNT)
+        emit("s_cbranch_scc1 .Lt2lo%d%s" % (k, tag))
         emit("s_cmp_eq_u32 s%d, 3" % CNT)
         emit("s_cbranch_scc1 .Lt2v%d_3%s" % (k, tag))
         nrd = nv + 1
         for c in (4, 3, 2, 1):
-            if c != 4:
+            if c == 2:
+                emit(".Lt2lo%d%s:" % (k, tag))
+                emit("s_cmp_eq_u32 s%d, 0" % CNT)
+                emit("s_cbranch_scc1 .Lt2pe%d%s" % (k, tag))
+                emit("s_cmp_eq_u32 s%d, 1" % CNT)
+                emit("s_cbranch_scc1 .Lt2v%d_1%s" % (k, tag))
+            if c in (3, 1):
                 emit(".Lt2v%d_%d%s:" % (k, c, tag))
             bufs = [(A, TBA), (B, TBB)]
             rd(k, 0, A)
@@ -269,6 +267,11 @@ def gen(nv, has_b1, f32=False, compact=True, half=False):
         emit("v_readfirstlane_b32 %%[w3], v%d" % (REC + 3))
         if k == NSET - 1:
             emit("s_branch .Lt2round0%s" % tag)
+    # ---- out of line: the TAIL wait of every unrolled round
+    for k in range(NSET):
+        emit(".Lt2tw%d%s:" % (k, tag))
+        emit("s_waitcnt vmcnt(0)")
+        emit("s_branch .Lt2bar%d%s" % (k, tag))
     # ---- the sequences
     def aidx(r, v, w):
         """accumulator pair of row r, piece v, half w of the piece (the half-piece instance has one pair per row)"""
