@@ -545,22 +545,28 @@ def test_team2_two_source_nonfinite_update_rowmap(crp, orc, gpu, monkeypatch, va
     pos = np.full(k, -1)
     pos[remote_rows] = np.arange(remote_rows.size)
     c2 = np.where((ci >= lo) & (ci < hi), ci - lo, ~pos[ci]).astype(np.int32)
-    for n_ in (48, 200):
+    for n_ in (48, 100, 200):                  # the half-piece, one-piece and two-piece instances
         B = np.random.default_rng(n_).normal(size=(k, n_))
         got = _spmm(crp, gpu, rp, c2, va, hi - lo, B[lo:hi], n_, B1=B[remote_rows], variant=5)
         assert orc.rel_fro_err(orc.spmm_csr(rp, ci, va, B), got) <= FP64_TOL, n_
     # non-finite B rows
-    n = 136
-    B = np.random.default_rng(5).normal(size=(k, n))
-    used = np.unique(ci)
-    B[used[::17]] = np.inf
-    B[used[5::29]] = np.nan
-    ref = orc.spmm_csr(rp, ci, va, B)
-    got = _spmm(crp, gpu, rp, ci, va, k, B, n, variant=5)
-    assert np.array_equal(np.isnan(ref), np.isnan(got)) and np.array_equal(np.isinf(ref), np.isinf(got))
-    fin = np.isfinite(ref)
-    assert np.abs(ref[fin] - got[fin]).max() <= 1e-12 * np.abs(ref[fin]).max()
+    for n in (40, 104, 136):
+        B = np.random.default_rng(5).normal(size=(k, n))
+        used = np.unique(ci)
+        B[used[::17]] = np.inf
+        B[used[5::29]] = np.nan
+        ref = orc.spmm_csr(rp, ci, va, B)
+        got = _spmm(crp, gpu, rp, ci, va, k, B, n, ldpad=2 if n == 104 else 0, variant=5)
+        assert np.array_equal(np.isnan(ref), np.isnan(got)) and np.array_equal(np.isinf(ref), np.isinf(got)), n
+        fin = np.isfinite(ref)
+        assert np.abs(ref[fin] - got[fin]).max() <= 1e-12 * np.abs(ref[fin]).max(), n
     # value update + repeats + row map
+    for n in (40, 104, 136):
+        _team2_update_and_repeat(crp, orc, gpu, hip, lib, m, k, rp, ci, va, n)
+
+
+def _team2_update_and_repeat(crp, orc, gpu, hip, lib, m, k, rp, ci, va, n):
+    import torch
     A = hip.CsrDev(m, k, rp, ci, va)
     Bf = np.random.default_rng(6).normal(size=(k, n))
     Bd = _t(Bf, gpu)
