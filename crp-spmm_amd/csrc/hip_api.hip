@@ -38,7 +38,8 @@ struct PanelDev
 // the row-panel kernel moved down (profiles/r04_team2_min_n.txt, variant 3 / 5: pwtk stand-in n = 80 0.138 / 0.146, n = 96 0.155 /
 // 0.151, n = 112 0.167 / 0.154; shell n = 64 0.120 / 0.119, n = 96 0.166 / 0.137; Queen stand-in n = 64 0.447 / 0.403, n = 96 0.531 / 0.444).
 constexpr int TEAM2_MIN_N = 96;
-// ... where the row-panel format asks for more than 12 B row slices per row of A (Queen / shell stand-ins: 17.8 / 13; pwtk: 10.5).
+// ... where the row-panel format asks for more than 12 B row slices per row of A (Queen stand-in: 17.3; pwtk: 10.4), or the matrix has
+// no stride lattice (the row-panel kernel then runs without its team schedule).
 // From 48 columns since the HALF-piece instances (operands of at most 64 fp64 / 128 fp32 columns: 8 bytes per lane, one FMA per row
 // and part, four workgroups per CU; profiles/r04_half_piece_instances.txt, variant 3 / 5: Queen stand-in n = 48 0.424 / 0.339 ms,
 // n = 64 0.451 / 0.361; shell n = 64 0.124 / 0.108; pwtk stand-in n = 64 0.119 / 0.126: stays with the row-panel kernel).
@@ -678,7 +679,14 @@ static int csr_dev_create_impl(int nrow, int ncol, const int *rowptr, const int 
         // 0.73 / 1.34 / 1.95 through CSR and 1.00 / 1.10 / 1.45 on R = 4; the shell stand-in 0.106 / 0.129 against 0.135 / 0.144
         // on R = 4.  Erdos-Renyi (e8 = nnz) stays with CSR.
         if ((double) e8 <= 0.6 * (double) nnz) A->auto_variant = 3;
-        if ((double) e8 > 12.0 * (double) nrow) A->team2_min_n = TEAM2_MIN_N_DENSE;
+        // ... or has no lattice team schedule to time its panels' shared rows in L2 (shell stand-in, locality order: n = 64 0.122 ms on the
+        // row-panel kernel, 0.103 on the team kernel; the pwtk stand-in, a lattice with 10.4 slices per row: 0.115 / 0.120)
+        {
+            double D1 = 0, D2 = 0;
+            int M = 0;
+            const bool lat = nrow >= 4096 && crp::detect_stride_lattice(nrow, fmt_rowptr(A), fmt_colidx(A), 8, &D1, &D2, &M);
+            if (!lat || (double) e8 > 12.0 * (double) nrow) A->team2_min_n = TEAM2_MIN_N_DENSE;
+        }
         if ((double) nnz < 0.35 * 8.0 * (double) e8)
         {
             A->team2_min_n = TEAM2_MIN_N_SPARSE;
