@@ -130,6 +130,7 @@ int main()
         std::vector<Csr> t2 = mats;
         t2.push_back(banded(9120, {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 304, 305, 306, 307, 308, 309, 3040, 3041, 3042, 3043, 3044, 3045}));
         t2.push_back(banded(300 * 40 + 5, {1, 2, 300, 301, 302}));          // enough teams for super-teams (>= 128)
+        t2.push_back(banded(96 * 32 * 32 + 3, {1, 2, 3, 96, 97, 96 * 32, 96 * 32 + 1}));   // a lattice with >= 1024 teams: the order search (team_order.cpp)
         for (const Csr &a : t2)
         {
             crp::PanelHost h8;
