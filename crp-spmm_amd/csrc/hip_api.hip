@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <new>
+#include <memory>
 #include <algorithm>
 #include <vector>
 #include "crpspmm_hip.h"
@@ -119,6 +120,11 @@ struct crp_csr_dev
     // crp_csr_dev_update_values() with a DEVICE pointer leaves the host copies (h_val / f_val) behind: formats built
     // afterwards take their values from the device CSR through their fresh slot maps (refresh_values_after_build)
     bool      host_vals_stale = false;
+    // The R = 8 panels in column order WITHOUT values (pcol, masks, slot map: 7 bytes per nonzero at fill 0.23) and the teams built on
+    // them: shared by the team formats of this matrix (team2, team2r for <= 32 and <= 64 columns) -- a further operand width costs the
+    // streams of its format, not the panels and the clustering again.  Dropped once all three exist.
+    std::unique_ptr<crp::PanelHost> skel8;
+    crp::TeamSeed seed8;
 };
 
 static const int *fmt_rowptr(const crp_csr_dev *A) { return A->perm.empty() ? A->h_rowptr.data() : A->f_rowptr.data(); }
@@ -131,6 +137,27 @@ static void fmt_slotmap_to_caller(const crp_csr_dev *A, crp::big_vector<uint32_t
     crp::big_vector<uint32_t> out(pmap->size());
     for (size_t pz = 0; pz < pmap->size(); pz++) out[(size_t) A->f_nz[pz]] = (*pmap)[pz];
     pmap->swap(out);
+}
+
+// the shared structure-only panels (see crp_csr_dev::skel8)
+static const crp::PanelHost &panel_skeleton(crp_csr_dev *A)
+{
+    if (!A->skel8)
+    {
+        A->skel8.reset(new crp::PanelHost);
+        crp::build_panels(A->nrow, fmt_rowptr(A), fmt_colidx(A), nullptr, 8, A->skel8.get(), false, false);
+        fmt_slotmap_to_caller(A, &A->skel8->pmap);
+    }
+    return *A->skel8;
+}
+static void drop_skeleton_when_done(crp_csr_dev *A)
+{
+    const bool r0 = A->team2r[0].built || A->team2r[0].refused, r1 = A->team2r[1].built || A->team2r[1].refused;
+    if (A->team2.built && r0 && r1)
+    {
+        A->skel8.reset();
+        A->seed8 = crp::TeamSeed();
+    }
 }
 
 #define CRP_TRY(expr)                                 \
@@ -232,11 +259,8 @@ static int ensure_team2(crp_csr_dev *A, hipStream_t stream)
     Team2Dev &t = A->team2;
     if (t.built) return 0;
     crp::PhaseClock clk;
-    crp::released_async<crp::PanelHost> h_owner;          // (freed by a background thread when this function returns)
-    crp::PanelHost &h = *h_owner;
-    crp::build_panels(A->nrow, fmt_rowptr(A), fmt_colidx(A), fmt_val(A), 8, &h, false, false);
-    fmt_slotmap_to_caller(A, &h.pmap);
-    clk.lap("ensure_team2: build_panels (R = 8)");
+    const crp::PanelHost &h = panel_skeleton(A);
+    clk.lap("ensure_team2: build_panels (R = 8, structure only)");
     crp::released_async<crp::Team2Host> th_owner;
     crp::Team2Host &th = *th_owner;
     // Value blocks: compact (only the values that exist) when under 40 % of the (row, entry) pairs of the panels exist, 8 per
@@ -250,7 +274,7 @@ static int ensure_team2(crp_csr_dev *A, hipStream_t stream)
         colpos.resize(A->perm.size());
         for (size_t i = 0; i < A->perm.size(); i++) colpos[(size_t) A->perm[i]] = (int) i;
     }
-    crp::build_team2(h, A->nrow, fmt_rowptr(A), fmt_colidx(A), &th, colpos.empty() ? nullptr : colpos.data());
+    crp::build_team2(h, A->nrow, fmt_rowptr(A), fmt_colidx(A), &th, colpos.empty() ? nullptr : colpos.data(), &A->seed8);
     clk.lap("ensure_team2: build_team2");
     t.nteam = th.nteam;
     t.entries = th.real_entries;
@@ -270,13 +294,17 @@ static int ensure_team2(crp_csr_dev *A, hipStream_t stream)
     t.value_entries = th.nvalues;          // values of the streams
     t.compact = th.compact;
     if (e == hipSuccess) e = up((void **) &t.tvoff, th.tvoff.data(), sizeof(long long) * th.tvoff.size(), 8);
-    // the kernel requests 256 bytes per wave and round: up to four groups past a wave's last part
-    if (e == hipSuccess) e = up((void **) &t.tval, th.tval.data(), sizeof(double) * th.tval.size(), 4096);
+    // the kernel requests 256 bytes per wave and round: up to four groups past a wave's last part.  The streams start as zeros in
+    // HBM and take their values from the device CSR through the slot map: no copy of them is ever made on the host.
+    if (e == hipSuccess) e = hipMalloc((void **) &t.tval, sizeof(double) * (size_t) th.nvalues + 4096);
+    if (e == hipSuccess) e = hipMemsetAsync(t.tval, 0, sizeof(double) * (size_t) th.nvalues + 4096, stream);
     if (e == hipSuccess) e = up((void **) &t.tmap, th.vmap.data(), sizeof(uint32_t) * th.vmap.size(), 4);
     if (e != hipSuccess) return (int) e;
-    if (A->host_vals_stale && A->nnz > 0) CRP_TRY(crp::scatter_vals_f64(A->nnz, t.tmap, A->val, t.tval, stream));
+    if (A->nnz > 0) CRP_TRY(crp::scatter_vals_f64(A->nnz, t.tmap, A->val, t.tval, stream));
+    CRP_TRY(hipStreamSynchronize(stream));
     clk.lap("ensure_team2: upload");
     t.built = true;
+    drop_skeleton_when_done(A);
     return 0;
 }
 
@@ -294,11 +322,8 @@ static int ensure_team2r(crp_csr_dev *A, hipStream_t stream, int G)
     // a cheap bound first: a wave's block takes at least 10 bytes per nonzero (value + offset), and the streams address 34 GB
     if ((double) A->nnz * 10.0 > 34.0e9) { t.refused = true; return -6; }
     crp::PhaseClock clk;
-    crp::released_async<crp::PanelHost> h_owner;
-    crp::PanelHost &h = *h_owner;
-    crp::build_panels(A->nrow, fmt_rowptr(A), fmt_colidx(A), fmt_val(A), 8, &h, false, false);
-    fmt_slotmap_to_caller(A, &h.pmap);
-    clk.lap("ensure_team2r: build_panels (R = 8)");
+    const crp::PanelHost &h = panel_skeleton(A);
+    clk.lap("ensure_team2r: build_panels (R = 8, structure only)");
     crp::released_async<crp::Team2RHost> th_owner;
     crp::Team2RHost &th = *th_owner;
     th.G = G == 2 ? 2 : 4;
@@ -308,12 +333,13 @@ static int ensure_team2r(crp_csr_dev *A, hipStream_t stream, int G)
         colpos.resize(A->perm.size());
         for (size_t i = 0; i < A->perm.size(); i++) colpos[(size_t) A->perm[i]] = (int) i;
     }
-    if (!crp::build_team2r(h, A->nrow, fmt_rowptr(A), fmt_colidx(A), &th, colpos.empty() ? nullptr : colpos.data()))
+    if (!crp::build_team2r(h, A->nrow, fmt_rowptr(A), fmt_colidx(A), &th, colpos.empty() ? nullptr : colpos.data(), &A->seed8))
     {
         t.refused = true;                   // too large for this format
+        drop_skeleton_when_done(A);
         return -6;
     }
-    clk.lap("ensure_team2r: build_team2n");
+    clk.lap("ensure_team2r: build_team2r");
     t.G = th.G;
     t.nteam = th.nteam;
     t.lattice = th.lattice;
@@ -336,9 +362,12 @@ static int ensure_team2r(crp_csr_dev *A, hipStream_t stream, int G)
     if (e == hipSuccess) e = up((void **) &t.tent, th.tent.data(), sizeof(uint32_t) * th.tent.size(), 1024);
     t.rows_epoch = -1;
     if (e != hipSuccess) return (int) e;
-    if (A->host_vals_stale && A->nnz > 0) CRP_TRY(crp::scatter_vals_f64(A->nnz, t.tmap, A->val, t.tval, stream));
+    // (the streams were uploaded with their offsets and headers and 0.0 for every value: the values come from the device CSR)
+    if (A->nnz > 0) CRP_TRY(crp::scatter_vals_f64(A->nnz, t.tmap, A->val, t.tval, stream));
+    CRP_TRY(hipStreamSynchronize(stream));
     clk.lap("ensure_team2r: upload");
     t.built = true;
+    drop_skeleton_when_done(A);
     return 0;
 }
 

@@ -122,10 +122,22 @@ struct TeamHost
     long long real_entries = 0;    // union entries before padding
     std::vector<int>      lat_key; // lattice teams: 3 per team -- team column (a, b) and position t along the teeth (team_order.h, lattice_block_order)
 };
+// What build_teams decides before it lays the entries out -- which panels form a team and in what order the teams are processed.
+// A matrix builds up to three formats on the same teams (team2, team2r for 32 and for 64 columns): the first build fills the seed,
+// the others take the teams from it (panel clustering and super-team order are 40 % of build_teams on the nlpkkt240-size matrix).
+struct TeamSeed
+{
+    bool valid = false;
+    int T = 0, np = 0;
+    bool lattice = false, clustered = false;
+    std::vector<int> team_of, slot_of;     // clustered teams: team and slot of every panel
+    std::vector<int> torder;
+};
 // colpos (optional, matrices in a locality order): position of row c of A in the order the panels were built on.
 // balanced = false: the union entries of a team stay in column order (the caller orders them itself).
 void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *colidx, TeamHost *out, int T = 4, const int *colpos = nullptr,
-                 bool balanced = true, int mix_mode = -1);      // mix_mode: panels of two kinds in one team (median-column order): -1 = by rule, 0 / 1
+                 bool balanced = true, int mix_mode = -1,       // mix_mode: panels of two kinds in one team (median-column order): -1 = by rule, 0 / 1
+                 TeamSeed *seed = nullptr);
 
 // Team schedule for the row-panel kernel itself (no LDS sharing): the entries of every panel are
 // re-ordered to the order in which its wave meets them in the team's balanced schedule, and the
@@ -176,7 +188,7 @@ struct Team2Host
     std::vector<int>       tpro;     // nteam * TEAM2_D * 8 * 2: {column, value offset} wave w fetches for round d < TEAM2_D
     big_vector<uint32_t>   trec;     // record blocks: 256 words each (8 rounds x 8 waves x 4)
     std::vector<long long> tvoff;    // 8 * nteam + 1: first value unit of wave w's stream
-    big_vector<double>     tval;     // the value streams
+    big_vector<double>     tval;     // the value streams (empty when the panels came without values: the caller scatters them through vmap)
     std::vector<uint32_t>  vmap;     // per CSR nonzero (panel format's own order of pmap): its slot in tval
     long long nvalues = 0;           // values in tval (blocks padded to TEAM2_VUNIT)
     long long real_entries = 0;      // union entries (filled slots)
@@ -187,7 +199,9 @@ struct Team2Host
 // build vmap (indexed like p.pmap: by the CSR nonzero position the panels were built from).
 // colpos (optional, square matrices in a locality order): position of row c of B in the processing order of the
 // rows of A, for the phase key of the union order (see build_team2); NULL = the column index itself.
-void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *colidx, Team2Host *out, const int *colpos = nullptr);
+// Panels built without values (build_panels(val = NULL)): tval stays empty, nvalues says how many zeros to allocate, and the values go in
+// through vmap (on the device: scatter_vals_f64 from the CSR values already in HBM -- no 8-values-per-entry copy on the host at all).
+void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *colidx, Team2Host *out, const int *colpos = nullptr, TeamSeed *seed = nullptr);
 
 // ---- team2r: the streams of the row-owner team kernel (csrc/team2r_kernel.hip) -- narrow operands, panels that are mostly holes --
 // Operands of at most 64 fp64 columns: a B row slice fills a quarter (n <= 32) or half (n <= 64) of a wave.  Same teams as team2 (8 panels on
@@ -222,12 +236,12 @@ struct Team2RHost
     big_vector<uint32_t>   trec;     // 128 words per round
     big_vector<uint32_t>   tent;     // 256 words per entry of tgrid
     std::vector<long long> tvoff;    // 8 * nteam + 1, units of 16 bytes
-    big_vector<double>     tval;     // the streams, as 8-byte words
+    big_vector<double>     tval;     // the streams, as 8-byte words (panels without values: the value words stay 0.0, offsets and headers are written)
     std::vector<uint32_t>  vmap;     // per CSR nonzero: its 8-byte word in tval
     long long nwords = 0, rounds = 0, steps = 0, nnz = 0, slots_filled = 0;   // steps = sum of Lp over (round, wave)
 };
 // false: the streams would pass what their 32-bit offsets address (34 GB); nothing usable in *out then
-bool build_team2r(const PanelHost &p, int nrow, const int *rowptr, const int *colidx, Team2RHost *out, const int *colpos = nullptr);
+bool build_team2r(const PanelHost &p, int nrow, const int *rowptr, const int *colidx, Team2RHost *out, const int *colpos = nullptr, TeamSeed *seed = nullptr);
 
 // Number of panel entries (before padding) a given R would need: cheap pass used
 // to pick R.  colidx may carry the two-source encoding.
@@ -239,7 +253,7 @@ long long count_block_union(int nrow, const int *rowptr, const int *colidx, int 
 
 // team_schedule = false keeps the entries of every panel in column order whatever CRPSPMM_PANEL_ORDER
 // says (the team format is built on that order).  need_order = false skips the processing order (porder stays empty):
-// the team formats bring their own.
+// the team formats bring their own.  val = NULL: structure only (pval stays empty; pmap says where every nonzero's value belongs).
 void build_panels(int nrow, const int *rowptr, const int *colidx, const double *val, int R, PanelHost *out,
                   bool team_schedule = true, bool need_order = true);
 

@@ -173,6 +173,36 @@ int main()
                 for (int g = 0; g < tr.nteam; g++) rounds += tr.tinfo[(size_t) g * 2];
                 if (rounds != tr.rounds) { printf("FAIL team2r rounds\n"); return 1; }
             }
+            // what the device path does (hip_api.hip, panel_skeleton): panels without values, the teams of the first format seed the
+            // next ones, values scattered through vmap -- the same streams as the full builds above
+            {
+                auto differs = [](const void *x, const void *y, size_t bytes) { return bytes > 0 && memcmp(x, y, bytes) != 0; };
+                crp::PanelHost sk;
+                crp::build_panels(a.m, a.rp.data(), a.ci.data(), nullptr, 8, &sk, false, false);
+                if (!sk.pval.empty() || sk.pcol.size() != h8.pcol.size() || differs(sk.pmap.data(), h8.pmap.data(), sizeof(uint32_t) * sk.pmap.size()))
+                { printf("FAIL structure-only panels\n"); return 1; }
+                crp::TeamSeed seed;
+                crp::Team2Host t0;
+                t0.compact = t.compact;
+                crp::build_team2(sk, a.m, a.rp.data(), a.ci.data(), &t0, pos.empty() ? nullptr : pos.data(), &seed);
+                if (!t0.tval.empty() || t0.nvalues != t.nvalues || t0.trec.size() != t.trec.size() || t0.tgrid != t.tgrid || t0.tinfo != t.tinfo || t0.tvoff != t.tvoff
+                    || t0.vmap != t.vmap || t0.tpro != t.tpro || differs(t0.trec.data(), t.trec.data(), sizeof(uint32_t) * t.trec.size()))
+                { printf("FAIL team2 from structure-only panels\n"); return 1; }
+                if (a.m >= 16 && !seed.valid) { printf("FAIL seed not filled\n"); return 1; }
+                for (int G : {4, 2})
+                {
+                    crp::Team2RHost full, tr;
+                    full.G = tr.G = G;
+                    if (!crp::build_team2r(h8, a.m, a.rp.data(), a.ci.data(), &full, pos.empty() ? nullptr : pos.data())) { printf("FAIL team2r refused\n"); return 1; }
+                    if (!crp::build_team2r(sk, a.m, a.rp.data(), a.ci.data(), &tr, pos.empty() ? nullptr : pos.data(), &seed)) { printf("FAIL team2r refused (seeded)\n"); return 1; }
+                    if (tr.tgrid != full.tgrid || tr.tinfo != full.tinfo || tr.tvoff != full.tvoff || tr.vmap != full.vmap || tr.tval.size() != full.tval.size()
+                        || tr.trec.size() != full.trec.size() || differs(tr.trec.data(), full.trec.data(), sizeof(uint32_t) * full.trec.size())
+                        || tr.tent.size() != full.tent.size() || differs(tr.tent.data(), full.tent.data(), sizeof(uint32_t) * full.tent.size()))
+                    { printf("FAIL seeded team2r structure\n"); return 1; }
+                    for (size_t p2 = 0; p2 < tr.vmap.size(); p2++) tr.tval[tr.vmap[p2]] = a.va[p2];
+                    if (differs(tr.tval.data(), full.tval.data(), sizeof(double) * full.tval.size())) { printf("FAIL seeded team2r streams\n"); return 1; }
+                }
+            }
         }
     }
 
