@@ -485,7 +485,7 @@ void locality_order(const PanelHost &p, int group, std::vector<int> *order)
 // ratio = true: the item that has the largest FRACTION of its own keys in the union already (ties: more shared keys) --
 // an item whose keys are a subset of the group's costs the group nothing, however short its list (the 7-point dual
 // rows of a KKT system next to the 27-point primal rows of the same nodes).
-static void greedy_cluster(int n, const std::vector<long long> &iptr, const std::vector<uint32_t> &ikey, int G, int span,
+static void greedy_cluster(int n, const std::vector<long long> &iptr, const big_vector<uint32_t> &ikey, int G, int span,
                            std::vector<int> *group_of, std::vector<int> *slot_of, int *ngroups, bool ratio = false)
 {
     group_of->assign((size_t) n, -1);
@@ -497,15 +497,15 @@ static void greedy_cluster(int n, const std::vector<long long> &iptr, const std:
         {
             const int i0 = (int) rg * span, i1 = std::min(n, i0 + span), cnt = i1 - i0;
             // inverted index of the range: (key, item) pairs sorted by key
-            std::vector<std::pair<uint32_t, int>> pairs;
+            big_vector<std::pair<uint32_t, int>> pairs;          // (big_vector: huge pages for the range's tens of megabytes, par.h)
             pairs.reserve((size_t) (iptr[(size_t) i1] - iptr[(size_t) i0]));
             for (int i = i0; i < i1; i++)
                 for (long long q = iptr[(size_t) i]; q < iptr[(size_t) i + 1]; q++) pairs.push_back({ikey[(size_t) q], i - i0});
             std::sort(pairs.begin(), pairs.end());
             // dense local key ids
             std::vector<long long> kptr;
-            std::vector<int> kitem(pairs.size());
-            std::vector<int> lkey(pairs.size());               // per pair (in item order below): local key id
+            big_vector<int> kitem(pairs.size());
+            big_vector<int> lkey(pairs.size());                 // per pair (in item order below): local key id
             for (size_t t = 0; t < pairs.size(); t++)
             {
                 if (t == 0 || pairs[t].first != pairs[t - 1].first) kptr.push_back((long long) t);
@@ -600,16 +600,16 @@ static void greedy_cluster(int n, const std::vector<long long> &iptr, const std:
 
 // CSR of sorted distinct keys per item, built in parallel: raw(i, buf) appends item i's keys to buf.
 template <typename F>
-static void build_key_csr(int n, F raw, std::vector<long long> *iptr, std::vector<uint32_t> *ikey)
+static void build_key_csr(int n, F raw, std::vector<long long> *iptr, big_vector<uint32_t> *ikey)
 {
     constexpr int CH = 2048;
     const int nch = (n + CH - 1) / CH;
     iptr->assign((size_t) n + 1, 0);
-    std::vector<std::vector<uint32_t>> cbuf((size_t) nch);
+    std::vector<big_vector<uint32_t>> cbuf((size_t) nch);
     parallel_chunks(nch, 1, [&](long long cb, long long ce, int) {
         for (long long c = cb; c < ce; c++)
         {
-            std::vector<uint32_t> &buf = cbuf[(size_t) c];
+            big_vector<uint32_t> &buf = cbuf[(size_t) c];
             const int i0 = (int) c * CH, i1 = std::min(n, i0 + CH);
             for (int i = i0; i < i1; i++)
             {
@@ -655,16 +655,22 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
     }
     out->st = st;
     out->lattice = lattice;
-    auto real_count = [&](int panel) {
-        int c = 0;
-        for (int q = p.pptr[panel]; q < p.pptr[panel + 1]; q++)
+    // entries of every panel before its padding (counted once, by all threads: the builders ask several times per panel)
+    std::vector<int> rcount((size_t) np, 0);
+    parallel_chunks(np, 4096, [&](long long b, long long e, int) {
+        for (long long panel = b; panel < e; panel++)
         {
-            const unsigned m = (p.pmask4[(size_t) q >> 2] >> (8 * (q & 3))) & 0xFFu;
-            if (m == 0) break;          // padding starts here: real entries always carry a row
-            c++;
+            int c = 0;
+            for (int q = p.pptr[(size_t) panel]; q < p.pptr[(size_t) panel + 1]; q++)
+            {
+                const unsigned m = (p.pmask4[(size_t) q >> 2] >> (8 * (q & 3))) & 0xFFu;
+                if (m == 0) break;          // padding starts here: real entries always carry a row
+                c++;
+            }
+            rcount[(size_t) panel] = c;
         }
-        return c;
-    };
+    });
+    auto real_count = [&](int panel) { return rcount[(size_t) panel]; };
     // Off a lattice, teams of eight are CLUSTERED: the eight panels of a team are picked for the columns they share
     // (greedy_cluster), not for being consecutive -- on a 3-D stencil in natural order eight consecutive panels are
     // a thin strip of one grid line (9.9 union entries per row on the 27-point fem3d stand-in), a cluster is a
@@ -683,7 +689,7 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
     else if (clustered)
     {
         std::vector<long long> iptr;
-        std::vector<uint32_t> ikey;
+        big_vector<uint32_t> ikey;
         // The clustering works on ranges of consecutive items: the panels are taken in the order of their MEDIAN column,
         // so that panels far apart in the row numbering that read the same B rows (the dual rows of a KKT system and the
         // primal rows of the same nodes) fall into one range; for a mesh numbered along its own lines that is the row order.
@@ -714,7 +720,7 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
             });
             std::stable_sort(pord.begin(), pord.end(), [&](int x, int y) { return med[(size_t) x] < med[(size_t) y]; });
         }
-        build_key_csr(np, [&](int i, std::vector<uint32_t> &buf) {
+        build_key_csr(np, [&](int i, big_vector<uint32_t> &buf) {
             const int q = pord[(size_t) i];
             const int e0 = p.pptr[q], e1 = e0 + real_count(q);
             for (int e = e0; e < e1; e++) buf.push_back(col_key(p.pcol[(size_t) e]));
@@ -833,14 +839,37 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
 
     // union entry lists: 4-way merge by (column key, occurrence inside the panel)
     std::vector<int> cnt((size_t) nteam, 0);
-    std::vector<std::vector<int>> ucol((size_t) nteam);
-    std::vector<std::vector<uint32_t>> umask((size_t) nteam);
-    std::vector<std::vector<int>> usrc((size_t) nteam);
+    // The unions of `upool` consecutive teams share three arrays (sized by the teams' panel entries, an upper bound on their union
+    // entries): one vector of each kind per TEAM was 1.3 M small allocations on the nlpkkt240-size matrix, whose fresh 4 KiB pages
+    // were faulted in no faster by 16 threads than by 4.
+    struct UnionPool { big_vector<int> col; big_vector<uint32_t> mask; big_vector<int> src; };
+    const int upool = (int) std::min<long long>(2048, std::max<long long>(64, nteam / (4LL * host_threads())));
+    const int npool = (nteam + upool - 1) / upool;
+    std::vector<UnionPool> pools((size_t) npool);
+    std::vector<const int *> ucol((size_t) nteam, nullptr), usrc((size_t) nteam, nullptr);      // team g: cnt[g] union entries at ucol[g], T * cnt[g] at usrc[g]
+    std::vector<const uint32_t *> umask((size_t) nteam, nullptr);
     // Nodes: the union of the panels' entry lists, equal (column, occurrence) keys merged.
     struct Node { int col; uint32_t mask; int src[TMAX]; int users; bool done; };
-    parallel_chunks(nteam, 64, [&](long long b, long long e, int) {
+    parallel_chunks(npool, 1, [&](long long pb, long long pe, int) {
         std::vector<Node> nodes;                               // (scratch of the builder thread, not of the team)
         std::vector<int> list[TMAX];                           // node ids of every wave, in column order
+        for (long long pl = pb; pl < pe; pl++)
+        {
+        const long long b = pl * upool, e = std::min<long long>(nteam, b + upool);
+        UnionPool &pool = pools[(size_t) pl];
+        {
+            size_t cap = 0;
+            for (long long g = b; g < e; g++)
+                for (int w = 0; w < T; w++)
+                {
+                    const int panel = out->tpanel[(size_t) g * T + w];
+                    if (panel >= 0) cap += (size_t) (p.pptr[panel + 1] - p.pptr[panel]);
+                }
+            pool.col.resize(cap);
+            pool.mask.resize(cap);
+            pool.src.resize(cap * (size_t) T);
+        }
+        size_t pat = 0;                                        // union entries of the pool so far
         for (long long g = b; g < e; g++)
         {
             int head[TMAX], end[TMAX], occ[TMAX];
@@ -851,16 +880,10 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
                 end[w] = panel >= 0 ? head[w] + real_count(panel) : 0;
                 occ[w] = 0;
             }
-            std::vector<int> &uc = ucol[(size_t) g];
-            std::vector<uint32_t> &um = umask[(size_t) g];
-            std::vector<int> &us = usrc[(size_t) g];       // per union entry: panel entry of wave 0..3 (or -1)
-            {
-                size_t cap = 0;
-                for (int w = 0; w < T; w++) cap += (size_t) (end[w] - head[w]);
-                uc.reserve(cap);
-                um.reserve(cap);
-                us.reserve(cap * (size_t) T);
-            }
+            int *const uc = pool.col.data() + pat;
+            uint32_t *const um = pool.mask.data() + pat;
+            int *const us = pool.src.data() + pat * (size_t) T;    // per union entry: panel entry of wave 0 .. T - 1 (or -1)
+            size_t un = 0;                                     // union entries of the team so far
             nodes.clear();
             for (int w = 0; w < T; w++) list[w].clear();
             for (;;)
@@ -915,9 +938,10 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
                 //  passes below were a fifth of the nlpkkt240-size format's build time)
                 for (size_t id = 0; id < nodes.size(); id++)
                 {
-                    uc.push_back(nodes[id].col);
-                    um.push_back(nodes[id].mask);
-                    for (int u = 0; u < T; u++) us.push_back(nodes[id].src[u]);
+                    uc[un] = nodes[id].col;
+                    um[un] = nodes[id].mask;
+                    for (int u = 0; u < T; u++) us[un * (size_t) T + (size_t) u] = nodes[id].src[u];
+                    un++;
                 }
                 left = 0;
             }
@@ -925,9 +949,10 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
                 Node &nd = nodes[(size_t) id];
                 nd.done = true;
                 left--;
-                uc.push_back(nd.col);
-                um.push_back(nd.mask);
-                for (int u = 0; u < T; u++) us.push_back(nd.src[u]);
+                uc[un] = nd.col;
+                um[un] = nd.mask;
+                for (int u = 0; u < T; u++) us[un * (size_t) T + (size_t) u] = nd.src[u];
+                un++;
             };
             while (left > 0)
             {
@@ -963,7 +988,12 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
                     for (size_t id = 0; id < nodes.size(); id++)
                         if (!nodes[id].done) { emit((int) id); break; }
             }
-            cnt[(size_t) g] = (int) uc.size();
+            cnt[(size_t) g] = (int) un;
+            ucol[(size_t) g] = uc;
+            umask[(size_t) g] = um;
+            usrc[(size_t) g] = us;
+            pat += un;
+        }
         }
     });
     clk.lap("build_teams: union lists + balanced passes");
@@ -986,14 +1016,14 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
         {
             size_t q = (size_t) out->tptr[(size_t) g];
             int last = 0;
-            for (size_t t = 0; t < ucol[(size_t) g].size(); t++, q++)
+            for (size_t t = 0; t < (size_t) cnt[(size_t) g]; t++, q++)
             {
                 out->tcol[q] = ucol[(size_t) g][t];
                 out->tmask[q] = umask[(size_t) g][t];
                 last = out->tcol[q];
             }
             int *ts = &out->tsrc[(size_t) out->tptr[(size_t) g] * T];
-            if (!usrc[(size_t) g].empty()) memcpy(ts, usrc[(size_t) g].data(), sizeof(int) * usrc[(size_t) g].size());
+            if (cnt[(size_t) g] > 0) memcpy(ts, usrc[(size_t) g], sizeof(int) * (size_t) cnt[(size_t) g] * (size_t) T);
             for (; q < (size_t) out->tptr[(size_t) g + 1]; q++)
             {
                 out->tcol[q] = last;      // padding: valid row, no reader
@@ -1015,8 +1045,8 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
             for (int w = 0; w < T; w++)
             {
                 out->tvoff[(size_t) g * T + w] = run;
-                const std::vector<int> &us = usrc[(size_t) g];
-                for (size_t t = 0; t < us.size() / (size_t) T; t++)
+                const int *us = usrc[(size_t) g];
+                for (size_t t = 0; t < (size_t) cnt[(size_t) g]; t++)
                 {
                     const int q = us[t * (size_t) T + (size_t) w];
                     if (q >= 0) out->tq[(size_t) q] = run++;
@@ -1042,9 +1072,9 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
         // served by the XCD's L2 once.  Generations = super-teams of 64 teams clustered by shared columns, again
         // greedily; the kernel deals the order to the XCDs in eight contiguous runs.
         std::vector<long long> iptr;
-        std::vector<uint32_t> ikey;
-        build_key_csr(nteam, [&](int g, std::vector<uint32_t> &buf) {
-            for (int c : ucol[(size_t) g]) buf.push_back(col_key(c));
+        big_vector<uint32_t> ikey;
+        build_key_csr(nteam, [&](int g, big_vector<uint32_t> &buf) {
+            for (int t = 0; t < cnt[(size_t) g]; t++) buf.push_back(col_key(ucol[(size_t) g][t]));
         }, &iptr, &ikey);
         std::vector<int> super_of, sslot;
         int ns = 0;
@@ -1138,12 +1168,12 @@ void build_teams(const PanelHost &p, int nrow, const int *rowptr, const int *col
     }
     if (seed != nullptr && !seeded) { seed->torder = out->torder; seed->valid = true; }
     clk.lap(seeded ? "build_teams: processing order (from the seed)" : "build_teams: processing order (super-teams)");
-    parallel_chunks(nteam, 1024, [&](long long b, long long e, int) {
-        for (long long g = b; g < e; g++)
+    parallel_chunks(npool, 1, [&](long long b, long long e, int) {
+        for (long long pl = b; pl < e; pl++)
         {
-            std::vector<int>().swap(ucol[(size_t) g]);
-            std::vector<uint32_t>().swap(umask[(size_t) g]);
-            std::vector<int>().swap(usrc[(size_t) g]);
+            big_vector<int>().swap(pools[(size_t) pl].col);
+            big_vector<uint32_t>().swap(pools[(size_t) pl].mask);
+            big_vector<int>().swap(pools[(size_t) pl].src);
         }
     });
 }
@@ -1183,12 +1213,19 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
     {
         int nr = 0, filled = 0, nparts = 0;
         int anycol = 0;                             // a column of the team (a valid row for the prologue's empty slots)
-        std::vector<int> col;                       // nr * W slot columns (TEAM2_NOCOL = empty slot)
+        size_t r0 = 0;                              // rounds of the pool in front of this team's
+        int *col = nullptr;                         // nr * W slot columns (TEAM2_NOCOL = empty slot)
         // parts of wave w in round r: ownp[(r * W + w) * CAP .. + ownc[r * W + w])  (flat: one small vector per
         // (round, wave) was 126 M heap allocations on the nlpkkt240-size matrix)
-        std::vector<Part> ownp;
-        std::vector<unsigned char> ownc;
+        Part *ownp = nullptr;
+        unsigned char *ownc = nullptr;
     };
+    // (The rounds of `rpool` consecutive teams share three arrays, like the unions of build_teams: three vectors per team were 1.3 M
+    //  allocations whose pages no number of threads faulted in faster; col / ownp / ownc of a team point into its pool.)
+    struct RoundPool { big_vector<int> col; big_vector<Part> ownp; big_vector<unsigned char> ownc; };
+    const int rpool = (int) std::min<long long>(2048, std::max<long long>(32, nteam / (4LL * host_threads())));
+    const int nrpool = (nteam + rpool - 1) / rpool;
+    std::vector<RoundPool> rpools((size_t) nrpool);
     std::vector<TeamOut> res((size_t) nteam);
     // real union entries of team g
     auto team_nodes = [&](int g, std::vector<int> &nodes) {
@@ -1226,8 +1263,9 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
     // load per round -- round 3)
     const bool swap_on = nteam <= 120000;                                   // (the balance pass costs 2 s per 100 k teams on 16 CPUs)
     struct SchedScratch { std::vector<unsigned char> rk, rr; std::vector<char> taken; };    // (one per builder thread, not one per team)
-    auto schedule_team = [&](int g, const std::vector<int> &nodes, SchedScratch &scr) {
+    auto schedule_team = [&](int g, const std::vector<int> &nodes, SchedScratch &scr, RoundPool &pool) {
         TeamOut &to = res[(size_t) g];
+        to.r0 = pool.ownc.size() / (size_t) W;
         to.anycol = nodes.empty() ? 0 : th.tcol[(size_t) nodes[0]];
         // the row ranges of every (node, wave), once: byte = first << 4 | len, up to 4 per wave (the look-ahead visits a
         // node several times before it fits)
@@ -1248,22 +1286,15 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
         std::vector<char> &taken = scr.taken;
         taken.assign(nn, 0);
         size_t head = 0, left = nn;
-        {
-            // (one allocation each instead of one per round: the allocator was what the builder threads were waiting for)
-            const size_t est = nn / (size_t) W + nn / (size_t) (4 * W) + 8;
-            to.col.reserve(est * (size_t) W);
-            to.ownp.reserve(est * (size_t) W * CAP);
-            to.ownc.reserve(est * (size_t) W);
-        }
         while (left > 0)
         {
             int cnt[W];
             for (int w = 0; w < W; w++) cnt[w] = 0;
             int nslot = 0;
-            const size_t base_col = to.col.size();
-            to.col.resize(base_col + (size_t) W, TEAM2_NOCOL);
-            to.ownp.resize(to.ownp.size() + (size_t) W * CAP);
-            to.ownc.resize(to.ownc.size() + (size_t) W, 0);
+            const size_t base_col = (to.r0 + (size_t) to.nr) * (size_t) W;
+            pool.col.resize(base_col + (size_t) W, TEAM2_NOCOL);
+            pool.ownp.resize((base_col + (size_t) W) * CAP);
+            pool.ownc.resize(base_col + (size_t) W, 0);
             while (head < nn && taken[head]) head++;
             int seen = 0;
             for (size_t t = head; t < nn && nslot < W && seen < 4 * W; t++)
@@ -1285,12 +1316,12 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
                         pt.len = (unsigned char) (b & 15);
                         pt.slot = (unsigned char) nslot;
                         pt.src = th.tsrc[(size_t) q * T + (size_t) w];
-                        to.ownp[((size_t) to.nr * W + (size_t) w) * CAP + (size_t) cnt[w]] = pt;
-                        to.ownc[(size_t) to.nr * W + (size_t) w]++;
+                        pool.ownp[(base_col + (size_t) w) * CAP + (size_t) cnt[w]] = pt;
+                        pool.ownc[base_col + (size_t) w]++;
                         cnt[w]++;
                         to.nparts++;
                     }
-                to.col[base_col + (size_t) nslot] = th.tcol[(size_t) q];
+                pool.col[base_col + (size_t) nslot] = th.tcol[(size_t) q];
                 nslot++;
                 taken[t] = 1;
                 left--;
@@ -1404,19 +1435,37 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
         }
     };
     compute_cut();
-    parallel_chunks(nteam, 32, [&](long long b, long long e, int) {
+    parallel_chunks(nrpool, 1, [&](long long pb, long long pe, int) {
         std::vector<int> nodes;
         std::vector<std::pair<int, int>> keyed;                 // (key, node): the key is looked up once per node, not per comparison
         SchedScratch scr;
-        for (long long g = b; g < e; g++)
+        for (long long pl = pb; pl < pe; pl++)
         {
-            team_nodes((int) g, nodes);
-            keyed.resize(nodes.size());
-            for (size_t i = 0; i < nodes.size(); i++) keyed[i] = {key(nodes[i]), nodes[i]};
-            std::sort(keyed.begin(), keyed.end());              // (nodes come in ascending order: ties keep it, as a stable sort by key would)
-            for (size_t i = 0; i < nodes.size(); i++) nodes[i] = keyed[i].second;
-            schedule_team((int) g, nodes, scr);
-            if (swap_on) balance_rounds(res[(size_t) g]);
+            RoundPool &pool = rpools[(size_t) pl];
+            const long long b = pl * rpool, e = std::min<long long>(nteam, b + rpool);
+            {
+                size_t est = 0;                                 // rounds: an eighth of the nodes, a quarter more for rounds left partly empty
+                for (long long g = b; g < e; g++) est += (size_t) nn[(size_t) g] / (size_t) W + (size_t) nn[(size_t) g] / (size_t) (4 * W) + 2;
+                pool.col.reserve(est * (size_t) W);
+                pool.ownp.reserve(est * (size_t) W * CAP);
+                pool.ownc.reserve(est * (size_t) W);
+            }
+            auto bind = [&](TeamOut &to) {
+                to.col = pool.col.data() + to.r0 * (size_t) W;
+                to.ownp = pool.ownp.data() + to.r0 * (size_t) W * CAP;
+                to.ownc = pool.ownc.data() + to.r0 * (size_t) W;
+            };
+            for (long long g = b; g < e; g++)
+            {
+                team_nodes((int) g, nodes);
+                keyed.resize(nodes.size());
+                for (size_t i = 0; i < nodes.size(); i++) keyed[i] = {key(nodes[i]), nodes[i]};
+                std::sort(keyed.begin(), keyed.end());          // (nodes come in ascending order: ties keep it, as a stable sort by key would)
+                for (size_t i = 0; i < nodes.size(); i++) nodes[i] = keyed[i].second;
+                schedule_team((int) g, nodes, scr, pool);
+                if (swap_on) { bind(res[(size_t) g]); balance_rounds(res[(size_t) g]); }
+            }
+            for (long long g = b; g < e; g++) bind(res[(size_t) g]);          // (the pool's arrays have stopped growing)
         }
     });
     clk.lap("build_team2: rounds (phase sort, list scheduler)");
@@ -1426,7 +1475,7 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
     {
         std::vector<const int *> cols((size_t) nteam);
         std::vector<int> nrs((size_t) nteam);
-        for (int g = 0; g < nteam; g++) { cols[(size_t) g] = res[(size_t) g].col.data(); nrs[(size_t) g] = res[(size_t) g].nr; }
+        for (int g = 0; g < nteam; g++) { cols[(size_t) g] = res[(size_t) g].col; nrs[(size_t) g] = res[(size_t) g].nr; }
         LatticeOrderInfo li;
         // an XCD's 4 MiB of L2 in row slices of the widest tile (2 KiB); a generation = the workgroups resident on an XCD
         const bool changed = lattice_block_order(nteam, th.lat_key.data(), W, WGS, 2048, TEAM2_NOCOL, cols.data(), nrs.data(), &out->torder, &li);
@@ -1585,13 +1634,12 @@ void build_team2(const PanelHost &p, int nrow, const int *rowptr, const int *col
     });
     clk.lap("build_team2: value-update map");
     // (hundreds of thousands of small vectors: released by all threads, not by the one that leaves the function)
-    parallel_chunks(nunit, 1024, [&](long long b, long long e, int) {
-        for (long long g = b; g < e; g++)
+    parallel_chunks(nrpool, 1, [&](long long b, long long e, int) {
+        for (long long pl = b; pl < e; pl++)
         {
-            TeamOut &to = ures[(size_t) g];
-            std::vector<int>().swap(to.col);
-            std::vector<Part>().swap(to.ownp);
-            std::vector<unsigned char>().swap(to.ownc);
+            big_vector<int>().swap(rpools[(size_t) pl].col);
+            big_vector<Part>().swap(rpools[(size_t) pl].ownp);
+            big_vector<unsigned char>().swap(rpools[(size_t) pl].ownc);
         }
     });
     clk.lap("build_team2: release");
@@ -1635,19 +1683,32 @@ bool build_team2r(const PanelHost &p, int nrow, const int *rowptr, const int *co
     struct TeamOutR
     {
         int nr = 0, anycol = 0;
-        std::vector<int> col;                 // nr * S (TEAM2_NOCOL = empty)
-        std::vector<int> iptr;                // (nr * W) + 1: items of (round, wave)
-        std::vector<ItemR> items;
-        std::vector<unsigned char> lp;        // nr * W: padded steps
+        size_t ocol = 0, oiptr = 0, oitem = 0, olp = 0;     // where the team's arrays start in its pool
+        long long wunits[8] = {0, 0, 0, 0, 0, 0, 0, 0}, steps = 0, filled = 0;   // 16-byte units of every wave's stream, padded steps, filled slots
+        const int *col = nullptr;             // nr * S (TEAM2_NOCOL = empty)
+        const int *iptr = nullptr;            // (nr * W) + 1: items of (round, wave)
+        const ItemR *items = nullptr;
+        const unsigned char *lp = nullptr;    // nr * W: padded steps
     };
+    // (pools of consecutive teams instead of four vectors per team: see build_team2)
+    struct RoundPoolR { big_vector<int> col, iptr; big_vector<ItemR> items; big_vector<unsigned char> lp; };
+    const int rpool = (int) std::min<long long>(2048, std::max<long long>(32, nteam / (4LL * host_threads())));
+    const int nrpool = (nteam + rpool - 1) / rpool;
+    std::vector<RoundPoolR> rpools((size_t) nrpool);
     std::vector<TeamOutR> res((size_t) nteam);
-    parallel_chunks(nteam, 32, [&](long long b, long long e, int) {
+    parallel_chunks(nrpool, 1, [&](long long pb, long long pe, int) {
         std::vector<int> nodes;
         std::vector<std::pair<long long, int>> keyed;
         std::vector<std::vector<ItemR>> wl((size_t) W);
+        struct { std::vector<int> col, iptr; std::vector<ItemR> items; std::vector<unsigned char> lp; } to_v;     // the team being built
+        for (long long pl = pb; pl < pe; pl++)
+        {
+        RoundPoolR &pool = rpools[(size_t) pl];
+        const long long b = pl * rpool, e = std::min<long long>(nteam, b + rpool);
         for (long long g = b; g < e; g++)
         {
             TeamOutR &to = res[(size_t) g];
+            to_v.col.clear(); to_v.iptr.clear(); to_v.items.clear(); to_v.lp.clear();
             nodes.clear();
             for (int q = th.tptr[(size_t) g]; q < th.tptr[(size_t) g + 1]; q++)
             {
@@ -1662,7 +1723,7 @@ bool build_team2r(const PanelHost &p, int nrow, const int *rowptr, const int *co
             // (dealing the ordered entries out to the rounds like cards, so that the waves of a round have equal steps -- mean / max
             //  0.59 -> 0.86 -- was 15 % slower: consecutive columns in a round are consecutive B rows in time for every team of the XCD)
             to.anycol = nodes.empty() ? 0 : th.tcol[(size_t) nodes[0]];
-            to.iptr.push_back(0);
+            to_v.iptr.push_back(0);
             const size_t nn = nodes.size();
             std::vector<char> taken(nn, 0);
             size_t head = 0, left = nn;
@@ -1673,8 +1734,8 @@ bool build_team2r(const PanelHost &p, int nrow, const int *rowptr, const int *co
                     for (int r = 0; r < 8; r++) cnt[w][r] = 0;
                 for (int w = 0; w < W; w++) wl[(size_t) w].clear();
                 int nslot = 0;
-                const size_t base_col = to.col.size();
-                to.col.resize(base_col + (size_t) S, TEAM2_NOCOL);
+                const size_t base_col = to_v.col.size();
+                to_v.col.resize(base_col + (size_t) S, TEAM2_NOCOL);
                 while (head < nn && taken[head]) head++;
                 int seen = 0;
                 for (size_t t = head; t < nn && nslot < S && seen < 3 * S; t++)
@@ -1703,7 +1764,7 @@ bool build_team2r(const PanelHost &p, int nrow, const int *rowptr, const int *co
                         it.src = src;
                         wl[(size_t) w].push_back(it);
                     }
-                    to.col[base_col + (size_t) nslot] = th.tcol[(size_t) q];
+                    to_v.col[base_col + (size_t) nslot] = th.tcol[(size_t) q];
                     nslot++;
                     taken[t] = 1;
                     left--;
@@ -1713,22 +1774,40 @@ bool build_team2r(const PanelHost &p, int nrow, const int *rowptr, const int *co
                 {
                     int mx = 0;
                     for (int r = 0; r < 8; r++) mx = std::max(mx, cnt[w][r]);
-                    to.lp.push_back((unsigned char) ((mx + 1) / 2 * 2));           // steps come in pairs (the kernel's half chunk)
-                    to.items.insert(to.items.end(), wl[(size_t) w].begin(), wl[(size_t) w].end());
-                    to.iptr.push_back((int) to.items.size());
+                    to_v.lp.push_back((unsigned char) ((mx + 1) / 2 * 2));           // steps come in pairs (the kernel's half chunk)
+                    to_v.items.insert(to_v.items.end(), wl[(size_t) w].begin(), wl[(size_t) w].end());
+                    to_v.iptr.push_back((int) to_v.items.size());
                 }
                 to.nr++;
             }
             if (to.nr == 0)                                                   // no nonzero in 64 rows: one empty round (the kernel's pipeline wants one)
             {
-                to.col.assign((size_t) S, TEAM2_NOCOL);
+                to_v.col.assign((size_t) S, TEAM2_NOCOL);
                 for (int w = 0; w < W; w++)
                 {
-                    to.lp.push_back(0);
-                    to.iptr.push_back(0);
+                    to_v.lp.push_back(0);
+                    to_v.iptr.push_back(0);
                 }
                 to.nr = 1;
             }
+            to.ocol = pool.col.size(); to.oiptr = pool.iptr.size(); to.oitem = pool.items.size(); to.olp = pool.lp.size();
+            pool.col.insert(pool.col.end(), to_v.col.begin(), to_v.col.end());
+            pool.iptr.insert(pool.iptr.end(), to_v.iptr.begin(), to_v.iptr.end());
+            pool.items.insert(pool.items.end(), to_v.items.begin(), to_v.items.end());
+            pool.lp.insert(pool.lp.end(), to_v.lp.begin(), to_v.lp.end());
+        }
+        for (long long g = b; g < e; g++)                                     // (the pool's arrays have stopped growing)
+        {
+            TeamOutR &to = res[(size_t) g];
+            to.col = pool.col.data() + to.ocol; to.iptr = pool.iptr.data() + to.oiptr; to.items = pool.items.data() + to.oitem; to.lp = pool.lp.data() + to.olp;
+            for (int w = 0; w < W; w++)
+                for (int r = 0; r < to.nr; r++)
+                {
+                    to.wunits[w] += 5LL * to.lp[(size_t) r * W + (size_t) w] + 4;   // 80 Lp bytes of values and offsets + the 64-byte header
+                    to.steps += to.lp[(size_t) r * W + (size_t) w];
+                }
+            for (size_t i = 0; i < (size_t) to.nr * (size_t) S; i++) to.filled += to.col[i] != TEAM2_NOCOL;
+        }
         }
     });
     clk.lap("build_team2r: rounds");
@@ -1746,15 +1825,10 @@ bool build_team2r(const PanelHost &p, int nrow, const int *rowptr, const int *co
         for (int w = 0; w < W; w++)
         {
             out->tvoff[(size_t) g * W + (size_t) w] = run;
-            long long u = 0;
-            for (int r = 0; r < to.nr; r++)
-            {
-                u += 5LL * to.lp[(size_t) r * W + (size_t) w] + 4;           // 80 Lp bytes of values and offsets + the 64-byte header
-                out->steps += to.lp[(size_t) r * W + (size_t) w];
-            }
-            run += u;
+            run += to.wunits[w];
         }
-        for (int c : to.col) out->slots_filled += c != TEAM2_NOCOL;
+        out->steps += to.steps;
+        out->slots_filled += to.filled;
     }
     out->tvoff[(size_t) nteam * W] = run;
     out->nwords = run * 2;
@@ -1862,14 +1936,13 @@ bool build_team2r(const PanelHost &p, int nrow, const int *rowptr, const int *co
     });
     clk.lap("build_team2r: value-update map");
     // (hundreds of thousands of small vectors: released by all threads, not by the one that leaves the function)
-    parallel_chunks(nteam, 1024, [&](long long b, long long e, int) {
-        for (long long g = b; g < e; g++)
+    parallel_chunks(nrpool, 1, [&](long long b, long long e, int) {
+        for (long long pl = b; pl < e; pl++)
         {
-            TeamOutR &to = res[(size_t) g];
-            std::vector<int>().swap(to.col);
-            std::vector<int>().swap(to.iptr);
-            std::vector<ItemR>().swap(to.items);
-            std::vector<unsigned char>().swap(to.lp);
+            big_vector<int>().swap(rpools[(size_t) pl].col);
+            big_vector<int>().swap(rpools[(size_t) pl].iptr);
+            big_vector<ItemR>().swap(rpools[(size_t) pl].items);
+            big_vector<unsigned char>().swap(rpools[(size_t) pl].lp);
         }
     });
     clk.lap("build_team2r: release");

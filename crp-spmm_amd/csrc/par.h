@@ -9,7 +9,9 @@
 #include "knobs.h"
 #ifdef __linux__
 #include <sched.h>
+#include <sys/mman.h>
 #endif
+#include <new>
 #include <memory>
 #include <thread>
 #include <utility>
@@ -91,12 +93,37 @@ void parallel_chunks(long long n, long long chunk, F fn)
 
 // std::vector whose resize() leaves new elements uninitialised (for arrays of hundreds of MB that are filled by
 // parallel_fill / by all threads afterwards: a value-initialising resize touches every page from ONE thread first)
+// Blocks of 4 MiB and more are aligned to 2 MiB and advised MADV_HUGEPAGE: first-touch page faults take a process-wide lock, and
+// with 4 KiB pages the builders' tens of gigabytes of fresh memory were faulted in at about the same speed by 4 threads and by 16
+// (profiles/r04_build_time.txt).
 template <typename T>
 struct default_init_allocator : std::allocator<T>
 {
     template <typename U> struct rebind { typedef default_init_allocator<U> other; };
     default_init_allocator() = default;
     template <typename U> default_init_allocator(const default_init_allocator<U> &) {}
+    static constexpr size_t HUGE_MIN = (size_t) 4 << 20, HUGE_ALIGN = (size_t) 2 << 20;
+    T *allocate(size_t n)
+    {
+        const size_t bytes = n * sizeof(T);
+#ifdef __linux__
+        if (bytes >= HUGE_MIN)
+        {
+            void *p = nullptr;
+            if (posix_memalign(&p, HUGE_ALIGN, (bytes + HUGE_ALIGN - 1) / HUGE_ALIGN * HUGE_ALIGN) != 0 || p == nullptr) throw std::bad_alloc();
+            (void) madvise(p, (bytes + HUGE_ALIGN - 1) / HUGE_ALIGN * HUGE_ALIGN, MADV_HUGEPAGE);
+            return static_cast<T *>(p);
+        }
+#endif
+        return static_cast<T *>(::operator new(bytes));
+    }
+    void deallocate(T *p, size_t n)
+    {
+#ifdef __linux__
+        if (n * sizeof(T) >= HUGE_MIN) { free(p); return; }
+#endif
+        ::operator delete(p);
+    }
     template <typename U> void construct(U *p) { ::new (static_cast<void *>(p)) U; }
     template <typename U, typename... A> void construct(U *p, A &&...a) { ::new (static_cast<void *>(p)) U(std::forward<A>(a)...); }
 };
