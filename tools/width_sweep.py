@@ -8,7 +8,7 @@ is built once, the device matrix is created once (formats are built by the first
 times are printed with CRPSPMM_TIMING=1), then every width is timed with HIP events through the device-level C ABI
 (crp_spmm_csr_f64: the call rp_spmm_exec makes for device operands).
 
-usage: width_sweep.py [--matrix kkt240] [--widths 256 128 64 32] [--steps 20] [--out FILE.jsonl]
+usage: width_sweep.py [--matrix kkt240] [--widths 256 128 64 32] [--steps 20] [--variant 0] [--out FILE.jsonl]
 """
 import argparse
 import ctypes as C
@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--widths", type=int, nargs="+", default=[256, 128, 64, 32])
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--variant", type=int, default=0, help="kernel variant (0 = what the library picks)")
     a = ap.parse_args()
     import torch
     import crp_spmm_amd
@@ -57,7 +58,7 @@ def main():
         del ii, jj
         Cm = torch.empty((m, n), dtype=torch.float64, device=dev)
         tf = time.perf_counter()
-        hip.spmm_csr(A, B, Cm, n=n, variant=0, stream=stream)
+        hip.spmm_csr(A, B, Cm, n=n, variant=a.variant, stream=stream)
         torch.cuda.synchronize()
         first = time.perf_counter() - tf
         got = Cm[torch.from_numpy(sel).to(dev)].cpu().numpy()
@@ -65,7 +66,7 @@ def main():
         err = float(np.linalg.norm(got - expect) / max(np.linalg.norm(expect), 1e-300))
         assert err <= 1e-12, (n, err)
         for _ in range(3):
-            hip.spmm_csr(A, B, Cm, n=n, variant=0, stream=stream)
+            hip.spmm_csr(A, B, Cm, n=n, variant=a.variant, stream=stream)
         torch.cuda.synchronize()
         ev = [(C.c_void_p(), C.c_void_p()) for _ in range(a.steps)]
         for x, y in ev:
@@ -73,7 +74,7 @@ def main():
             lib.crp_event_create(C.byref(y))
         for x, y in ev:
             lib.crp_event_record(x, stream)
-            hip.spmm_csr(A, B, Cm, n=n, variant=0, stream=stream)
+            hip.spmm_csr(A, B, Cm, n=n, variant=a.variant, stream=stream)
             lib.crp_event_record(y, stream)
         torch.cuda.synchronize()
         ms = C.c_float()
