@@ -28,7 +28,7 @@ typedef unsigned v4u __attribute__((ext_vector_type(4)));
 // inline ds_read (a read the compiler sees would get a vmcnt(0) in front: it may alias the DMAs in flight), the barrier is the bare
 // instruction, the waits are written by hand, and the unit's row numbers are copied to LDS before its pipeline starts (a vector load of
 // them inside the loop would wait for every DMA issued before it: vmcnt counts in order).
-constexpr int VBLK = 64;                            // bytes of LDS behind one value DMA (at most 4 lanes of 16 bytes)
+constexpr int VBLK = 128;                           // bytes of LDS behind one value DMA (at most 8 lanes of 16 bytes)
 template <int S>
 __global__ __launch_bounds__(512) void replay_kernel(Plan p, const char *__restrict__ B, char *__restrict__ C, const char *__restrict__ avals, int *ctr, unsigned *sink)
 {

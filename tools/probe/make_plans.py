@@ -51,13 +51,20 @@ def main():
     ap.add_argument("--L", type=int, default=400)
     ap.add_argument("--wgs", type=int, default=3, help="workgroups per CU of the strip plan")
     ap.add_argument("--orders", action="store_true", help="also teams_orders.bin: the teams under alternative processing orders")
+    ap.add_argument("--matrix", default="pwtk", help="pwtk | shell | fem3d | kkt (bench.py's stand-ins; anything but pwtk: the teams plan only)")
     a = ap.parse_args()
     os.makedirs(a.outdir, exist_ok=True)
     import l2sim
     import sliding_window_model as sw
     from crp_spmm_amd import gen, hip
-    m = 217918
-    rp, ci, va = gen.banded_fem(m)
+    import bench
+    name = {"pwtk": "pwtk", "shell": "pwtk_shell"}.get(a.matrix, a.matrix)
+    _, _, m, k, rp, ci, va = bench.build_matrix(name, None)
+    perm, info = hip.locality_order_host(rp, ci, k) if a.matrix == "shell" else (None, None)       # (the stand-in the library re-orders)
+    if perm is not None and info is not None:
+        import scipy.sparse as sp                  # (the library builds its formats on the re-ordered rows)
+        Ap = sp.csr_matrix((va, ci, rp), shape=(m, k))[perm]
+        rp, ci, va = Ap.indptr.astype(np.int32), Ap.indices.astype(np.int32), Ap.data
     t = hip.team2_format_host(rp, ci, va)
     rounds = l2sim.team_rounds(t)
     units = []
@@ -76,7 +83,8 @@ def main():
     reads = int(round(parts / (sum(len(u) for u in units) * 8.0)))
     # value bytes per wave and round: 12 bytes per nonzero (value + its share of the records)
     ab = 12.0 * len(ci) / (sum(len(u) for u in units) * 8)
-    write_plan(os.path.join(a.outdir, "teams.bin"), 8, m, len(units) * 64, 2, 1, max(1, min(4, int(round(ab / 16)))), max(1, reads), units, queues, cbase, cn)
+    tag = "" if a.matrix == "pwtk" else "_" + a.matrix
+    write_plan(os.path.join(a.outdir, "teams%s.bin" % tag), 8, k, len(units) * 64, 2, 1, max(1, min(8, int(round(ab / 16)))), max(1, reads), units, queues, cbase, cn)
     if a.orders:
         # alternative processing orders of the same teams, the family csrc/team_order.cpp searches with its L2 model: XCD boxes of team
         # columns (pa x pb), blocks of bt positions x ba x bb columns, blocks and teams in either nesting; every order is cut into eight
@@ -101,12 +109,14 @@ def main():
                         seen.add(key)
                         cands.append(l2sim.xcd_queues(rounds, [int(g) for g in order]))
                         names.append("boxes %dx%d blocks %dx%dx%d flags %d" % (pa, pb, bt, ba, bb, flags))
-        write_plan(os.path.join(a.outdir, "teams_orders.bin"), 8, m, len(units) * 64, 2, 1, max(1, min(4, int(round(ab / 16)))), max(1, reads), units, cands, cbase, cn)
+        write_plan(os.path.join(a.outdir, "teams_orders.bin"), 8, m, len(units) * 64, 2, 1, max(1, min(8, int(round(ab / 16)))), max(1, reads), units, cands, cbase, cn)
         with open(os.path.join(a.outdir, "teams_orders.txt"), "w") as f:
             for k, nm in enumerate(names):
                 f.write("%d %s\n" % (k, nm))
         print("  %d candidate orders" % len(cands))
     print("  parts per wave and round %.2f -> %d ring reads; value bytes per wave and round %.0f" % (parts / (sum(len(u) for u in units) * 8.0), max(1, reads), ab))
+    if a.matrix != "pwtk":
+        return
 
     # strips
     sw.BY_OFFSET = True
@@ -141,7 +151,7 @@ def main():
         queues[min(7, int(s * per_seg + i * per_seg / NI))].append(k)
     print("strips per XCD:", [len(q) for q in queues])
     ab = 12.0 * len(ci) / (sum(len(u) for u in sunits) * 8)
-    write_plan(os.path.join(a.outdir, "strips_L%d.bin" % a.L), 5, m, m, a.wgs, 0, max(1, min(4, int(round(ab / 16)))), max(1, reads), sunits, queues, scb, scn)
+    write_plan(os.path.join(a.outdir, "strips_L%d.bin" % a.L), 5, m, m, a.wgs, 0, max(1, min(8, int(round(ab / 16)))), max(1, reads), sunits, queues, scb, scn)
     print("  value bytes per wave and round %.0f" % ab)
 
 
