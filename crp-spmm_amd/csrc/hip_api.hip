@@ -254,7 +254,7 @@ static int ensure_panel(crp_csr_dev *A, int idx, hipStream_t stream)
 }
 
 // Build (once) and upload the team2 streams on top of the R = 8 panels (column-ordered entries). Blocking.
-static int ensure_team2(crp_csr_dev *A, hipStream_t stream)
+static int ensure_team2(crp_csr_dev *A, hipStream_t stream, bool for_f32 = false)
 {
     Team2Dev &t = A->team2;
     if (t.built) return 0;
@@ -263,11 +263,16 @@ static int ensure_team2(crp_csr_dev *A, hipStream_t stream)
     clk.lap("ensure_team2: build_panels (R = 8, structure only)");
     crp::released_async<crp::Team2Host> th_owner;
     crp::Team2Host &th = *th_owner;
-    // Value blocks: compact (only the values that exist) when under 40 % of the (row, entry) pairs of the panels exist, 8 per
-    // part otherwise -- the kernel instance for full groups decodes no value position (two instructions per part and three
-    // per round fewer).  Same box, compact against full groups: shell stand-in 0.2686 / 0.2649 ms, Queen stand-in 0.8597 / 0.854,
-    // nlpkkt stand-in (fill 0.23) 1.91 / 2.05 and 13 GB smaller at nlpkkt240 size.  CRPSPMM_TEAM2_COMPACT=0|1 forces.
-    th.compact = crp::knobs().team2_compact >= 0 ? crp::knobs().team2_compact != 0 : h.fill() < 0.4;
+    // Value blocks: compact (only the values that exist), or 8 per part -- the kernel instance for full groups decodes no value position
+    // (two instructions per part and three per round fewer) and streams up to 64 % more value bytes.  Mostly-hole panels (under 40 % of the
+    // (row, entry) pairs exist: KKT systems) are always compact: nlpkkt stand-in 1.91 against 2.05 ms, 13 GB smaller at nlpkkt240 size.  On
+    // filled panels it used to be a wash that full groups won by 1 %; since the round-4 loop (fewer scalar instructions per round) the
+    // kernels run at the speed of their memory schedule and the bytes decide -- fp64, compact against full, same box
+    // (profiles/r04_compact_ab.txt): pwtk stand-in n = 256 0.2724 / 0.2776 ms, n = 1024 1.077 / 1.104, n = 128 0.1687 / 0.1697, shell n = 128
+    // 0.1432 / 0.1481, n = 64 0.0986 / 0.1024, Queen stand-in n = 256 0.7917 / 0.8066, n = 64 0.3472 / 0.3581, n = 1024 3.170 / 3.161.  In
+    // fp32 a value is 4 bytes and the decoding costs the same: full groups stay 0.3 - 0.8 % ahead (Queen stand-in n = 128 / 256 / 1024), so a
+    // format that is first built for the fp32 path keeps them.  CRPSPMM_TEAM2_COMPACT=0|1 forces.
+    th.compact = crp::knobs().team2_compact >= 0 ? crp::knobs().team2_compact != 0 : (h.fill() < 0.4 || !for_f32);
     std::vector<int> colpos;                    // position of every row in the processing order (square, re-ordered matrices)
     if (!A->perm.empty())
     {
@@ -1013,7 +1018,7 @@ int crp_spmm_csr_f32(crp_csr_dev_p A, int n, const float *B0, long long ldB0, co
                       crp::spmm_team2_applicable_f32(a);
     A->last_variant = team ? 5 : 1;
     if (!team) return (int) crp::spmm_rm_f32_rowgroup(a, (hipStream_t) stream);
-    const int rc = ensure_team2(A, (hipStream_t) stream);
+    const int rc = ensure_team2(A, (hipStream_t) stream, true);
     if (rc != 0) return rc;
     Team2Dev &d = A->team2;
     if (d.tval32 == nullptr)

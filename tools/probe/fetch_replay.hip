@@ -19,7 +19,7 @@ struct Plan
     const int *nr; const long long *off; const int *rows; const int *queue; const int *cbase; const int *cn;
 };
 
-constexpr int ROWB = 2048, RINGR = 4, D = 3;
+constexpr int RINGR = 4, D = 3;
 typedef __attribute__((address_space(3))) void *lds_ptr;
 typedef const __attribute__((address_space(1))) void *glb_ptr;
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
@@ -29,7 +29,7 @@ typedef unsigned v4u __attribute__((ext_vector_type(4)));
 // instruction, the waits are written by hand, and the unit's row numbers are copied to LDS before its pipeline starts (a vector load of
 // them inside the loop would wait for every DMA issued before it: vmcnt counts in order).
 constexpr int VBLK = 128;                           // bytes of LDS behind one value DMA (at most 8 lanes of 16 bytes)
-template <int S>
+template <int S, int ROWB>                          // slots of a round; bytes of a row slice: 2048 (n = 256 fp64) or 1024 (n = 128)
 __global__ __launch_bounds__(512) void replay_kernel(Plan p, const char *__restrict__ B, char *__restrict__ C, const char *__restrict__ avals, int *ctr, unsigned *sink)
 {
     extern __shared__ __attribute__((aligned(16))) char ring[];             // RINGR * S slots of 2 KiB, 8 x 256 bytes for the value blocks, the unit's rows
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(512) void replay_kernel(Plan p, const char *__restr
                 const char *src = B + (long long) row * ROWB + lane * 16;
                 char *dst = ring + ((r & (RINGR - 1)) * S + wave) * ROWB;
                 __builtin_amdgcn_global_load_lds((glb_ptr) src, (lds_ptr) dst, 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((glb_ptr) (src + 1024), (lds_ptr) (dst + 1024), 16, 0, 0);
+                if (ROWB == 2048) __builtin_amdgcn_global_load_lds((glb_ptr) (src + 1024), (lds_ptr) (dst + 1024), 16, 0, 0);
             }
             // the wave's value block of the round (streamed once); waves without a slot fetch three times as much of it, so that every
             // wave counts three DMAs per round.  Every DMA has its own place in LDS (the compiler orders DMAs to one address itself).
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(512) void replay_kernel(Plan p, const char *__restr
                 if (wave >= S)
                 {
                     __builtin_amdgcn_global_load_lds((glb_ptr) vsrc, (lds_ptr) (vdst + VBLK), 16, 0, 0);
-                    __builtin_amdgcn_global_load_lds((glb_ptr) vsrc, (lds_ptr) (vdst + 2 * VBLK), 16, 0, 0);
+                    if (ROWB == 2048) __builtin_amdgcn_global_load_lds((glb_ptr) vsrc, (lds_ptr) (vdst + 2 * VBLK), 16, 0, 0);
                 }
             }
         };
@@ -89,9 +89,18 @@ __global__ __launch_bounds__(512) void replay_kernel(Plan p, const char *__restr
             {
                 // my fetches of round r have landed when at most those of the younger rounds in flight are outstanding (3 per round)
                 const int younger = min(D - 1, nr - 1 - r);
-                if (younger >= 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-                else if (younger == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (ROWB == 2048)
+                {
+                    if (younger >= 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                    else if (younger == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                else                                                        // two DMAs per round: the row slice and the value block
+                {
+                    if (younger >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    else if (younger == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
                 asm volatile("s_barrier" ::: "memory");
             }
             if (r + D < nr) issue(r + D);
@@ -99,27 +108,30 @@ __global__ __launch_bounds__(512) void replay_kernel(Plan p, const char *__restr
             for (int k = 0; k < p.reads; k++)
             {
                 const int slot = (wave + k) % S;
-                v4u a, b;
-                asm volatile("ds_read_b128 %0, %2\n ds_read_b128 %1, %2 offset:16\n s_waitcnt lgkmcnt(0)"
-                             : "=&v"(a), "=&v"(b) : "v"(ring_lds + (unsigned) (((r & (RINGR - 1)) * S + slot) * ROWB + lane * 32)));
+                v4u a, b = {0u, 0u, 0u, 0u};
+                if (ROWB == 2048)
+                    asm volatile("ds_read_b128 %0, %2\n ds_read_b128 %1, %2 offset:16\n s_waitcnt lgkmcnt(0)"
+                                 : "=&v"(a), "=&v"(b) : "v"(ring_lds + (unsigned) (((r & (RINGR - 1)) * S + slot) * ROWB + lane * 32)));
+                else
+                    asm volatile("ds_read_b128 %0, %1\n s_waitcnt lgkmcnt(0)" : "=&v"(a) : "v"(ring_lds + (unsigned) (((r & (RINGR - 1)) * S + slot) * ROWB + lane * 16)));
                 acc ^= a.x ^ a.w ^ b.y ^ b.z;
             }
             // strips: one finished row of C per round, written by a wave that fetches no B row (its vmcnt is nobody's business)
             if (!p.write_at_end && r < cn && wave == (S < 8 ? S + (r % (8 - S > 0 ? 8 - S : 1)) : (r & 7)))
             {
                 v4u v = {acc, 0u, 0u, 0u};
-                v4u *c = (v4u *) (C + (long long) (cbase + r) * ROWB) + lane * 2;
+                v4u *c = (v4u *) (C + (long long) (cbase + r) * ROWB) + lane * (ROWB / 1024);
                 __builtin_nontemporal_store(v, c);
-                __builtin_nontemporal_store(v, c + 1);
+                if (ROWB == 2048) __builtin_nontemporal_store(v, c + 1);
             }
         }
         if (p.write_at_end)
             for (int i = wave; i < cn; i += 8)
             {
                 v4u v = {acc, 0u, 0u, 0u};
-                v4u *c = (v4u *) (C + (long long) (cbase + i) * ROWB) + lane * 2;
+                v4u *c = (v4u *) (C + (long long) (cbase + i) * ROWB) + lane * (ROWB / 1024);
                 __builtin_nontemporal_store(v, c);
-                __builtin_nontemporal_store(v, c + 1);
+                if (ROWB == 2048) __builtin_nontemporal_store(v, c + 1);
             }
     }
     if (acc == 0x12345u) sink[0] = acc;
@@ -129,7 +141,7 @@ __global__ __launch_bounds__(512) void replay_kernel(Plan p, const char *__restr
 // when they have landed -- the path the team kernel left for LDS-DMA.  Teams only (S = 8); the waits are the compiler's.
 __global__ __launch_bounds__(512) void replay_vgpr_kernel(Plan p, const char *__restrict__ B, char *__restrict__ C, const char *__restrict__ avals, int *ctr, unsigned *sink)
 {
-    constexpr int S = 8;
+    constexpr int S = 8, ROWB = 2048;
     extern __shared__ __attribute__((aligned(16))) char ring[];             // 2 rounds x 8 slots of 2 KiB, the unit's rows
     __shared__ int s_unit;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
@@ -208,6 +220,7 @@ int main(int argc, char **argv)
     if (argc < 2) { fprintf(stderr, "usage: fetch_replay PLAN.bin [launches]\n"); return 2; }
     const int launches = argc > 2 ? atoi(argv[2]) : 50;
     const bool vgpr = argc > 3 && !strcmp(argv[3], "vgpr");
+    const int ROWB = argc > 3 && !strcmp(argv[3], "n128") ? 1024 : 2048;      // "n128": row slices of 1 KiB (S = 8 plans)
     FILE *f = fopen(argv[1], "rb");
     if (!f) { perror(argv[1]); return 1; }
     int hdr[13];
@@ -225,7 +238,7 @@ int main(int argc, char **argv)
     if (!ok) { fprintf(stderr, "short plan file\n"); return 1; }
     // everything the kernel indexes by, checked here: it has no bounds tests of its own
     if (p.S != 5 && p.S != 8) { fprintf(stderr, "S must be 5 or 8\n"); return 1; }
-    if (p.alanes < 1 || p.alanes > VBLK / 16 || p.reads < 0 || p.reads > 8 || p.wgs_per_cu < 1 || p.wgs_per_cu > 3) { fprintf(stderr, "bad parameters\n"); return 1; }
+    if (p.alanes < 1 || p.alanes > VBLK / 16 || p.reads < 0 || p.reads > 8 || p.wgs_per_cu < 1 || p.wgs_per_cu > 4) { fprintf(stderr, "bad parameters\n"); return 1; }
     for (int u = 0; u < p.nunit; u++)
         if (nr[u] < 1 || nr[u] > 4096 || off[u] < 0 || off[u] + nr[u] > nrounds || cbase[u] < 0 || cn[u] < 0 || (long long) cbase[u] + cn[u] > p.nrowC || (!p.write_at_end && cn[u] > nr[u])) { fprintf(stderr, "bad unit %d\n", u); return 1; }
     p.maxnr = *std::max_element(nr.begin(), nr.end());
@@ -233,16 +246,17 @@ int main(int argc, char **argv)
     for (int q : queue) if (q < -1 || q >= p.nunit) { fprintf(stderr, "bad queue entry\n"); return 1; }
     hipDeviceProp_t prop;
     CHECK(hipGetDeviceProperties(&prop, 0));
+    if (const char *e = getenv("FETCH_REPLAY_WGS")) p.wgs_per_cu = std::max(1, std::min(4, atoi(e)));       // workgroups per CU, over the plan's
     p.wgs = prop.multiProcessorCount * p.wgs_per_cu;
     p.wgs -= p.wgs % 8;
     char *B, *C, *av;
     int *d_nr, *d_rows, *d_queue, *d_cbase, *d_cn, *ctr;
     long long *d_off;
     unsigned *sink;
-    CHECK(hipMalloc(&B, (size_t) p.nrowB * ROWB));
-    CHECK(hipMalloc(&C, (size_t) std::max(p.nrowC, 1) * ROWB));
+    CHECK(hipMalloc(&B, (size_t) p.nrowB * 2048));
+    CHECK(hipMalloc(&C, (size_t) std::max(p.nrowC, 1) * 2048));
     CHECK(hipMalloc(&av, (size_t) nrounds * 8 * 256 + 4096));
-    CHECK(hipMemset(B, 1, (size_t) p.nrowB * ROWB));
+    CHECK(hipMemset(B, 1, (size_t) p.nrowB * 2048));
     CHECK(hipMemset(av, 1, (size_t) nrounds * 8 * 256 + 4096));
     CHECK(hipMalloc(&d_nr, 4 * nr.size())); CHECK(hipMemcpy(d_nr, nr.data(), 4 * nr.size(), hipMemcpyHostToDevice));
     CHECK(hipMalloc(&d_off, 8 * off.size())); CHECK(hipMemcpy(d_off, off.data(), 8 * off.size(), hipMemcpyHostToDevice));
@@ -252,11 +266,13 @@ int main(int argc, char **argv)
     CHECK(hipMalloc(&d_rows, 4 * rows.size())); CHECK(hipMemcpy(d_rows, rows.data(), 4 * rows.size(), hipMemcpyHostToDevice));
     CHECK(hipMalloc(&ctr, 64)); CHECK(hipMalloc(&sink, 64));
     p.nr = d_nr; p.off = d_off; p.rows = d_rows; p.queue = d_queue; p.cbase = d_cbase; p.cn = d_cn;
+    if (ROWB == 1024 && p.S != 8) { fprintf(stderr, "n128 replays teams (S = 8)\n"); return 1; }
     if (vgpr && p.S != 8) { fprintf(stderr, "the register variant replays teams (S = 8)\n"); return 1; }
-    const size_t lds = vgpr ? (size_t) 2 * 8 * ROWB + (size_t) p.maxnr * 8 * 4 : (size_t) RINGR * p.S * ROWB + RINGR * 8 * 3 * VBLK + (size_t) p.maxnr * p.S * 4;
+    const size_t lds = vgpr ? (size_t) 2 * 8 * 2048 + (size_t) p.maxnr * 8 * 4 : (size_t) RINGR * p.S * ROWB + RINGR * 8 * 3 * VBLK + (size_t) p.maxnr * p.S * 4;
     if (vgpr) CHECK(hipFuncSetAttribute((const void *) replay_vgpr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-    if (p.S == 5) CHECK(hipFuncSetAttribute((const void *) replay_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-    else CHECK(hipFuncSetAttribute((const void *) replay_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+    if (p.S == 5) CHECK(hipFuncSetAttribute((const void *) replay_kernel<5, 2048>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+    else if (ROWB == 1024) CHECK(hipFuncSetAttribute((const void *) replay_kernel<8, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+    else CHECK(hipFuncSetAttribute((const void *) replay_kernel<8, 2048>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     for (int q = 0; q < nq; q++)
@@ -268,8 +284,9 @@ int main(int argc, char **argv)
             CHECK(hipMemsetAsync(ctr, 0, 64, 0));
             CHECK(hipEventRecord(e0, 0));
             if (vgpr) hipLaunchKernelGGL(replay_vgpr_kernel, dim3(p.wgs), dim3(512), lds, 0, p, B, C, av, ctr, sink);
-            else if (p.S == 5) hipLaunchKernelGGL(replay_kernel<5>, dim3(p.wgs), dim3(512), lds, 0, p, B, C, av, ctr, sink);
-            else hipLaunchKernelGGL(replay_kernel<8>, dim3(p.wgs), dim3(512), lds, 0, p, B, C, av, ctr, sink);
+            else if (p.S == 5) hipLaunchKernelGGL((replay_kernel<5, 2048>), dim3(p.wgs), dim3(512), lds, 0, p, B, C, av, ctr, sink);
+            else if (ROWB == 1024) hipLaunchKernelGGL((replay_kernel<8, 1024>), dim3(p.wgs), dim3(512), lds, 0, p, B, C, av, ctr, sink);
+            else hipLaunchKernelGGL((replay_kernel<8, 2048>), dim3(p.wgs), dim3(512), lds, 0, p, B, C, av, ctr, sink);
             CHECK(hipGetLastError());
             CHECK(hipEventRecord(e1, 0));
             CHECK(hipEventSynchronize(e1));
@@ -280,7 +297,7 @@ int main(int argc, char **argv)
         std::sort(ms.begin(), ms.end());
         double tot = 0;
         for (float t : ms) tot += t;
-        printf("%s%s [queue %d]: %d units, %lld rounds of %d slots, %d workgroups (%d per CU), LDS %zu B: mean %.4f ms, median %.4f, min %.4f\n", argv[1], vgpr ? " (register fetch)" : "", q, p.nunit, nrounds, p.S, p.wgs,
+        printf("%s%s%s [queue %d]: %d units, %lld rounds of %d slots, %d workgroups (%d per CU), LDS %zu B: mean %.4f ms, median %.4f, min %.4f\n", argv[1], vgpr ? " (register fetch)" : "", ROWB == 1024 ? " (1 KiB row slices)" : "", q, p.nunit, nrounds, p.S, p.wgs,
                p.wgs_per_cu, lds, tot / ms.size(), ms[ms.size() / 2], ms[0]);
     }
     return 0;
