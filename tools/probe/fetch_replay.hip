@@ -15,7 +15,7 @@
 
 struct Plan
 {
-    int nunit, qlen, S, nrowB, nrowC, wgs, wgs_per_cu, write_at_end, alanes, reads, maxnr;
+    int nunit, qlen, S, nrowB, nrowC, wgs, wgs_per_cu, write_at_end, alanes, reads, maxnr, store_policy;
     const int *nr; const long long *off; const int *rows; const int *queue; const int *cbase; const int *cn;
 };
 
@@ -130,8 +130,18 @@ __global__ __launch_bounds__(512) void replay_kernel(Plan p, const char *__restr
             {
                 v4u v = {acc, 0u, 0u, 0u};
                 v4u *c = (v4u *) (C + (long long) (cbase + i) * ROWB) + lane * (ROWB / 1024);
-                __builtin_nontemporal_store(v, c);
-                if (ROWB == 2048) __builtin_nontemporal_store(v, c + 1);
+                // cache policy of the C stores (FETCH_REPLAY_STORE): 0 nt (what the kernels use), 1 plain, 2 sc0 sc1, 3 sc0 sc1 nt, 4 sc1, 5 sc1 nt
+                switch (p.store_policy)
+                {
+                case 1: asm volatile("global_store_dwordx4 %0, %1, off\n global_store_dwordx4 %0, %1, off offset:16" :: "v"(c), "v"(v) : "memory"); break;
+                case 2: asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n global_store_dwordx4 %0, %1, off offset:16 sc0 sc1" :: "v"(c), "v"(v) : "memory"); break;
+                case 3: asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt\n global_store_dwordx4 %0, %1, off offset:16 sc0 sc1 nt" :: "v"(c), "v"(v) : "memory"); break;
+                case 4: asm volatile("global_store_dwordx4 %0, %1, off sc1\n global_store_dwordx4 %0, %1, off offset:16 sc1" :: "v"(c), "v"(v) : "memory"); break;
+                case 5: asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n global_store_dwordx4 %0, %1, off offset:16 sc1 nt" :: "v"(c), "v"(v) : "memory"); break;
+                default:
+                    __builtin_nontemporal_store(v, c);
+                    if (ROWB == 2048) __builtin_nontemporal_store(v, c + 1);
+                }
             }
     }
     if (acc == 0x12345u) sink[0] = acc;
@@ -246,6 +256,8 @@ int main(int argc, char **argv)
     for (int q : queue) if (q < -1 || q >= p.nunit) { fprintf(stderr, "bad queue entry\n"); return 1; }
     hipDeviceProp_t prop;
     CHECK(hipGetDeviceProperties(&prop, 0));
+    p.store_policy = getenv("FETCH_REPLAY_STORE") ? atoi(getenv("FETCH_REPLAY_STORE")) : 0;       // (2 KiB row slices, teams only)
+    if (getenv("FETCH_REPLAY_NOWRITE")) { for (int &c : cn) c = 0; }                        // no C rows written: what the stores cost
     if (const char *e = getenv("FETCH_REPLAY_WGS")) p.wgs_per_cu = std::max(1, std::min(4, atoi(e)));       // workgroups per CU, over the plan's
     p.wgs = prop.multiProcessorCount * p.wgs_per_cu;
     p.wgs -= p.wgs % 8;
