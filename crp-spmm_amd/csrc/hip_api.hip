@@ -39,6 +39,10 @@ struct PanelDev
 // the row-panel kernel moved down (profiles/r04_team2_min_n.txt, variant 3 / 5: pwtk stand-in n = 80 0.138 / 0.146, n = 96 0.155 /
 // 0.151, n = 112 0.167 / 0.154; shell n = 64 0.120 / 0.119, n = 96 0.166 / 0.137; Queen stand-in n = 64 0.447 / 0.403, n = 96 0.531 / 0.444).
 constexpr int TEAM2_MIN_N = 96;
+// ... and for a FULL half-piece tile (61 .. 64 columns) since the value blocks are compact (round 4, item 7): the half-piece instance takes the
+// same time from 48 to 64 columns, the row-panel kernel's grows with them -- pwtk stand-in, variant 3 / 5: n = 48 0.0929 / 0.1093 ms, n = 64
+// 0.1134 / 0.1096, n = 80 0.1389 / 0.1378, n = 96 0.1546 / 0.1547 (profiles/r04_compact_ab.txt).
+constexpr int TEAM2_HALF_FULL_LO = 61, TEAM2_HALF_FULL_HI = 64;
 // ... where the row-panel format asks for more than 12 B row slices per row of A (Queen stand-in: 17.3; pwtk: 10.4), or the matrix has
 // no stride lattice (the row-panel kernel then runs without its team schedule).
 // From 48 columns since the HALF-piece instances (operands of at most 64 fp64 / 128 fp32 columns: 8 bytes per lane, one FMA per row
@@ -928,7 +932,8 @@ int crp_spmm_csr_f64(crp_csr_dev_p A, int layout, int n, const double *B0, long 
     // auto: from TEAM2_MIN_N columns on the LDS-sharing team kernel wherever teams share columns (against the best
     // other variant on the pwtk / shell / fem3d stand-ins: n = 128: 1.00 / 0.81 / 0.73 of its time, n = 256: 0.85 /
     // 0.65 / 0.63; at n = 96 -- a tile of 128 columns three quarters used -- 1.17 / 1.00 / 0.94, at n = 32 1.6 x)
-    if (variant == 0 && A->team2_pays && n >= A->team2_min_n && crp::spmm_team2_applicable(a)) v = 5;
+    const bool team2_width = n >= A->team2_min_n || (A->team2_min_n == TEAM2_MIN_N && n >= TEAM2_HALF_FULL_LO && n <= TEAM2_HALF_FULL_HI);
+    if (variant == 0 && A->team2_pays && team2_width && crp::spmm_team2_applicable(a)) v = 5;
     if (v == 5 && (!crp::spmm_team2_applicable(a) || A->nnz == 0 || A->nrow < 8)) v = 3;
     // narrow operands (24 <= n <= 64) whose R = 8 panels are mostly holes: the team kernel whose lane groups own rows (variant 7)
     {
@@ -1040,7 +1045,8 @@ int crp_csr_dev_resolved_variant(crp_csr_dev_p A, int n)
     if (A == NULL) return -1;
     int v = A->auto_variant;
     if (v >= 2 && n < 24) v = 1;
-    if (A->team2_pays && n >= A->team2_min_n && (n % 2 == 0)) v = 5;
+    const bool team2_width = n >= A->team2_min_n || (A->team2_min_n == TEAM2_MIN_N && n >= TEAM2_HALF_FULL_LO && n <= TEAM2_HALF_FULL_HI);
+    if (A->team2_pays && team2_width && (n % 2 == 0)) v = 5;
     else if (A->team2_pays && team2r_auto(A) && n >= 24 && n <= 64 && (n % 2 == 0) && A->nnz > 0 && A->nrow >= 8) v = 7;
     return v;
 }
