@@ -20,6 +20,13 @@ struct Plan
 };
 
 constexpr int RINGR = 4, D = 3;
+// cache policy of the DMAs (-DVPOL=.. value blocks, -DBPOL=.. row slices): 0 default, 1 sc0, 2 nt, 16 sc1 (and sums)
+#ifndef VPOL
+#define VPOL 0
+#endif
+#ifndef BPOL
+#define BPOL 0
+#endif
 typedef __attribute__((address_space(3))) void *lds_ptr;
 typedef const __attribute__((address_space(1))) void *glb_ptr;
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
@@ -64,8 +71,8 @@ __global__ __launch_bounds__(512) void replay_kernel(Plan p, const char *__restr
                 row = __builtin_amdgcn_readfirstlane(row);
                 const char *src = B + (long long) row * ROWB + lane * 16;
                 char *dst = ring + ((r & (RINGR - 1)) * S + wave) * ROWB;
-                __builtin_amdgcn_global_load_lds((glb_ptr) src, (lds_ptr) dst, 16, 0, 0);
-                if (ROWB == 2048) __builtin_amdgcn_global_load_lds((glb_ptr) (src + 1024), (lds_ptr) (dst + 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((glb_ptr) src, (lds_ptr) dst, 16, 0, BPOL);
+                if (ROWB == 2048) __builtin_amdgcn_global_load_lds((glb_ptr) (src + 1024), (lds_ptr) (dst + 1024), 16, 0, BPOL);
             }
             // the wave's value block of the round (streamed once); waves without a slot fetch three times as much of it, so that every
             // wave counts three DMAs per round.  Every DMA has its own place in LDS (the compiler orders DMAs to one address itself).
@@ -73,7 +80,7 @@ __global__ __launch_bounds__(512) void replay_kernel(Plan p, const char *__restr
             char *vdst = vblk + (((r & (RINGR - 1)) * 8 + wave) * 3) * VBLK;
             if (lane < p.alanes)
             {
-                __builtin_amdgcn_global_load_lds((glb_ptr) vsrc, (lds_ptr) vdst, 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((glb_ptr) vsrc, (lds_ptr) vdst, 16, 0, VPOL);
                 if (wave >= S)
                 {
                     __builtin_amdgcn_global_load_lds((glb_ptr) vsrc, (lds_ptr) (vdst + VBLK), 16, 0, 0);
