@@ -49,10 +49,14 @@ constexpr int TEAM2_HALF_FULL_LO = 61, TEAM2_HALF_FULL_HI = 64;
 // and part, four workgroups per CU; profiles/r04_half_piece_instances.txt, variant 3 / 5: Queen stand-in n = 48 0.424 / 0.339 ms,
 // n = 64 0.451 / 0.361; shell n = 64 0.124 / 0.108; pwtk stand-in n = 64 0.119 / 0.126: stays with the row-panel kernel).
 constexpr int TEAM2_MIN_N_DENSE = 48;
-// ... when fewer than 35 % of the (row, entry) pairs of the R = 8 panels are present: the row-panel format then stores mostly
-// zeros (8 values per entry) while the team kernel's value streams are compact (nlpkkt stand-in, fill 0.23, n = 96: 1.26 ms
-// against 1.47; at n = 64 -- half of the kernel's 128-column tile idle -- 1.23 against 1.14, so not below 80)
-constexpr int TEAM2_MIN_N_SPARSE = 80;
+// ... when fewer than 35 % of the (row, entry) pairs of the R = 8 panels are present (KKT systems): the row-panel format then stores mostly
+// zeros (8 values per entry) while the team kernel's value streams are compact.  From 33 columns since the half-piece instances and three
+// workgroups per CU (round 4): up to 32 columns the row-owner team kernel (variant 7, four rows' slices per wave instruction) is 2 x ahead;
+// above, variant 3 / 5 / 7 on the nlpkkt stand-in (profiles/r04_team2r_probes.txt): n = 34 0.971 / 0.784 / 0.833 ms, n = 48 1.016 / 0.801 /
+// 0.834, n = 64 1.096 / 0.849 / 0.839, n = 72 1.148 / 0.930 / -; at nlpkkt240 size variant 5 / 7: n = 40 12.81 / 13.53, n = 48 13.27 / 13.35,
+// n = 56 13.83 / 13.49, n = 64 13.72 / 13.91 -- the two-rows-per-lane-group format of variant 7 (n <= 64) buys nothing that the team format
+// the matrix has anyway does not, and costs 4 s of build and 4 GB of HBM at that size: variant 0 no longer takes it (it was 80 in round 3).
+constexpr int TEAM2_MIN_N_SPARSE = 33;
 // fp32: the only other fp32 kernel is the CSR row-group one, which the team kernel beats from 64 columns on (fem3d
 // stand-in, n = 64 / 128 / 192 / 256: 0.648 / 0.649 / 0.652 / 0.660 ms against 0.663 / 1.24 / 2.31 / 2.37)
 constexpr int TEAM2_MIN_N_F32 = 64;
@@ -126,7 +130,7 @@ struct crp_csr_dev
     bool      host_vals_stale = false;
     // The R = 8 panels in column order WITHOUT values (pcol, masks, slot map: 7 bytes per nonzero at fill 0.23) and the teams built on
     // them: shared by the team formats of this matrix (team2, team2r for <= 32 and <= 64 columns) -- a further operand width costs the
-    // streams of its format, not the panels and the clustering again.  Dropped once all three exist.
+    // streams of its format, not the panels and the clustering again.  Dropped once the two that variant 0 uses exist.
     std::unique_ptr<crp::PanelHost> skel8;
     crp::TeamSeed seed8;
 };
@@ -156,8 +160,10 @@ static const crp::PanelHost &panel_skeleton(crp_csr_dev *A)
 }
 static void drop_skeleton_when_done(crp_csr_dev *A)
 {
-    const bool r0 = A->team2r[0].built || A->team2r[0].refused, r1 = A->team2r[1].built || A->team2r[1].refused;
-    if (A->team2.built && r0 && r1)
+    // (the formats variant 0 can ask for: the team format and the row-owner format of n <= 32; an explicit variant 7 at 33 .. 64 columns
+    //  afterwards builds its panels and teams again)
+    const bool r0 = A->team2r[0].built || A->team2r[0].refused;
+    if (A->team2.built && r0)
     {
         A->skel8.reset();
         A->seed8 = crp::TeamSeed();

@@ -961,12 +961,14 @@ def test_team2r_kernel(crp, orc, gpu, n, variant):
         rp, ci, va = gen.kkt3d(14)
         m = len(rp) - 1
         A = hip.CsrDev(m, m, rp, ci, va)
-        assert lib.crp_csr_dev_resolved_variant(A.handle, n) == 7
+        # (up to 32 columns; above, the half-piece instances of the team kernel, variant 5, since round 4)
+        want = 7 if n <= 32 else 5
+        assert lib.crp_csr_dev_resolved_variant(A.handle, n) == want
         Bk = np.random.default_rng(n + 3).normal(size=(m, n))
         Cd = torch.empty((m, n), dtype=torch.float64, device=gpu)
         hip.spmm_csr(A, _t(Bk, gpu), Cd, n=n, variant=0)
         torch.cuda.synchronize()
-        assert lib.crp_spmm_variant_name(lib.crp_csr_dev_last_variant(A.handle)) == vname
+        assert lib.crp_csr_dev_last_variant(A.handle) == want
         assert orc.rel_fro_err(orc.spmm_csr(rp, ci, va, Bk), Cd.cpu().numpy()) <= FP64_TOL
         A.free()
         # ... and not for filled panels
