@@ -48,7 +48,11 @@ constexpr int TEAM2_HALF_FULL_LO = 61, TEAM2_HALF_FULL_HI = 64;
 // From 48 columns since the HALF-piece instances (operands of at most 64 fp64 / 128 fp32 columns: 8 bytes per lane, one FMA per row
 // and part, four workgroups per CU; profiles/r04_half_piece_instances.txt, variant 3 / 5: Queen stand-in n = 48 0.424 / 0.339 ms,
 // n = 64 0.451 / 0.361; shell n = 64 0.124 / 0.108; pwtk stand-in n = 64 0.119 / 0.126: stays with the row-panel kernel).
-constexpr int TEAM2_MIN_N_DENSE = 48;
+constexpr int TEAM2_MIN_N_NOLATTICE = 48;
+// ... dense row-panel formats from 33 columns: the half-piece instance takes the same time from 34 to 64 columns (Queen stand-in, variant 3 / 5,
+// compact values: n = 34 0.409 / 0.323 ms, n = 40 0.404 / 0.326; the shell stand-in, no lattice and 9 slices per row: 0.097 / 0.099 at both -- it
+// keeps 48); at 32 columns the narrow kernel is ahead (0.235 / 0.314).
+constexpr int TEAM2_MIN_N_DENSE = 33;
 // ... when fewer than 35 % of the (row, entry) pairs of the R = 8 panels are present (KKT systems): the row-panel format then stores mostly
 // zeros (8 values per entry) while the team kernel's value streams are compact.  From 33 columns since the half-piece instances and three
 // workgroups per CU (round 4): up to 32 columns the row-owner team kernel (variant 7, four rows' slices per wave instruction) is 2 x ahead;
@@ -729,12 +733,13 @@ static int csr_dev_create_impl(int nrow, int ncol, const int *rowptr, const int 
             double D1 = 0, D2 = 0;
             int M = 0;
             const bool lat = nrow >= 4096 && crp::detect_stride_lattice(nrow, fmt_rowptr(A), fmt_colidx(A), 8, &D1, &D2, &M);
-            if (!lat || (double) e8 > 12.0 * (double) nrow) A->team2_min_n = TEAM2_MIN_N_DENSE;
+            if (!lat) A->team2_min_n = TEAM2_MIN_N_NOLATTICE;
+            if ((double) e8 > 12.0 * (double) nrow) A->team2_min_n = TEAM2_MIN_N_DENSE;
         }
         if ((double) nnz < 0.35 * 8.0 * (double) e8)
         {
             A->team2_min_n = TEAM2_MIN_N_SPARSE;
-            // ... and at 24 .. 64 columns such panels go to the row-owner team kernel (variant 7, csrc/team2r_kernel.hip): nlpkkt
+            // ... and at 24 .. 32 columns (24 .. 64 until the team kernel's half-piece instances: TEAM2_MIN_N_SPARSE) such panels go to the row-owner team kernel (variant 7, csrc/team2r_kernel.hip): nlpkkt
             // stand-in 0.388 / 0.839 ms at n = 32 / 64 against 0.546 / 1.04 of the narrow and row-panel kernels, at nlpkkt240 size
             // 6.58 / 14.0 against 8.85 / 18.2 (pwtk stand-in, fill 0.61: 0.075 against 0.062 -- stays).  CRPSPMM_TEAM2R=0|1 forces.
             A->team2r_pays = true;

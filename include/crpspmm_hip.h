@@ -128,8 +128,8 @@ int crp_csr_dev_auto_variant(crp_csr_dev_p A);
  * every row's products are still summed in the kernel variant's own order. */
 int crp_csr_dev_reordered(crp_csr_dev_p A);
 /* the variant `variant = 0` (auto) runs for a row-major fp64 product of n columns with 16-byte aligned operands and even n,
- * ldB, ldC: the create-time choice (crp_csr_dev_auto_variant), replaced by 5 (team2-R8) from 96 columns on (from 48 when the
- * row-panel format would ask for more than 12 B row slices per row of A or the matrix has no stride lattice; from 33 when
+ * ldB, ldC: the create-time choice (crp_csr_dev_auto_variant), replaced by 5 (team2-R8) from 96 columns on (from 33 when the
+ * row-panel format would ask for more than 12 B row slices per row of A, from 48 when the matrix has no stride lattice; from 33 when
  * fewer than 35 % of the (row, entry) pairs of the R = 8 panels exist; for 61 .. 64 columns otherwise) where 64 consecutive rows share columns, and by 1
  * below 24 columns.  Operands that are not aligned like that fall back (5 -> 3 -> 1): what a product actually launched is
  * crp_csr_dev_last_variant().  Variants 4 and 6 (the round-1 LDS team kernel, the narrow team kernel of round 3) were
