@@ -61,9 +61,12 @@ constexpr int TEAM2_MIN_N_DENSE = 33;
 // n = 56 13.83 / 13.49, n = 64 13.72 / 13.91 -- the two-rows-per-lane-group format of variant 7 (n <= 64) buys nothing that the team format
 // the matrix has anyway does not, and costs 4 s of build and 4 GB of HBM at that size: variant 0 no longer takes it (it was 80 in round 3).
 constexpr int TEAM2_MIN_N_SPARSE = 33;
-// fp32: the only other fp32 kernel is the CSR row-group one, which the team kernel beats from 64 columns on (fem3d
-// stand-in, n = 64 / 128 / 192 / 256: 0.648 / 0.649 / 0.652 / 0.660 ms against 0.663 / 1.24 / 2.31 / 2.37)
-constexpr int TEAM2_MIN_N_F32 = 64;
+// fp32: the only other fp32 kernel is the CSR row-group one.  Since the half-piece instances (at most 128 fp32 columns: one time from 32 to
+// 128) the team kernel is level or ahead from 32 columns -- row-group / team, ms (profiles/r04_compact_ab.txt, fp32 block): Queen stand-in n = 24
+// 0.377 / 0.311, 32 0.385 / 0.310, 48 0.643 / 0.312, 64 0.662 / 0.316; shell 32 0.116 / 0.097, 48 0.177 / 0.098; pwtk stand-in 24 0.102 / 0.107, 32 0.107 /
+// 0.108, 48 0.167 / 0.108 -- except on mostly-hole panels, where a part is 1.8 rows: nlpkkt stand-in 32 0.385 / 0.720, 48 0.664 / 0.734, 64 0.706 /
+// 0.742, 96 1.301 / 0.789, 128 1.365 / 0.842 (it was 64 for every matrix).
+constexpr int TEAM2_MIN_N_F32 = 32, TEAM2_MIN_N_F32_SPARSE = 65;
 struct Team2Dev
 {
     bool built = false;
@@ -1030,7 +1033,7 @@ int crp_spmm_csr_f32(crp_csr_dev_p A, int n, const float *B0, long long ldB0, co
     crp::SpmmArgsF32 a;
     a.nrow = A->nrow; a.n = n; a.rowptr = A->rowptr; a.colidx = A->colidx; a.val = A->val32;
     a.B0 = B0; a.ldB0 = ldB0; a.B1 = B1; a.ldB1 = ldB1; a.C = C; a.ldC = ldC; a.rowmap = A->rowmap;
-    const bool team = (variant == 5 || (variant == 0 && A->team2_pays && n >= TEAM2_MIN_N_F32)) && A->nnz > 0 && A->nrow >= 8 &&
+    const bool team = (variant == 5 || (variant == 0 && A->team2_pays && n >= (A->team2r_pays ? TEAM2_MIN_N_F32_SPARSE : TEAM2_MIN_N_F32))) && A->nnz > 0 && A->nrow >= 8 &&
                       crp::spmm_team2_applicable_f32(a);
     A->last_variant = team ? 5 : 1;
     if (!team) return (int) crp::spmm_rm_f32_rowgroup(a, (hipStream_t) stream);

@@ -115,7 +115,7 @@ int crp_csr_dev_row_part_comm_size(crp_csr_dev_p A, int nblk, const int *rblk_pt
 /* The fp32 value path (BASELINE configs[3]; the reference itself is fp64-only, src/rowpara_spmm.h:28): the same
  * product with A's values, B and C in fp32 and fp32 FMAs, row-major operands.  A is the matrix created from fp64
  * values; its fp32 copies are derived on first use and follow crp_csr_dev_update_values.  variant 0 = auto (the
- * fp32 instance of the team kernel from 64 columns on where teams share columns and the operands are 16-byte
+ * fp32 instance of the team kernel from 32 columns on (from 65 on mostly-hole panels) where teams share columns and the operands are 16-byte
  * aligned with n, ldB, ldC multiples of 4; else the fp32 CSR row-group kernel), 1 = row-group, 5 = team kernel.
  * Parity is defined against the fp64 product: relative Frobenius error <= 1e-5 (tests/test_gpu_parity.py). */
 int crp_spmm_csr_f32(crp_csr_dev_p A, int n, const float *B0, long long ldB0, const float *B1, long long ldB1, float *C,
