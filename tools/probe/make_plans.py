@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--L", type=int, default=400)
     ap.add_argument("--wgs", type=int, default=3, help="workgroups per CU of the strip plan")
     ap.add_argument("--orders", action="store_true", help="also teams_orders.bin: the teams under alternative processing orders")
+    ap.add_argument("--strides", type=int, nargs=2, default=[1200, 36000], help="--orders: the lattice's two strides in rows (pwtk stand-in 1200 36000; fem3d(56) 168 9408)")
     ap.add_argument("--matrix", default="pwtk", help="pwtk | shell | fem3d | kkt (bench.py's stand-ins; anything but pwtk: the teams plan only)")
     a = ap.parse_args()
     os.makedirs(a.outdir, exist_ok=True)
@@ -91,13 +92,16 @@ def main():
         # runs of equal rounds like the format's own.  Queue 0 is the format's grid.
         nt = len(units)
         first = np.array([int(tp[g][tp[g] >= 0].min()) * 8 for g in range(nt)])
-        A, Bc, Tt = ((first % 36000) // 1200) // 2, (first // 36000) // 2, (first % 1200) // 16
+        D1, D2 = a.strides
+        A, Bc, Tt = ((first % D2) // D1) // 2, (first // D2) // 2, (first % D1) // 16
         na, nb = int(A.max()) + 1, int(Bc.max()) + 1
         cands, names, seen = [queues], ["format"], set()
-        for (pa, pb) in [(8, 1), (4, 2), (2, 4)]:
+        boxes = [(8, 1), (4, 2), (2, 4)] + ([(1, 8)] if nb >= 8 else [])
+        blocks = [(1, 1), (2, 1), (1, 2), (2, 2), (4, 2), (1000, 1000)] + ([(2, 4), (4, 4), (4, 6), (6, 4), (8, 8)] if nb >= 8 else [])
+        for (pa, pb) in boxes:
             box = np.minimum(A * pa // na, pa - 1) * pb + np.minimum(Bc * pb // nb, pb - 1)
             for bt in [1, 2, 3, 4, 6, 8, 12, 1000]:
-                for (ba, bb) in [(1, 1), (2, 1), (1, 2), (2, 2), (4, 2), (1000, 1000)]:
+                for (ba, bb) in blocks:
                     for flags in range(4):
                         tb, ab_, bb_ = Tt // bt, A // ba, Bc // bb
                         inner = (A, Bc, Tt) if flags & 1 else (Tt, A, Bc)             # fastest key first
@@ -109,8 +113,8 @@ def main():
                         seen.add(key)
                         cands.append(l2sim.xcd_queues(rounds, [int(g) for g in order]))
                         names.append("boxes %dx%d blocks %dx%dx%d flags %d" % (pa, pb, bt, ba, bb, flags))
-        write_plan(os.path.join(a.outdir, "teams_orders.bin"), 8, m, len(units) * 64, 2, 1, max(1, min(8, int(round(ab / 16)))), max(1, reads), units, cands, cbase, cn)
-        with open(os.path.join(a.outdir, "teams_orders.txt"), "w") as f:
+        write_plan(os.path.join(a.outdir, "teams%s_orders.bin" % tag), 8, k, len(units) * 64, 2, 1, max(1, min(8, int(round(ab / 16)))), max(1, reads), units, cands, cbase, cn)
+        with open(os.path.join(a.outdir, "teams%s_orders.txt" % tag), "w") as f:
             for k, nm in enumerate(names):
                 f.write("%d %s\n" % (k, nm))
         print("  %d candidate orders" % len(cands))
