@@ -393,6 +393,12 @@ static int ensure_team2r(crp_csr_dev *A, hipStream_t stream, int G)
     return 0;
 }
 
+// the widths at which variant 0 takes the team kernel on this matrix (fp64): from its class's threshold on, and a full half-piece tile
+static bool team2_width(const crp_csr_dev *A, int n)
+{
+    return n >= A->team2_min_n || (A->team2_min_n == TEAM2_MIN_N && n >= TEAM2_HALF_FULL_LO && n <= TEAM2_HALF_FULL_HI);
+}
+
 // variant 0 on narrow operands: the row-owner team kernel where the R = 8 panels are mostly holes (CRPSPMM_TEAM2R=0|1 forces)
 static bool team2r_auto(const crp_csr_dev *A)
 {
@@ -946,8 +952,7 @@ int crp_spmm_csr_f64(crp_csr_dev_p A, int layout, int n, const double *B0, long 
     // auto: from TEAM2_MIN_N columns on the LDS-sharing team kernel wherever teams share columns (against the best
     // other variant on the pwtk / shell / fem3d stand-ins: n = 128: 1.00 / 0.81 / 0.73 of its time, n = 256: 0.85 /
     // 0.65 / 0.63; at n = 96 -- a tile of 128 columns three quarters used -- 1.17 / 1.00 / 0.94, at n = 32 1.6 x)
-    const bool team2_width = n >= A->team2_min_n || (A->team2_min_n == TEAM2_MIN_N && n >= TEAM2_HALF_FULL_LO && n <= TEAM2_HALF_FULL_HI);
-    if (variant == 0 && A->team2_pays && team2_width && crp::spmm_team2_applicable(a)) v = 5;
+    if (variant == 0 && A->team2_pays && team2_width(A, n) && crp::spmm_team2_applicable(a)) v = 5;
     if (v == 5 && (!crp::spmm_team2_applicable(a) || A->nnz == 0 || A->nrow < 8)) v = 3;
     // narrow operands (24 <= n <= 64) whose R = 8 panels are mostly holes: the team kernel whose lane groups own rows (variant 7)
     {
@@ -1059,8 +1064,7 @@ int crp_csr_dev_resolved_variant(crp_csr_dev_p A, int n)
     if (A == NULL) return -1;
     int v = A->auto_variant;
     if (v >= 2 && n < 24) v = 1;
-    const bool team2_width = n >= A->team2_min_n || (A->team2_min_n == TEAM2_MIN_N && n >= TEAM2_HALF_FULL_LO && n <= TEAM2_HALF_FULL_HI);
-    if (A->team2_pays && team2_width && (n % 2 == 0)) v = 5;
+    if (A->team2_pays && team2_width(A, n) && (n % 2 == 0)) v = 5;
     else if (A->team2_pays && team2r_auto(A) && n >= 24 && n <= 64 && (n % 2 == 0) && A->nnz > 0 && A->nrow >= 8) v = 7;
     return v;
 }
